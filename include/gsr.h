@@ -1,0 +1,120 @@
+/* gsr.h — C ABI of libgsr_hip.so, the MI355X (gfx950) differentiable 3D-Gaussian rasterizer.
+ *
+ * This is the drop-in boundary for the one native operator PF3plat depends on: the external
+ * CUDA extension `diff_gaussian_rasterization` (reference requirements.txt:2), reached from
+ * src/model/decoder/cuda_splatting.py:5-8 (import), :99-124 and :192-217 (call sites).  The
+ * upstream extension exposes three pybind entry points (`rasterize_gaussians`,
+ * `rasterize_gaussians_backward`, `mark_visible`; SURVEY.md §2 #6, Appendix A "Python-side");
+ * the entry points below replace them one for one, with plain pointers and sizes instead of
+ * torch tensors, and with two MI355X-first extensions the reference's per-view Python loop
+ * (cuda_splatting.py:91-126) cannot express:
+ *   - a call renders V views in one launch chain; views are grouped in `num_sets` sets that share
+ *     one copy of the Gaussian arrays (kills decoder_splatting_cuda.py:52-56's V-fold `repeat`);
+ *   - the scale-invariant pre-scale of cuda_splatting.py:64-71 is a per-view factor applied on
+ *     load, and an optional extra blended channel carries the depth image of :226-269 in the same
+ *     pass instead of a second raster pass.
+ *
+ * Conventions (all pointers are DEVICE pointers owned by the caller unless noted; the library
+ * allocates nothing persistent, enqueues all work on `stream`, never synchronises the host, never
+ * throws; every entry point returns GSR_OK or a negative error code):
+ *   means     (num_sets, N, 3)   fp32 world-space centres                     (means3D)
+ *   cov6      (num_sets, N, 6)   fp32 xx,xy,xz,yy,yz,zz                       (cov3D_precomp)
+ *   opacities (num_sets, N)      fp32 in (0,1)
+ *   colors    (num_sets, N, M, 3) SH coefficients if sh_coeffs = M > 0        (shs)
+ *             (num_sets, N, 3)   precomputed RGB if sh_coeffs == 0            (colors_precomp)
+ *   extra     (V, N)             optional per-(view,Gaussian) scalar blended as a 4th channel
+ *   views     (V) GsrView        cameras, in set-major order: view v uses set v / views_per_set
+ *   out_color (V, 3, H, W), out_extra (V, H, W), radii (V, N) int32
+ */
+#ifndef GSR_H_
+#define GSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK 0
+#define GSR_ERR_INVALID_ARGUMENT (-1)
+#define GSR_ERR_LAUNCH (-2)
+#define GSR_ERR_UNSUPPORTED (-3)
+#define GSR_ABI_VERSION 1
+
+/* One camera = the non-tensor fields of upstream's GaussianRasterizationSettings
+ * (constructed at cuda_splatting.py:99-112), 48 floats = 192 bytes. */
+typedef struct GsrView {
+  float viewmatrix[16];  /* world->camera, transposed (row-vector convention), cuda_splatting.py:86,106 */
+  float projmatrix[16];  /* full projection = view @ proj, transposed, cuda_splatting.py:87,107 */
+  float campos[3];       /* camera centre in (pre-scaled) world units, cuda_splatting.py:109 */
+  float tanfovx, tanfovy;
+  float bg[3];
+  float scale;           /* scale-invariant factor s applied on load: mean*s (cuda_splatting.py:70) */
+  float scale2;          /* s*s computed by the caller in fp32: cov*s2 (cuda_splatting.py:69) */
+  float scale_modifier;  /* upstream scale_modifier (only with scales/rotations; 1.0) */
+  float reserved[5];
+} GsrView;
+
+typedef struct GsrDims {
+  int32_t abi_version;    /* GSR_ABI_VERSION */
+  int32_t num_views;      /* V = num_sets * views_per_set */
+  int32_t num_sets;       /* independent Gaussian sets (scenes) */
+  int32_t views_per_set;  /* views sharing one set */
+  int32_t num_gaussians;  /* N per set */
+  int32_t height, width;
+  int32_t sh_degree;      /* active degree D (settings.sh_degree) */
+  int32_t sh_coeffs;      /* M coefficients in memory; 0 => colours are precomputed RGB */
+  int32_t max_sh_eval;    /* highest SH band evaluated (4; 3 = vanilla upstream) */
+  int32_t has_extra;      /* 1 => `extra`/`out_extra` are used */
+  int32_t flags;          /* bit0: prefiltered (ignored, as upstream without debug); bit1: debug */
+  int64_t pair_capacity;  /* capacity of the (tile,splat) pair workspaces, in pairs */
+} GsrDims;
+
+/* Host-visible status block written by gsr_forward at the start of the `bin` workspace. */
+typedef struct GsrStatus {
+  uint64_t num_pairs;     /* total (8x8-tile, splat) pairs this call needs ("num_rendered") */
+  uint32_t overflow;      /* 1 => num_pairs > pair_capacity: nothing was blended, call again bigger */
+  uint32_t max_list;      /* longest per-tile list */
+  uint64_t reserved[6];
+} GsrStatus;
+
+/* ABI/arch self-description; safe without a GPU. */
+int gsr_abi_version(void);
+const char* gsr_build_info(void);
+
+/* Workspace sizes in bytes for a call with these dims (host-only arithmetic; no GPU needed).
+ * geom: per-(view,Gaussian) projected records; bin: status + per-tile counters/ranges + pair
+ * lists (scales with pair_capacity); img: per-pixel final transmittance + contributor count.
+ * Replaces upstream's geomBuffer/binningBuffer/imgBuffer resize callbacks. */
+int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes);
+
+/* Forward: replaces upstream `_C.rasterize_gaussians` (called through
+ * GaussianRasterizer.forward at cuda_splatting.py:116-124).  `extra`/`out_extra` may be NULL when
+ * has_extra == 0.  geom/bin/img must stay alive and untouched until gsr_backward has run. */
+int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                const float* opacities, const float* colors, const float* extra, float* out_color,
+                float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream);
+
+/* Backward: replaces upstream `_C.rasterize_gaussians_backward` (autograd of the call above).
+ * dL_dcolor (V,3,H,W); dL_dextra_img (V,H,W) or NULL.  Outputs are fully written (zeros for culled
+ * Gaussians): dL_dmeans (num_sets,N,3), dL_dcov6 (num_sets,N,6), dL_dopacities (num_sets,N),
+ * dL_dcolors (same shape as colors), dL_dextra (V,N) or NULL, dL_dmeans2D (V,N,3) or NULL.
+ * Gradients of views sharing a set are summed, including the scale / scale2 chain factors.
+ * `scratch` holds V*N*GSR_SCREEN_GRAD_FLOATS floats of screen-space accumulators. */
+#define GSR_SCREEN_GRAD_FLOATS 12
+int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                 const float* opacities, const float* colors, const float* extra, const void* geom,
+                 const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
+                 void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
+                 float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream);
+
+/* Replaces upstream `_C.mark_visible` (GaussianRasterizer.markVisible): present[i] = 1 iff the
+ * Gaussian passes the near-plane test of view 0 of its set (p_view.z > 0.2). */
+int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_ */

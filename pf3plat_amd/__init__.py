@@ -1,0 +1,21 @@
+"""pf3plat_amd — MI355X-native differentiable 3D-Gaussian rasterizer behind PF3plat's
+`cuda_splatting` operator surface (C ABI in include/gsr.h)."""
+from .types import DecoderOutput, DepthRenderingMode, Gaussians  # noqa: F401
+from .rasterizer import (  # noqa: F401
+    GaussianRasterizationSettings,
+    GaussianRasterizer,
+    RasterConfig,
+    get_backend,
+    pack_views,
+    rasterize_views,
+)
+from .splatting import (  # noqa: F401
+    render_cuda,
+    render_cuda_orthographic,
+    render_depth_cuda,
+    render_views,
+)
+from .decoder import DecoderSplattingCUDA, DecoderSplattingCUDACfg, get_decoder  # noqa: F401
+from .geometry import depth_to_relative_disparity, get_fov, get_projection_matrix, homogenize_points  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,104 @@
+"""Loader for the in-tree HIP library `pf3plat_amd/libgsr_hip.so` (C ABI: include/gsr.h).
+
+The product path has no CPU fallback: if the library is missing, cannot be loaded, or reports a
+different ABI version, every raster call raises.  `build()` cross-compiles it with hipcc for gfx950
+(works without a GPU); the built .so stays in-tree so it travels to the GPU box.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+REPO_ROOT = os.path.dirname(_HERE)
+SRC = os.path.join(_HERE, "csrc", "gsr_hip.hip")
+HEADER = os.path.join(REPO_ROOT, "include", "gsr.h")
+LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+GSR_ABI_VERSION = 1
+SCREEN_GRAD_FLOATS = 12
+
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+
+class GsrDims(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32), ("num_views", ctypes.c_int32), ("num_sets", ctypes.c_int32),
+        ("views_per_set", ctypes.c_int32), ("num_gaussians", ctypes.c_int32), ("height", ctypes.c_int32),
+        ("width", ctypes.c_int32), ("sh_degree", ctypes.c_int32), ("sh_coeffs", ctypes.c_int32),
+        ("max_sh_eval", ctypes.c_int32), ("has_extra", ctypes.c_int32), ("flags", ctypes.c_int32),
+        ("pair_capacity", ctypes.c_int64),
+    ]
+
+
+def find_hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
+
+
+def is_stale() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(s) > t for s in (SRC, HEADER))
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/gsr_hip.hip -> libgsr_hip.so for gfx950 (seconds; no GPU needed)."""
+    if force or is_stale():
+        cmd = [find_hipcc(), *HIPCC_FLAGS, "-o", LIB_PATH + ".tmp", SRC]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
+        os.replace(LIB_PATH + ".tmp", LIB_PATH)
+        if verbose:
+            print("built", LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library (after torch, so both share torch's libamdhip64) and bind signatures."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first; our NEEDED entry resolves to the same object)
+
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: the MI355X rasterizer has no fallback path. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc) first."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64)
+    szp = ctypes.POINTER(ctypes.c_size_t)
+    dp = ctypes.POINTER(GsrDims)
+    lib.gsr_abi_version.restype = ctypes.c_int
+    lib.gsr_abi_version.argtypes = []
+    lib.gsr_build_info.restype = ctypes.c_char_p
+    lib.gsr_build_info.argtypes = []
+    lib.gsr_workspace_sizes.restype = ctypes.c_int
+    lib.gsr_workspace_sizes.argtypes = [dp, szp, szp, szp]
+    lib.gsr_workspace_layout.restype = ctypes.c_int
+    lib.gsr_workspace_layout.argtypes = [dp, i64p]
+    lib.gsr_forward.restype = ctypes.c_int
+    lib.gsr_forward.argtypes = [dp] + [vp] * 13
+    lib.gsr_backward.restype = ctypes.c_int
+    lib.gsr_backward.argtypes = [dp] + [vp] * 19
+    lib.gsr_mark_visible.restype = ctypes.c_int
+    lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
+    if lib.gsr_abi_version() != GSR_ABI_VERSION:
+        raise RuntimeError(f"libgsr_hip.so ABI {lib.gsr_abi_version()} != expected {GSR_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = (
+    "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
+    "gsr_backward", "gsr_mark_visible",
+)

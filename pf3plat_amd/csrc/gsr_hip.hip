@@ -1,0 +1,1038 @@
+// gsr_hip.hip — MI355X (gfx950 / CDNA4) differentiable 3D-Gaussian rasterizer, C ABI in include/gsr.h.
+//
+// Replaces, behind the same operator surface, the external CUDA extension the reference calls at
+// src/model/decoder/cuda_splatting.py:113-124 (forward) and through autograd (backward).  The
+// arithmetic it must reproduce is restated in oracle/gsr_oracle.hpp; this
+// file is not a translation of the CUDA package's structure:
+//
+//   * one launch chain renders V views (grid.y / per-view tile ranges) instead of one chain per view;
+//   * tiles are 8x8 pixels = ONE 64-lane wavefront per tile: no block barriers in the blend loops,
+//     wave-uniform early-out, per-splat gradients reduced across the wavefront before a single
+//     atomic per value.  Membership keeps the reference's rule (a splat reaches a pixel iff the
+//     pixel's 16x16 parent tile is inside the ceil(3 sigma) rect) and then drops (8x8 tile, splat)
+//     pairs that provably cannot reach alpha >= 1/255 anywhere in the tile (exact min of the conic
+//     quadratic over the tile box) - a result-preserving cull;
+//   * binning is a counting sort by tile (64-way replicated counters -> wave scan -> slot scatter)
+//     followed by a per-tile depth sort in LDS (64-bit key = depth bits : Gaussian index, so ties
+//     break by index as the reference's stable radix sort does); no global 64-bit radix sort and
+//     no device->host read of the pair count;
+//   * SH coefficients (300 of the ~350 input bytes per Gaussian) are staged wave-cooperatively
+//     through LDS with 16-byte coalesced loads and read once per set for all of its views in backward.
+//
+// Built with -ffp-contract=off: projection / EWA / SH arithmetic then evaluates the same expression
+// trees as the fp32 oracle (IEEE +,-,*,/ and sqrt are correctly rounded on both sides).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/gsr.h"
+
+namespace {
+
+constexpr int kNRep = 64;         // replicated tile counters (= one wavefront scans a tile's replicas)
+constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
+constexpr float kNear = 0.2f;     // [EXT] auxiliary.h in_frustum: p_view.z <= 0.2f culls
+
+struct __attribute__((aligned(16))) GeomRec {  // 48 B per (view, Gaussian)
+  float4 q0;  // x, y, conic a, conic b
+  float4 q1;  // conic c, opacity, r, g
+  float4 q2;  // b, extra, depth, bits(radius | clamped << 28)
+};
+
+struct Grid {
+  int W, H, gx16, gy16, sgx, sgy, sw, sh, T;  // sw/sh: 8x8 tiles that contain at least one pixel
+};
+
+__host__ __device__ inline Grid make_grid(int W, int H) {
+  Grid g;
+  g.W = W; g.H = H;
+  g.gx16 = (W + 15) / 16; g.gy16 = (H + 15) / 16;
+  g.sgx = 2 * g.gx16; g.sgy = 2 * g.gy16;
+  g.sw = (W + 7) / 8; g.sh = (H + 7) / 8;
+  g.T = g.sgx * g.sgy;
+  return g;
+}
+
+struct Layout {
+  size_t geom_bytes, bin_bytes, img_bytes;
+  size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list;  // in bin
+  size_t o_finalT, o_ncontrib;                                   // in img
+};
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+Layout make_layout(const GsrDims& d) {
+  Layout L;
+  const Grid g = make_grid(d.width, d.height);
+  const size_t V = d.num_views, N = d.num_gaussians, VT = V * (size_t)g.T;
+  const size_t cap = d.pair_capacity > 0 ? (size_t)d.pair_capacity : 0;
+  L.geom_bytes = align_up(V * N * sizeof(GeomRec), 256);
+  size_t o = 0;
+  L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
+  L.o_counts = o; o = align_up(o + VT * kNRep * 4, 256);
+  L.o_total = o; o = align_up(o + VT * 4, 256);
+  L.o_ranges = o; o = align_up(o + VT * 8, 256);
+  L.o_keys = o; o = align_up(o + cap * 8, 256);
+  L.o_list = o; o = align_up(o + cap * 4, 256);
+  L.bin_bytes = o;
+  const size_t px = V * (size_t)d.height * d.width;
+  L.o_finalT = 0;
+  L.o_ncontrib = align_up(px * 4, 256);
+  L.img_bytes = align_up(L.o_ncontrib + px * 4, 256);
+  return L;
+}
+
+struct Params {
+  GsrDims d;
+  Grid g;
+  const GsrView* views;
+  const float *means, *cov6, *opac, *colors, *extra;
+  float* out_color;
+  float* out_extra;
+  int32_t* radii;
+  GeomRec* geom;
+  GsrStatus* status;
+  uint32_t* counts;
+  uint32_t* tile_total;
+  uint2* ranges;
+  unsigned long long* keys;
+  uint32_t* point_list;
+  float* final_T;
+  uint32_t* n_contrib;
+  // backward only
+  const float *dL_dcolor, *dL_dextra_img;
+  float* scratch;
+  float *dL_dmeans, *dL_dcov6, *dL_dopac, *dL_dcolors, *dL_dextra, *dL_dmeans2D;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only), so give
+// each XCD a contiguous run of tiles - neighbouring tiles gather the same splat records from one L2.
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+  const int q = n >> 3, r = n & 7;
+  const int xcd = b & 7, k = b >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + k;
+}
+
+// Real-SH polynomial basis and its x/y/z partials, visited in coefficient order with compile-time k.
+// Same expression trees as oracle/gsr_oracle.hpp sh_basis / sh_basis_grad ([EXT] forward.cu
+// computeColorFromSH, backward.cu computeColorFromSH; band 4 per SURVEY.md Appendix A.1).
+template <class F>
+__device__ __forceinline__ void sh_visit(int deg, float x, float y, float z, F&& f) {
+  constexpr float C0 = 0.28209479177387814f, C1 = 0.4886025119029199f;
+  constexpr float C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
+                  C23 = -1.0925484305920792f, C24 = 0.5462742152960396f;
+  constexpr float C30 = -0.5900435899266435f, C31 = 2.890611442640554f, C32 = -0.4570457994644658f,
+                  C33 = 0.3731763325901154f, C34 = -0.4570457994644658f, C35 = 1.445305721320277f,
+                  C36 = -0.5900435899266435f;
+  constexpr float C40 = 2.5033429417967046f, C41 = -1.7701307697799304f, C42 = 0.9461746957575601f,
+                  C43 = -0.6690465435572892f, C44 = 0.10578554691520431f, C45 = -0.6690465435572892f,
+                  C46 = 0.47308734787878004f, C47 = -1.7701307697799304f, C48 = 0.6258357354491761f;
+  f(0, C0, 0.f, 0.f, 0.f);
+  if (deg > 0) {
+    f(1, -C1 * y, 0.f, -C1, 0.f);
+    f(2, C1 * z, 0.f, 0.f, C1);
+    f(3, -C1 * x, -C1, 0.f, 0.f);
+    if (deg > 1) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      f(4, C20 * xy, C20 * y, C20 * x, 0.f);
+      f(5, C21 * yz, 0.f, C21 * z, C21 * y);
+      f(6, C22 * (2.f * zz - xx - yy), C22 * -2.f * x, C22 * -2.f * y, C22 * 4.f * z);
+      f(7, C23 * xz, C23 * z, 0.f, C23 * x);
+      f(8, C24 * (xx - yy), C24 * 2.f * x, C24 * -2.f * y, 0.f);
+      if (deg > 2) {
+        f(9, C30 * y * (3.f * xx - yy), C30 * 6.f * xy, C30 * (3.f * xx - 3.f * yy), 0.f);
+        f(10, C31 * xy * z, C31 * yz, C31 * xz, C31 * xy);
+        f(11, C32 * y * (4.f * zz - xx - yy), C32 * -2.f * xy, C32 * (4.f * zz - xx - 3.f * yy), C32 * 8.f * yz);
+        f(12, C33 * z * (2.f * zz - 3.f * xx - 3.f * yy), C33 * -6.f * xz, C33 * -6.f * yz,
+          C33 * (6.f * zz - 3.f * xx - 3.f * yy));
+        f(13, C34 * x * (4.f * zz - xx - yy), C34 * (4.f * zz - 3.f * xx - yy), C34 * -2.f * xy, C34 * 8.f * xz);
+        f(14, C35 * z * (xx - yy), C35 * 2.f * xz, C35 * -2.f * yz, C35 * (xx - yy));
+        f(15, C36 * x * (xx - 3.f * yy), C36 * (3.f * xx - 3.f * yy), C36 * -6.f * xy, 0.f);
+        if (deg > 3) {
+          f(16, C40 * xy * (xx - yy), C40 * (3.f * xx * y - yy * y), C40 * (xx * x - 3.f * x * yy), 0.f);
+          f(17, C41 * yz * (3.f * xx - yy), C41 * 6.f * xy * z, C41 * z * (3.f * xx - 3.f * yy), C41 * y * (3.f * xx - yy));
+          f(18, C42 * xy * (7.f * zz - 1.f), C42 * y * (7.f * zz - 1.f), C42 * x * (7.f * zz - 1.f), C42 * 14.f * xy * z);
+          f(19, C43 * yz * (7.f * zz - 3.f), 0.f, C43 * z * (7.f * zz - 3.f), C43 * y * (21.f * zz - 3.f));
+          f(20, C44 * (zz * (35.f * zz - 30.f) + 3.f), 0.f, 0.f, C44 * (140.f * zz * z - 60.f * z));
+          f(21, C45 * xz * (7.f * zz - 3.f), C45 * z * (7.f * zz - 3.f), 0.f, C45 * x * (21.f * zz - 3.f));
+          f(22, C46 * (xx - yy) * (7.f * zz - 1.f), C46 * 2.f * x * (7.f * zz - 1.f), C46 * -2.f * y * (7.f * zz - 1.f),
+            C46 * 14.f * z * (xx - yy));
+          f(23, C47 * xz * (xx - 3.f * yy), C47 * z * (3.f * xx - 3.f * yy), C47 * -6.f * xy * z, C47 * x * (xx - 3.f * yy));
+          f(24, C48 * (xx * (xx - 3.f * yy) - yy * (3.f * xx - yy)), C48 * (4.f * xx * x - 12.f * x * yy),
+            C48 * (4.f * yy * y - 12.f * xx * y), 0.f);
+        }
+      }
+    }
+  }
+}
+
+// EWA projection pieces shared by forward and backward ([EXT] forward.cu computeCov2D);
+// same expression trees as oracle cov2d_parts.
+struct Cov2D {
+  float t0, t1, t2;
+  float M[6];
+  float a, b, c;
+  float fx, fy;
+  bool xcl, ycl;
+};
+
+__device__ __forceinline__ void cov2d_parts(const float mx, const float my, const float mz, const float* cov6,
+                                            const GsrView& cam, int W, int H, Cov2D& o) {
+  const float* v = cam.viewmatrix;
+  float t0 = v[0] * mx + v[4] * my + v[8] * mz + v[12];
+  float t1 = v[1] * mx + v[5] * my + v[9] * mz + v[13];
+  const float t2 = v[2] * mx + v[6] * my + v[10] * mz + v[14];
+  const float limx = 1.3f * cam.tanfovx, limy = 1.3f * cam.tanfovy;
+  const float txtz = t0 / t2, tytz = t1 / t2;
+  o.xcl = (txtz < -limx) || (txtz > limx);
+  o.ycl = (tytz < -limy) || (tytz > limy);
+  t0 = fminf(limx, fmaxf(-limx, txtz)) * t2;
+  t1 = fminf(limy, fmaxf(-limy, tytz)) * t2;
+  o.t0 = t0; o.t1 = t1; o.t2 = t2;
+  o.fx = (float)W / (2.f * cam.tanfovx);
+  o.fy = (float)H / (2.f * cam.tanfovy);
+  const float J00 = o.fx / t2, J02 = -(o.fx * t0) / (t2 * t2);
+  const float J11 = o.fy / t2, J12 = -(o.fy * t1) / (t2 * t2);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    o.M[j] = J00 * v[4 * j + 0] + J02 * v[4 * j + 2];
+    o.M[3 + j] = J11 * v[4 * j + 1] + J12 * v[4 * j + 2];
+  }
+  const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+  float MS[6];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      MS[3 * i + j] = o.M[3 * i + 0] * S[0 * 3 + j] + o.M[3 * i + 1] * S[1 * 3 + j] + o.M[3 * i + 2] * S[2 * 3 + j];
+  o.a = MS[0] * o.M[0] + MS[1] * o.M[1] + MS[2] * o.M[2] + 0.3f;
+  o.b = MS[0] * o.M[3] + MS[1] * o.M[4] + MS[2] * o.M[5];
+  o.c = MS[3] * o.M[3] + MS[4] * o.M[4] + MS[5] * o.M[5] + 0.3f;
+}
+
+// Footprint of one projected Gaussian over the 8x8-tile grid.  The candidate range is the reference's
+// 16x16-tile rect ([EXT] auxiliary.h getRect) expressed in 8x8 tiles, clipped to the image and to the
+// axis-aligned bounds of the ellipse {q <= tau}, q = a dx^2 + 2 b dx dy + c dy^2, tau = 2 ln(255 o):
+// outside it alpha = o exp(-q/2) < 1/255 and the blend would skip the pixel anyway.
+struct Foot {
+  float cx, cy, A, B, C, tau;
+  bool convex;
+  int sx0, sx1, sy0, sy1;
+};
+
+__device__ __forceinline__ int f2i_clamped(float f) { return (int)fminf(1e9f, fmaxf(-1e9f, f)); }
+
+__device__ __forceinline__ void ref_rect16(float x, float y, float r, const Grid& g, int& rx0, int& ry0, int& rx1, int& ry1) {
+  rx0 = min(g.gx16, max(0, f2i_clamped((x - r) / 16.f)));
+  ry0 = min(g.gy16, max(0, f2i_clamped((y - r) / 16.f)));
+  rx1 = min(g.gx16, max(0, f2i_clamped((x + r + 15.f) / 16.f)));
+  ry1 = min(g.gy16, max(0, f2i_clamped((y + r + 15.f) / 16.f)));
+}
+
+__device__ __forceinline__ Foot make_foot(float x, float y, float A, float B, float C, float o, float r, const Grid& g) {
+  Foot f;
+  f.cx = x; f.cy = y; f.A = A; f.B = B; f.C = C;
+  int rx0, ry0, rx1, ry1;
+  ref_rect16(x, y, r, g, rx0, ry0, rx1, ry1);
+  f.sx0 = 2 * rx0; f.sy0 = 2 * ry0;
+  f.sx1 = min(2 * rx1, g.sw); f.sy1 = min(2 * ry1, g.sh);
+  const float tau = 2.f * logf(255.f * o);
+  f.tau = tau + 1e-4f * fabsf(tau) + 0.02f;  // margin >> fp32 error of the blend's own power evaluation
+  const float detc = A * C - B * B;
+  f.convex = (A > 0.f) && (C > 0.f) && (detc > 0.f) && (detc < 3.0e38f);
+  if (!(f.tau >= 0.f)) {  // opacity < 1/255 (or NaN): alpha < 1/255 everywhere
+    f.sx1 = f.sx0; f.sy1 = f.sy0;
+  } else if (f.convex) {
+    const float hx = sqrtf(f.tau * C / detc) + 0.5f, hy = sqrtf(f.tau * A / detc) + 0.5f;
+    f.sx0 = max(f.sx0, f2i_clamped(floorf((x - hx) * 0.125f)));
+    f.sx1 = min(f.sx1, f2i_clamped(floorf((x + hx) * 0.125f)) + 1);
+    f.sy0 = max(f.sy0, f2i_clamped(floorf((y - hy) * 0.125f)));
+    f.sy1 = min(f.sy1, f2i_clamped(floorf((y + hy) * 0.125f)) + 1);
+  }
+  return f;
+}
+
+// Exact minimum of q over the pixel-centre box of 8x8 tile (sx, sy); true if some pixel may reach alpha >= 1/255.
+__device__ __forceinline__ bool subtile_hit(const Foot& f, int sx, int sy, const Grid& g) {
+  if (!f.convex) return true;
+  const float dx0 = (float)(8 * sx) - f.cx, dx1 = (float)min(8 * sx + 7, g.W - 1) - f.cx;
+  const float dy0 = (float)(8 * sy) - f.cy, dy1 = (float)min(8 * sy + 7, g.H - 1) - f.cy;
+  const bool inx = (dx0 <= 0.f) && (dx1 >= 0.f), iny = (dy0 <= 0.f) && (dy1 >= 0.f);
+  if (inx && iny) return true;
+  auto qx = [&](float dxe) {
+    const float ys = fminf(fmaxf(-f.B * dxe / f.C, dy0), dy1);
+    return f.A * dxe * dxe + 2.f * f.B * dxe * ys + f.C * ys * ys;
+  };
+  auto qy = [&](float dye) {
+    const float xs = fminf(fmaxf(-f.B * dye / f.A, dx0), dx1);
+    return f.A * xs * xs + 2.f * f.B * xs * dye + f.C * dye * dye;
+  };
+  const float qmin = fminf(fminf(qx(dx0), qx(dx1)), fminf(qy(dy0), qy(dy1)));
+  return qmin <= f.tau;
+}
+
+// Wave-cooperative copy of `cnt` rows of `rowf` floats from global to LDS (row stride ldstride floats).
+__device__ __forceinline__ void stage_rows(float* lds, const float* src, int cnt, int rowf, int ldstride, int lane) {
+  const int total = cnt * rowf;
+  if (ldstride == rowf) {
+    if ((((uintptr_t)src) & 15) == 0) {
+      const int n4 = total >> 2;
+      for (int k = lane; k < n4; k += 64) reinterpret_cast<float4*>(lds)[k] = reinterpret_cast<const float4*>(src)[k];
+      for (int k = (n4 << 2) + lane; k < total; k += 64) lds[k] = src[k];
+    } else {
+      for (int k = lane; k < total; k += 64) lds[k] = src[k];
+    }
+  } else {
+    for (int k = lane; k < total; k += 64) {
+      const int row = k / rowf;
+      lds[row * ldstride + (k - row * rowf)] = src[k];
+    }
+  }
+}
+__device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int cnt, int rowf, int ldstride, int lane) {
+  const int total = cnt * rowf;
+  if (ldstride == rowf) {
+    if ((((uintptr_t)dst) & 15) == 0) {
+      const int n4 = total >> 2;
+      for (int k = lane; k < n4; k += 64) reinterpret_cast<float4*>(dst)[k] = reinterpret_cast<const float4*>(lds)[k];
+      for (int k = (n4 << 2) + lane; k < total; k += 64) dst[k] = lds[k];
+    } else {
+      for (int k = lane; k < total; k += 64) dst[k] = lds[k];
+    }
+  } else {
+    for (int k = lane; k < total; k += 64) {
+      const int row = k / rowf;
+      dst[k] = lds[row * ldstride + (k - row * rowf)];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: preprocess — projection, EWA covariance, conic, radius, SH -> RGB, per-tile pair counts
+// ([EXT] forward.cu preprocessCUDA; oracle preprocess()).  One wavefront per 64 Gaussians of a view.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_preprocess(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x, v = blockIdx.y;
+  const int N = p.d.num_gaussians;
+  const int g0 = blockIdx.x * 64;
+  const int i = g0 + lane;
+  const int set = v / p.d.views_per_set;
+  const GsrView& cam = p.views[v];
+  const Grid& g = p.g;
+  const bool in_range = i < N;
+  const size_t gi = (size_t)set * N + (in_range ? i : 0), oi = (size_t)v * N + (in_range ? i : 0);
+
+  bool vis = in_range;
+  float mx = 0, my = 0, mz = 0, cov6[6] = {0, 0, 0, 0, 0, 0}, op = 0;
+  if (in_range) {
+    mx = p.means[3 * gi + 0] * cam.scale; my = p.means[3 * gi + 1] * cam.scale; mz = p.means[3 * gi + 2] * cam.scale;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov6[k] = p.cov6[6 * gi + k] * cam.scale2;
+    op = p.opac[gi];
+  }
+  const float* vm = cam.viewmatrix;
+  const float* pm = cam.projmatrix;
+  const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+  vis = vis && !(pvz <= kNear);
+  const float ph0 = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
+  const float ph1 = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
+  const float ph3 = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
+  const float p_w = 1.0f / (ph3 + 0.0000001f);
+  const float ppx = ph0 * p_w, ppy = ph1 * p_w;
+  Cov2D c2;
+  cov2d_parts(mx, my, mz, cov6, cam, g.W, g.H, c2);
+  const float det = c2.a * c2.c - c2.b * c2.b;
+  vis = vis && !(det == 0.f);
+  const float det_inv = 1.f / det;
+  const float conA = c2.c * det_inv, conB = -c2.b * det_inv, conC = c2.a * det_inv;
+  const float mid = 0.5f * (c2.a + c2.c);
+  const float root = sqrtf(fmaxf(0.1f, mid * mid - det));
+  const float lambda1 = mid + root, lambda2 = mid - root;
+  const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+  const float px = ((ppx + 1.0f) * (float)g.W - 1.0f) * 0.5f;
+  const float py = ((ppy + 1.0f) * (float)g.H - 1.0f) * 0.5f;
+  vis = vis && (fabsf(px) < 3.0e38f) && (fabsf(py) < 3.0e38f) && (my_radius < 16777216.f) && (pvz < 3.0e38f);
+  if (vis) {
+    int rx0, ry0, rx1, ry1;
+    ref_rect16(px, py, my_radius, g, rx0, ry0, rx1, ry1);
+    vis = (rx1 - rx0) * (ry1 - ry0) != 0;
+  }
+
+  // colour
+  const int M = p.d.sh_coeffs;
+  float cr = 0, cg = 0, cb = 0;
+  uint32_t clampbits = 0;
+  if (M > 0) {
+    if (__any(vis)) {
+      const int rowf = 3 * M, ldstride = rowf | 1;
+      stage_rows(lds, p.colors + ((size_t)set * N + g0) * rowf, min(64, N - g0), rowf, ldstride, lane);
+      __syncthreads();
+      if (vis) {
+        const float* sh = lds + lane * ldstride;
+        float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+        dx = dx / len; dy = dy / len; dz = dz / len;
+        const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
+          if (k < M) { cr += bk * sh[3 * k + 0]; cg += bk * sh[3 * k + 1]; cb += bk * sh[3 * k + 2]; }
+        });
+        cr += 0.5f; cg += 0.5f; cb += 0.5f;
+        clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
+        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
+      }
+    }
+  } else if (vis) {
+    cr = p.colors[3 * gi + 0]; cg = p.colors[3 * gi + 1]; cb = p.colors[3 * gi + 2];
+  }
+
+  if (in_range) {
+    const int radius = vis ? (int)my_radius : 0;
+    p.radii[oi] = radius;
+    GeomRec rec;
+    const float ex = (vis && p.d.has_extra) ? p.extra[oi] : 0.f;
+    rec.q0 = vis ? make_float4(px, py, conA, conB) : make_float4(0, 0, 0, 0);
+    rec.q1 = vis ? make_float4(conC, op, cr, cg) : make_float4(0, 0, 0, 0);
+    rec.q2 = make_float4(vis ? cb : 0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius | (clampbits << 28)));
+    p.geom[oi] = rec;
+    if (vis) {
+      const Foot f = make_foot(px, py, conA, conB, conC, op, my_radius, g);
+      const uint32_t rep = (uint32_t)(i >> 6) & (kNRep - 1);
+      uint32_t* cnt = p.counts + (size_t)v * g.T * kNRep + rep;
+      for (int sy = f.sy0; sy < f.sy1; ++sy)
+        for (int sx = f.sx0; sx < f.sx1; ++sx)
+          if (subtile_hit(f, sx, sy, g)) atomicAdd(cnt + (size_t)(sy * g.sgx + sx) * kNRep, 1u);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2a: per-tile exclusive scan over the 64 counter replicas (one wavefront per tile)
+// K2b: exclusive scan over all (view, tile) totals -> list ranges, pair total, overflow flag
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_tile_prefix(const Params p) {
+  const size_t w = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  const size_t VT = (size_t)p.d.num_views * p.g.T;
+  if (w >= VT) return;
+  const uint32_t c = p.counts[w * kNRep + lane];
+  uint32_t s = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)s, o, 64);
+    if (lane >= o) s += t;
+  }
+  p.counts[w * kNRep + lane] = s - c;
+  if (lane == 63) p.tile_total[w] = s;
+}
+
+__global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
+  __shared__ unsigned long long part[1024];
+  __shared__ uint32_t smax;
+  const int tid = threadIdx.x;
+  const size_t n = (size_t)p.d.num_views * p.g.T;
+  const size_t per = (n + 1023) / 1024;
+  const size_t b = (size_t)tid * per, e = b + per < n ? b + per : n;
+  if (tid == 0) smax = 0;
+  unsigned long long sum = 0;
+  uint32_t mx = 0;
+  for (size_t k = b; k < e; ++k) {
+    const uint32_t t = p.tile_total[k];
+    sum += t;
+    mx = t > mx ? t : mx;
+  }
+  part[tid] = sum;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const unsigned long long t = tid >= o ? part[tid - o] : 0ull;
+    __syncthreads();
+    part[tid] += t;
+    __syncthreads();
+  }
+  atomicMax(&smax, mx);
+  const unsigned long long total = part[1023];
+  const bool overflow = total > (unsigned long long)p.d.pair_capacity;
+  unsigned long long run = part[tid] - sum;
+  for (size_t k = b; k < e; ++k) {
+    const uint32_t t = p.tile_total[k];
+    p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + t));
+    run += t;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    p.status->num_pairs = total;
+    p.status->overflow = overflow ? 1u : 0u;
+    p.status->max_list = smax;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: emit (depth bits : Gaussian index) keys into each tile's list segment (order inside a segment is
+// arbitrary here; K4 sorts it).  Recomputes the footprint from the stored record with the same code as K1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_emit(const Params p) {
+  if (p.status->overflow) return;
+  const int v = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int N = p.d.num_gaussians;
+  if (i >= N) return;
+  const Grid& g = p.g;
+  const GeomRec* rec = p.geom + (size_t)v * N + i;
+  const float4 q2 = rec->q2;
+  const uint32_t radius = __float_as_uint(q2.w) & 0x0fffffffu;
+  if (radius == 0) return;
+  const float4 q0 = rec->q0, q1 = rec->q1;
+  const Foot f = make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)radius, g);
+  const uint32_t rep = (uint32_t)(i >> 6) & (kNRep - 1);
+  const unsigned long long key = ((unsigned long long)__float_as_uint(q2.z) << 32) | (uint32_t)i;
+  for (int sy = f.sy0; sy < f.sy1; ++sy)
+    for (int sx = f.sx0; sx < f.sx1; ++sx)
+      if (subtile_hit(f, sx, sy, g)) {
+        const size_t vt = (size_t)v * g.T + (size_t)(sy * g.sgx + sx);
+        const uint32_t slot = p.ranges[vt].x + atomicAdd(p.counts + vt * kNRep + rep, 1u);
+        if (slot < p.ranges[vt].y) p.keys[slot] = key;
+      }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-tile depth sort, one wavefront per tile.  Bitonic network in its all-ascending (mirror) form so
+// that a list of any length sorts with virtual +inf padding; <= kSortLds keys sort in LDS, longer lists
+// in place in global memory.  Writes the sorted Gaussian indices (the reference's point_list).
+// ------------------------------------------------------------------------------------------------
+template <class KeyPtr>
+__device__ __forceinline__ void bitonic_wave(KeyPtr a, int n, int np, int lane) {
+  const int half = np >> 1;
+  for (int k = 2; k <= np; k <<= 1) {
+    const int hk = k >> 1;
+    for (int t = lane; t < half; t += 64) {
+      const int blk = t / hk, off = t - blk * hk;
+      const int i = blk * k + off, j = blk * k + k - 1 - off;
+      if (j < n) {
+        const unsigned long long x = a[i], y = a[j];
+        if (x > y) { a[i] = y; a[j] = x; }
+      }
+    }
+    __syncthreads();
+    for (int jj = k >> 2; jj >= 1; jj >>= 1) {
+      for (int t = lane; t < half; t += 64) {
+        const int blk = t / jj, off = t - blk * jj;
+        const int i = blk * 2 * jj + off, j = i + jj;
+        if (j < n) {
+          const unsigned long long x = a[i], y = a[j];
+          if (x > y) { a[i] = y; a[j] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_sort_tiles(const Params p) {
+  __shared__ unsigned long long sk[kSortLds];
+  const int lane = threadIdx.x;
+  const uint2 rg = p.ranges[blockIdx.x];
+  const int n = (int)(rg.y - rg.x);
+  if (n == 0) return;
+  unsigned long long* keys = p.keys + rg.x;
+  uint32_t* out = p.point_list + rg.x;
+  int np = 2;
+  while (np < n) np <<= 1;
+  if (n <= kSortLds) {
+    for (int k = lane; k < n; k += 64) sk[k] = keys[k];
+    __syncthreads();
+    bitonic_wave(sk, n, np, lane);
+    for (int k = lane; k < n; k += 64) out[k] = (uint32_t)sk[k];
+  } else {
+    __syncthreads();
+    bitonic_wave(keys, n, np, lane);
+    for (int k = lane; k < n; k += 64) out[k] = (uint32_t)keys[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: forward blend, one wavefront per 8x8 tile, lane = pixel ([EXT] forward.cu renderCUDA; oracle
+// blend_forward).  Splat records are gathered 64 at a time (lane = splat) into LDS and then broadcast.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_blend_fwd(const Params p) {
+  __shared__ float4 s0[64], s1[64], s2[64];
+  const Grid& g = p.g;
+  const int lane = threadIdx.x;
+  const int v = blockIdx.y;
+  const int t = xcd_remap(blockIdx.x, g.T);
+  const int tx = t % g.sgx, ty = t / g.sgx;
+  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
+  const bool inside = pxi < g.W && pyi < g.H;
+  const float pxf = (float)pxi, pyf = (float)pyi;
+  const uint2 rg = p.ranges[(size_t)v * g.T + t];
+  const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
+  const bool has_extra = p.d.has_extra != 0;
+
+  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;
+  uint32_t last = 0;
+  bool done = !inside;
+  for (uint32_t base = rg.x; base < rg.y; base += 64) {
+    if (__all(done)) break;
+    const int nb = min(64u, rg.y - base);
+    if (lane < nb) {
+      const GeomRec* r = geom + p.point_list[base + lane];
+      s0[lane] = r->q0; s1[lane] = r->q1; s2[lane] = r->q2;
+    }
+    __syncthreads();
+    for (int j = 0; j < nb; ++j) {
+      if ((j & 3) == 0 && __all(done)) break;
+      const float4 a = s0[j], b = s1[j], c = s2[j];
+      const float dx = a.x - pxf, dy = a.y - pyf;
+      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+      const float alpha = fminf(0.99f, b.y * __expf(power));
+      const float test_T = T * (1.f - alpha);
+      const bool ok = !done && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+      const bool stop = ok && (test_T < 0.0001f);
+      const bool acc = ok && !stop;
+      done = done || stop;
+      if (acc) {
+        C0 += b.z * alpha * T; C1 += b.w * alpha * T; C2 += c.x * alpha * T;
+        if (has_extra) E += c.y * alpha * T;
+        T = test_T;
+        last = base - rg.x + j + 1;
+      }
+    }
+    __syncthreads();
+  }
+  if (inside) {
+    const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
+    const GsrView& cam = p.views[v];
+    p.final_T[(size_t)v * HW + pix] = T;
+    p.n_contrib[(size_t)v * HW + pix] = last;
+    float* oc = p.out_color + (size_t)v * 3 * HW;
+    oc[pix] = C0 + T * cam.bg[0];
+    oc[HW + pix] = C1 + T * cam.bg[1];
+    oc[2 * HW + pix] = C2 + T * cam.bg[2];
+    if (has_extra) p.out_extra[(size_t)v * HW + pix] = E;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B1: backward blend, one wavefront per 8x8 tile, back-to-front replay ([EXT] backward.cu renderCUDA;
+// oracle blend_backward).  Per splat the 64 pixel gradients are reduced across the wavefront and one
+// lane per value issues the atomic into the per-(view,Gaussian) screen-space accumulator:
+//   scratch[.. * 12 + {0,1: dmean2D  2,3,4: dconic  5: dopacity  6,7,8: dcolor  9: dextra}]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
+  __shared__ float4 s0[64], s1[64], s2[64];
+  __shared__ uint32_t sid[64];
+  const Grid& g = p.g;
+  const int lane = threadIdx.x;
+  const int v = blockIdx.y;
+  const int t = xcd_remap(blockIdx.x, g.T);
+  const int tx = t % g.sgx, ty = t / g.sgx;
+  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
+  const bool inside = pxi < g.W && pyi < g.H;
+  const float pxf = (float)pxi, pyf = (float)pyi;
+  const uint2 rg = p.ranges[(size_t)v * g.T + t];
+  const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
+  const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
+  float* scratch = p.scratch + (size_t)v * p.d.num_gaussians * GSR_SCREEN_GRAD_FLOATS;
+  const GsrView& cam = p.views[v];
+  const bool has_extra = p.d.has_extra != 0 && p.dL_dextra_img != nullptr;
+
+  const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
+  const uint32_t my_last = inside ? p.n_contrib[(size_t)v * HW + pix] : 0u;
+  float g0 = 0, g1 = 0, g2 = 0, ge = 0;
+  if (inside) {
+    const float* dc = p.dL_dcolor + (size_t)v * 3 * HW;
+    g0 = dc[pix]; g1 = dc[HW + pix]; g2 = dc[2 * HW + pix];
+    if (has_extra) ge = p.dL_dextra_img[(size_t)v * HW + pix];
+  }
+  const float bg_dot = cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2;
+  const float ddelx_dx = 0.5f * (float)g.W, ddely_dy = 0.5f * (float)g.H;
+  const uint32_t nmax = wave_max_u32(my_last);
+  if (nmax == 0) return;
+
+  float T = T_final, last_alpha = 0.f;
+  float ar0 = 0, ar1 = 0, ar2 = 0, are = 0, lc0 = 0, lc1 = 0, lc2 = 0, lce = 0;
+  for (int base = (int)((nmax - 1) & ~63u); base >= 0; base -= 64) {
+    const int nb = min(64, (int)nmax - base);
+    if (lane < nb) {
+      const uint32_t id = p.point_list[rg.x + base + lane];
+      const GeomRec* r = geom + id;
+      s0[lane] = r->q0; s1[lane] = r->q1; s2[lane] = r->q2;
+      sid[lane] = id;
+    }
+    __syncthreads();
+    for (int j = nb - 1; j >= 0; --j) {
+      const float4 a = s0[j], b = s1[j], c = s2[j];
+      const uint32_t idx = (uint32_t)(base + j);
+      const float dx = a.x - pxf, dy = a.y - pyf;
+      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+      const float G = __expf(power);
+      const float alpha = fminf(0.99f, b.y * G);
+      const bool ok = (idx < my_last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+      if (!__any(ok)) continue;
+      float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
+      if (ok) {
+        T = T / (1.f - alpha);
+        const float dchannel_dcolor = alpha * T;
+        float dL_dalpha = 0.f;
+        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = b.z; dL_dalpha += (b.z - ar0) * g0; v6 = dchannel_dcolor * g0;
+        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = b.w; dL_dalpha += (b.w - ar1) * g1; v7 = dchannel_dcolor * g1;
+        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.x; dL_dalpha += (c.x - ar2) * g2; v8 = dchannel_dcolor * g2;
+        if (has_extra) {
+          are = last_alpha * lce + (1.f - last_alpha) * are; lce = c.y; dL_dalpha += (c.y - are) * ge; v9 = dchannel_dcolor * ge;
+        }
+        dL_dalpha *= T;
+        last_alpha = alpha;
+        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
+        const float dL_dG = b.y * dL_dalpha;
+        const float gdx = G * dx, gdy = G * dy;
+        const float dG_ddelx = -gdx * a.z - gdy * a.w;
+        const float dG_ddely = -gdy * b.x - gdx * a.w;
+        v0 = dL_dG * dG_ddelx * ddelx_dx;
+        v1 = dL_dG * dG_ddely * ddely_dy;
+        v2 = -0.5f * gdx * dx * dL_dG;
+        v3 = -0.5f * gdx * dy * dL_dG;
+        v4 = -0.5f * gdy * dy * dL_dG;
+        v5 = G * dL_dalpha;
+      }
+      v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
+      v5 = wave_sum(v5); v6 = wave_sum(v6); v7 = wave_sum(v7); v8 = wave_sum(v8);
+      if (has_extra) v9 = wave_sum(v9);
+      if (lane < 10) {
+        float val = v0;
+        val = lane == 1 ? v1 : val; val = lane == 2 ? v2 : val; val = lane == 3 ? v3 : val; val = lane == 4 ? v4 : val;
+        val = lane == 5 ? v5 : val; val = lane == 6 ? v6 : val; val = lane == 7 ? v7 : val; val = lane == 8 ? v8 : val;
+        val = lane == 9 ? v9 : val;
+        unsafeAtomicAdd(scratch + (size_t)sid[j] * GSR_SCREEN_GRAD_FLOATS + lane, val);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B2: backward preprocess — conic -> cov2D -> cov3D/mean, projection, SH ([EXT] backward.cu
+// computeCov2DCUDA + preprocessCUDA; oracle preprocess_backward).  One wavefront per 64 Gaussians of a SET;
+// loops over the set's views so SH is read once and every gradient is written once.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x, set = blockIdx.y;
+  const int N = p.d.num_gaussians, Vs = p.d.views_per_set;
+  const int g0 = blockIdx.x * 64;
+  const int i = g0 + lane;
+  const bool in_range = i < N;
+  const size_t gi = (size_t)set * N + (in_range ? i : 0);
+  const Grid& g = p.g;
+  const int M = p.d.sh_coeffs;
+  const int rowf = 3 * M, ldstride = rowf | 1;
+  const int cnt = min(64, N - g0);
+  float* sh_in = lds;
+  float* sh_out = lds + 64 * ldstride;
+  if (M > 0) {
+    stage_rows(sh_in, p.colors + ((size_t)set * N + g0) * rowf, cnt, rowf, ldstride, lane);
+    for (int k = 0; k < rowf; ++k) sh_out[lane * ldstride + k] = 0.f;
+    __syncthreads();
+  }
+  float rmx = 0, rmy = 0, rmz = 0, rcov[6] = {0, 0, 0, 0, 0, 0};
+  if (in_range) {
+    rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rcov[k] = p.cov6[6 * gi + k];
+  }
+  float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0};
+  for (int vv = 0; vv < Vs; ++vv) {
+    const int v = set * Vs + vv;
+    const GsrView& cam = p.views[v];
+    const size_t oi = (size_t)v * N + (in_range ? i : 0);
+    uint32_t bits = 0;
+    if (in_range) bits = __float_as_uint(p.geom[oi].q2.w);
+    const bool vis = in_range && (bits & 0x0fffffffu) != 0;
+    float sg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (vis) {
+      const float* s = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
+#pragma unroll
+      for (int k = 0; k < 10; ++k) sg[k] = s[k];
+    }
+    if (in_range) {
+      if (p.dL_dextra) p.dL_dextra[oi] = sg[9];
+      if (p.dL_dmeans2D) { p.dL_dmeans2D[3 * oi + 0] = sg[0]; p.dL_dmeans2D[3 * oi + 1] = sg[1]; p.dL_dmeans2D[3 * oi + 2] = 0.f; }
+    }
+    if (!vis) continue;
+    const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
+    float cov6[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov6[k] = rcov[k] * cam.scale2;
+    dop += sg[5];
+    // --- computeCov2DCUDA
+    Cov2D c2;
+    cov2d_parts(mx, my, mz, cov6, cam, g.W, g.H, c2);
+    const float a = c2.a, b = c2.b, c = c2.c;
+    const float dA = sg[2], dB = sg[3], dC = sg[4];
+    const float denom = a * c - b * b;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    float dcv[6] = {0, 0, 0, 0, 0, 0};
+    const float* Mm = c2.M;
+    if (denom2inv != 0.f) {
+      dL_da = denom2inv * (-c * c * dA + 2.f * b * c * dB + (denom - a * c) * dC);
+      dL_dc = denom2inv * (-a * a * dC + 2.f * a * b * dB + (denom - a * c) * dA);
+      dL_db = denom2inv * 2.f * (b * c * dA - (denom + 2.f * b * b) * dB + a * b * dC);
+      dcv[0] = Mm[0] * Mm[0] * dL_da + Mm[0] * Mm[3] * dL_db + Mm[3] * Mm[3] * dL_dc;
+      dcv[3] = Mm[1] * Mm[1] * dL_da + Mm[1] * Mm[4] * dL_db + Mm[4] * Mm[4] * dL_dc;
+      dcv[5] = Mm[2] * Mm[2] * dL_da + Mm[2] * Mm[5] * dL_db + Mm[5] * Mm[5] * dL_dc;
+      dcv[1] = 2.f * Mm[0] * Mm[1] * dL_da + (Mm[0] * Mm[4] + Mm[1] * Mm[3]) * dL_db + 2.f * Mm[3] * Mm[4] * dL_dc;
+      dcv[2] = 2.f * Mm[0] * Mm[2] * dL_da + (Mm[0] * Mm[5] + Mm[2] * Mm[3]) * dL_db + 2.f * Mm[3] * Mm[5] * dL_dc;
+      dcv[4] = 2.f * Mm[2] * Mm[1] * dL_da + (Mm[1] * Mm[5] + Mm[2] * Mm[4]) * dL_db + 2.f * Mm[4] * Mm[5] * dL_dc;
+    }
+    const float S[9] = {cov6[0], cov6[1], cov6[2], cov6[1], cov6[3], cov6[4], cov6[2], cov6[4], cov6[5]};
+    float dM[6];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float m0s = Mm[0] * S[0 * 3 + j] + Mm[1] * S[1 * 3 + j] + Mm[2] * S[2 * 3 + j];
+      const float m1s = Mm[3] * S[0 * 3 + j] + Mm[4] * S[1 * 3 + j] + Mm[5] * S[2 * 3 + j];
+      dM[j] = 2.f * m0s * dL_da + m1s * dL_db;
+      dM[3 + j] = 2.f * m1s * dL_dc + m0s * dL_db;
+    }
+    const float* vw = cam.viewmatrix;
+    const float dJ00 = vw[0] * dM[0] + vw[4] * dM[1] + vw[8] * dM[2];
+    const float dJ02 = vw[2] * dM[0] + vw[6] * dM[1] + vw[10] * dM[2];
+    const float dJ11 = vw[1] * dM[3] + vw[5] * dM[4] + vw[9] * dM[5];
+    const float dJ12 = vw[2] * dM[3] + vw[6] * dM[4] + vw[10] * dM[5];
+    const float tz = 1.f / c2.t2, tz2 = tz * tz, tz3 = tz2 * tz;
+    const float xg = c2.xcl ? 0.f : 1.f, yg = c2.ycl ? 0.f : 1.f;
+    const float dtx = xg * -c2.fx * tz2 * dJ02;
+    const float dty = yg * -c2.fy * tz2 * dJ12;
+    const float dtz = -c2.fx * tz2 * dJ00 - c2.fy * tz2 * dJ11 + (2.f * c2.fx * c2.t0) * tz3 * dJ02 +
+                      (2.f * c2.fy * c2.t1) * tz3 * dJ12;
+    float dm[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dm[j] = vw[4 * j + 0] * dtx + vw[4 * j + 1] * dty + vw[4 * j + 2] * dtz;
+    // --- projection
+    const float* pr = cam.projmatrix;
+    const float mh3 = pr[3] * mx + pr[7] * my + pr[11] * mz + pr[15];
+    const float m_w = 1.0f / (mh3 + 0.0000001f);
+    const float mul1 = (pr[0] * mx + pr[4] * my + pr[8] * mz + pr[12]) * m_w * m_w;
+    const float mul2 = (pr[1] * mx + pr[5] * my + pr[9] * mz + pr[13]) * m_w * m_w;
+    dm[0] += (pr[0] * m_w - pr[3] * mul1) * sg[0] + (pr[1] * m_w - pr[3] * mul2) * sg[1];
+    dm[1] += (pr[4] * m_w - pr[7] * mul1) * sg[0] + (pr[5] * m_w - pr[7] * mul2) * sg[1];
+    dm[2] += (pr[8] * m_w - pr[11] * mul1) * sg[0] + (pr[9] * m_w - pr[11] * mul2) * sg[1];
+    // --- SH
+    if (M > 0) {
+      const float ox = mx - cam.campos[0], oy = my - cam.campos[1], oz = mz - cam.campos[2];
+      const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+      const float x = ox / len, y = oy / len, z = oz / len;
+      const uint32_t cl = bits >> 28;
+      const float d0 = (cl & 1u) ? 0.f : sg[6], d1 = (cl & 2u) ? 0.f : sg[7], d2 = (cl & 4u) ? 0.f : sg[8];
+      const float* sh = sh_in + lane * ldstride;
+      float* dsh = sh_out + lane * ldstride;
+      float ddx = 0, ddy = 0, ddz = 0;
+      const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+      sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
+        if (k < M) {
+          dsh[3 * k + 0] += bk * d0; dsh[3 * k + 1] += bk * d1; dsh[3 * k + 2] += bk * d2;
+          const float sd = sh[3 * k + 0] * d0 + sh[3 * k + 1] * d1 + sh[3 * k + 2] * d2;
+          ddx += bx * sd; ddy += by * sd; ddz += bz * sd;
+        }
+      });
+      const float sum2 = ox * ox + oy * oy + oz * oz;
+      const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+      dm[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+      dm[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+      dm[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+    } else {
+      dcol[0] += sg[6]; dcol[1] += sg[7]; dcol[2] += sg[8];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dmean[j] += dm[j] * cam.scale;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
+  }
+  if (in_range) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) p.dL_dmeans[3 * gi + j] = dmean[j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) p.dL_dcov6[6 * gi + k] = dcov[k];
+    p.dL_dopac[gi] = dop;
+    if (M == 0) { p.dL_dcolors[3 * gi + 0] = dcol[0]; p.dL_dcolors[3 * gi + 1] = dcol[1]; p.dL_dcolors[3 * gi + 2] = dcol[2]; }
+  }
+  if (M > 0) {
+    __syncthreads();
+    unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_out, cnt, rowf, ldstride, lane);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mark_visible(const Params p, uint8_t* present) {
+  const int set = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int N = p.d.num_gaussians;
+  if (i >= N) return;
+  const GsrView& cam = p.views[set * p.d.views_per_set];
+  const size_t gi = (size_t)set * N + i;
+  const float mx = p.means[3 * gi] * cam.scale, my = p.means[3 * gi + 1] * cam.scale, mz = p.means[3 * gi + 2] * cam.scale;
+  const float* vm = cam.viewmatrix;
+  const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
+  present[gi] = !(pvz <= kNear) ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+bool dims_ok(const GsrDims* d) {
+  if (!d || d->abi_version != GSR_ABI_VERSION) return false;
+  if (d->num_views < 0 || d->num_sets < 0 || d->views_per_set < 0 || d->num_gaussians < 0) return false;
+  if ((int64_t)d->num_sets * d->views_per_set != d->num_views) return false;
+  if (d->height <= 0 || d->width <= 0 || d->height > 32768 || d->width > 32768) return false;
+  if (d->sh_coeffs < 0 || d->sh_coeffs > 25 || d->sh_degree < 0 || d->sh_degree > 4) return false;
+  if (d->num_views > 65535 || d->pair_capacity < 0 || d->pair_capacity > 0xfffffff0ll) return false;
+  const Grid g = make_grid(d->width, d->height);
+  if ((int64_t)d->num_views * g.T > 0x7fffffffll) return false;
+  return true;
+}
+
+Params base_params(const GsrDims* d, const GsrView* views, const float* means, const float* cov6, const float* opac,
+                   const float* colors, const float* extra, void* geom, void* bin, void* img) {
+  Params p{};
+  p.d = *d;
+  p.g = make_grid(d->width, d->height);
+  p.views = views; p.means = means; p.cov6 = cov6; p.opac = opac; p.colors = colors; p.extra = extra;
+  const Layout L = make_layout(*d);
+  char* b = static_cast<char*>(bin);
+  p.geom = static_cast<GeomRec*>(geom);
+  p.status = reinterpret_cast<GsrStatus*>(b + L.o_status);
+  p.counts = reinterpret_cast<uint32_t*>(b + L.o_counts);
+  p.tile_total = reinterpret_cast<uint32_t*>(b + L.o_total);
+  p.ranges = reinterpret_cast<uint2*>(b + L.o_ranges);
+  p.keys = reinterpret_cast<unsigned long long*>(b + L.o_keys);
+  p.point_list = reinterpret_cast<uint32_t*>(b + L.o_list);
+  char* im = static_cast<char*>(img);
+  p.final_T = reinterpret_cast<float*>(im + L.o_finalT);
+  p.n_contrib = reinterpret_cast<uint32_t*>(im + L.o_ncontrib);
+  return p;
+}
+
+#define GSR_CHECK(expr)                       \
+  do {                                        \
+    if ((expr) != hipSuccess) return GSR_ERR_LAUNCH; \
+  } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+const char* gsr_build_info(void) {
+  return "gsr_hip gfx950 wave64 tile8x8 nrep64 sortlds4096 abi1";
+}
+
+int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes) {
+  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+  const Layout L = make_layout(*dims);
+  if (geom_bytes) *geom_bytes = L.geom_bytes;
+  if (bin_bytes) *bin_bytes = L.bin_bytes;
+  if (img_bytes) *img_bytes = L.img_bytes;
+  return GSR_OK;
+}
+
+// Debug aid for tests: byte offsets of the sub-buffers inside bin (6) and img (2).
+int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8) {
+  if (!dims_ok(dims) || !offsets8) return GSR_ERR_INVALID_ARGUMENT;
+  const Layout L = make_layout(*dims);
+  offsets8[0] = (int64_t)L.o_status; offsets8[1] = (int64_t)L.o_counts; offsets8[2] = (int64_t)L.o_total;
+  offsets8[3] = (int64_t)L.o_ranges; offsets8[4] = (int64_t)L.o_keys; offsets8[5] = (int64_t)L.o_list;
+  offsets8[6] = (int64_t)L.o_finalT; offsets8[7] = (int64_t)L.o_ncontrib;
+  return GSR_OK;
+}
+
+int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                const float* opacities, const float* colors, const float* extra, float* out_color,
+                float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream_) {
+  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const GsrDims& d = *dims;
+  const size_t V = d.num_views, N = d.num_gaussians, HW = (size_t)d.height * d.width;
+  if (V == 0) return GSR_OK;
+  if (!views || !out_color || !bin || !img) return GSR_ERR_INVALID_ARGUMENT;
+  if (d.has_extra && (!extra || !out_extra)) return GSR_ERR_INVALID_ARGUMENT;
+  Params p = base_params(dims, views, means, cov6, opacities, colors, extra, geom, bin, img);
+  p.out_color = out_color; p.out_extra = out_extra; p.radii = radii;
+  const Layout L = make_layout(d);
+  if (N == 0) {  // upstream returns an all-zero image when there is nothing to rasterize
+    GSR_CHECK(hipMemsetAsync(out_color, 0, V * 3 * HW * sizeof(float), st));
+    if (d.has_extra) GSR_CHECK(hipMemsetAsync(out_extra, 0, V * HW * sizeof(float), st));
+    GSR_CHECK(hipMemsetAsync(bin, 0, L.o_counts, st));
+    GSR_CHECK(hipMemsetAsync(img, 0, L.img_bytes, st));
+    return GSR_OK;
+  }
+  if (!means || !cov6 || !opacities || !colors || !radii || !geom) return GSR_ERR_INVALID_ARGUMENT;
+  const size_t VT = V * (size_t)p.g.T;
+  GSR_CHECK(hipMemsetAsync(p.counts, 0, VT * kNRep * sizeof(uint32_t), st));
+  const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
+  const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
+  hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + 63) / 64), (unsigned)V), dim3(64), shmem, st, p);
+  hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT * 64 + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)((N + 255) / 256), (unsigned)V), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                 const float* opacities, const float* colors, const float* extra, const void* geom,
+                 const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
+                 void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
+                 float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_) {
+  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  const GsrDims& d = *dims;
+  const size_t V = d.num_views, N = d.num_gaussians;
+  if (V == 0 || N == 0) return GSR_OK;
+  if (!views || !means || !cov6 || !opacities || !colors || !geom || !bin || !img || !dL_dcolor || !scratch ||
+      !dL_dmeans || !dL_dcov6 || !dL_dopacities || !dL_dcolors)
+    return GSR_ERR_INVALID_ARGUMENT;
+  Params p = base_params(dims, views, means, cov6, opacities, colors, extra, const_cast<void*>(geom),
+                         const_cast<void*>(bin), const_cast<void*>(img));
+  p.dL_dcolor = dL_dcolor; p.dL_dextra_img = d.has_extra ? dL_dextra_img : nullptr;
+  p.scratch = static_cast<float*>(scratch);
+  p.dL_dmeans = dL_dmeans; p.dL_dcov6 = dL_dcov6; p.dL_dopac = dL_dopacities; p.dL_dcolors = dL_dcolors;
+  p.dL_dextra = d.has_extra ? dL_dextra : nullptr; p.dL_dmeans2D = dL_dmeans2D;
+  GSR_CHECK(hipMemsetAsync(scratch, 0, V * N * GSR_SCREEN_GRAD_FLOATS * sizeof(float), st));
+  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
+  const size_t shmem = d.sh_coeffs > 0 ? (size_t)2 * 64 * ldstride * sizeof(float) : 0;
+  hipLaunchKernelGGL(k_preprocess_bwd, dim3((unsigned)((N + 63) / 64), (unsigned)d.num_sets), dim3(64), shmem, st, p);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present, void* stream_) {
+  if (!dims_ok(dims) || !views || !present) return GSR_ERR_INVALID_ARGUMENT;
+  if (dims->num_gaussians == 0 || dims->num_sets == 0) return GSR_OK;
+  if (!means) return GSR_ERR_INVALID_ARGUMENT;
+  Params p{};
+  p.d = *dims; p.g = make_grid(dims->width, dims->height); p.views = views; p.means = means;
+  hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((dims->num_gaussians + 255) / 256), (unsigned)dims->num_sets),
+                     dim3(256), 0, static_cast<hipStream_t>(stream_), p, present);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,360 @@
+"""Operator surface of the rasterizer: `GaussianRasterizationSettings` / `GaussianRasterizer`.
+
+Keeps the Python surface of the external package the reference imports at
+src/model/decoder/cuda_splatting.py:5-8 and calls at :99-124 / :192-217 (12-field settings tuple;
+`GaussianRasterizer(settings)(means3D=, means2D=, shs=, colors_precomp=, opacities=,
+cov3D_precomp=) -> (image[3,H,W], radii[N])`; autograd through a `torch.autograd.Function`
+that returns no gradient for the settings).  Behind it sits the batched MI355X operator
+`rasterize_views`, which renders V views (grouped in sets sharing one copy of the Gaussians) in a
+single launch chain of the HIP library (include/gsr.h); the per-view API is its V = 1 case.
+
+There is no CPU path here: tensors must live on a ROCm device and the HIP library must load.
+"""
+from __future__ import annotations
+
+import ctypes
+from dataclasses import dataclass
+from typing import NamedTuple, Optional
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib
+
+VIEW_FLOATS = 48  # sizeof(GsrView) / 4
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: Tensor
+    scale_modifier: float
+    viewmatrix: Tensor
+    projmatrix: Tensor
+    sh_degree: int
+    campos: Tensor
+    prefiltered: bool
+    debug: bool
+
+
+@dataclass(frozen=True)
+class RasterConfig:
+    num_views: int
+    num_sets: int
+    views_per_set: int
+    num_gaussians: int
+    height: int
+    width: int
+    sh_degree: int
+    sh_coeffs: int  # M; 0 => precomputed colours
+    max_sh_eval: int = 4
+    has_extra: bool = False
+
+
+def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx: Tensor, tanfovy: Tensor,
+               bg: Tensor, scale: Optional[Tensor] = None, scale_modifier: float = 1.0) -> Tensor:
+    """Pack V cameras into the (V, 48) fp32 `GsrView` array (include/gsr.h) on the inputs' device.
+
+    viewmatrix/projmatrix are the transposed matrices exactly as the reference passes them
+    (cuda_splatting.py:85-87, 106-107); `scale` is the scale-invariant factor of :64-71 (None = 1).
+    """
+    v = viewmatrix.shape[0]
+    dev = viewmatrix.device
+    f32 = torch.float32
+    if scale is None:
+        scale = torch.ones(v, dtype=f32, device=dev)
+    scale = scale.to(f32).reshape(v, 1)
+    parts = [
+        viewmatrix.to(f32).reshape(v, 16), projmatrix.to(f32).reshape(v, 16), campos.to(f32).reshape(v, 3),
+        tanfovx.to(f32).reshape(v, 1), tanfovy.to(f32).reshape(v, 1), bg.to(f32).reshape(v, 3),
+        scale, scale * scale, torch.full((v, 1), float(scale_modifier), dtype=f32, device=dev),
+        torch.zeros((v, 5), dtype=f32, device=dev),
+    ]
+    out = torch.cat(parts, dim=1).contiguous()
+    assert out.shape == (v, VIEW_FLOATS)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# HIP backend: tensors in, tensors out, through the C ABI
+# --------------------------------------------------------------------------------------------------
+def _ptr(t: Optional[Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+class HipBackend:
+    """Calls libgsr_hip.so with raw device pointers on torch's current HIP stream."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.capacity_hint = {}  # (V, N, H, W) -> pairs needed last time
+        self.defer_status = False  # True: never read the status block back (caller checks later)
+        self.pending = []  # status tensors not yet checked (deferred mode)
+        self.last_status = None
+
+    @staticmethod
+    def _dims(cfg: RasterConfig, capacity: int) -> _lib.GsrDims:
+        return _lib.GsrDims(_lib.GSR_ABI_VERSION, cfg.num_views, cfg.num_sets, cfg.views_per_set, cfg.num_gaussians,
+                            cfg.height, cfg.width, cfg.sh_degree, cfg.sh_coeffs, cfg.max_sh_eval,
+                            int(cfg.has_extra), 0, int(capacity))
+
+    def workspace_sizes(self, dims: _lib.GsrDims):
+        g, b, i = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
+        rc = self.lib.gsr_workspace_sizes(ctypes.byref(dims), ctypes.byref(g), ctypes.byref(b), ctypes.byref(i))
+        if rc != 0:
+            raise RuntimeError(f"gsr_workspace_sizes rejected the call (code {rc}): {cfg_repr(dims)}")
+        return g.value, b.value, i.value
+
+    def workspace_layout(self, dims: _lib.GsrDims):
+        offs = (ctypes.c_int64 * 8)()
+        rc = self.lib.gsr_workspace_layout(ctypes.byref(dims), offs)
+        if rc != 0:
+            raise RuntimeError(f"gsr_workspace_layout failed (code {rc})")
+        return dict(zip(("status", "counts", "tile_total", "ranges", "keys", "point_list", "final_T", "n_contrib"),
+                        [int(o) for o in offs]))
+
+    def _check_device(self, *tensors):
+        for t in tensors:
+            if t is not None and not t.is_cuda:
+                raise RuntimeError(
+                    "pf3plat_amd rasterizer: tensors must be on a ROCm device (there is no CPU fallback path)")
+
+    def _default_capacity(self, cfg: RasterConfig) -> int:
+        key = (cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width)
+        hint = self.capacity_hint.get(key)
+        if hint is not None:
+            return int(hint * 1.25) + 4096
+        return cfg.num_views * max(8 * cfg.num_gaussians, 1 << 18)
+
+    def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None):
+        self._check_device(viewbuf, means, cov6, opac, colors, extra)
+        dev = viewbuf.device
+        v, h, w, n = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians
+        cap = self._default_capacity(cfg) if capacity is None else int(capacity)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        color = torch.empty((v, 3, h, w), dtype=torch.float32, device=dev)
+        extra_img = torch.empty((v, h, w), dtype=torch.float32, device=dev) if cfg.has_extra else None
+        radii = torch.empty((v, n), dtype=torch.int32, device=dev)
+        for attempt in range(3):
+            dims = self._dims(cfg, cap)
+            gb, bb, ib = self.workspace_sizes(dims)
+            geom = torch.empty(gb, dtype=torch.uint8, device=dev)
+            binb = torch.empty(bb, dtype=torch.uint8, device=dev)
+            img = torch.empty(ib, dtype=torch.uint8, device=dev)
+            rc = self.lib.gsr_forward(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac),
+                                      _ptr(colors), _ptr(extra), _ptr(color), _ptr(extra_img), _ptr(radii),
+                                      _ptr(geom), _ptr(binb), _ptr(img), stream)
+            if rc != 0:
+                raise RuntimeError(f"gsr_forward failed with code {rc}")
+            saved = (dims, geom, binb, img)
+            if self.defer_status or n == 0:
+                if n > 0:
+                    self.pending.append(binb[:16])
+                return color, extra_img, radii, saved
+            st = binb[:16].cpu()  # one small D2H read (the reference extension also reads its pair count back)
+            num_pairs = int(st[:8].view(torch.int64).item())
+            overflow = int(st[8:12].view(torch.int32).item())
+            self.last_status = {"num_pairs": num_pairs, "overflow": overflow, "max_list": int(st[12:16].view(torch.int32).item())}
+            self.capacity_hint[(v, n, h, w)] = num_pairs
+            if not overflow:
+                return color, extra_img, radii, saved
+            cap = int(num_pairs * 1.05) + 4096
+        raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
+
+    def check_pending(self):
+        """Deferred mode: verify that no forward since the last check overflowed its pair workspace."""
+        bad = 0
+        for s in self.pending:
+            st = s.cpu()
+            bad += int(st[8:12].view(torch.int32).item())
+        self.pending = []
+        if bad:
+            raise RuntimeError(f"{bad} deferred gsr_forward call(s) overflowed the pair workspace; results invalid")
+
+    def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
+                 want_means2d: bool):
+        dims, geom, binb, img = saved
+        dev = viewbuf.device
+        v, n = cfg.num_views, cfg.num_gaussians
+        s = cfg.num_sets
+        f32 = torch.float32
+        d_means = torch.empty((s, n, 3), dtype=f32, device=dev)
+        d_cov6 = torch.empty((s, n, 6), dtype=f32, device=dev)
+        d_opac = torch.empty((s, n), dtype=f32, device=dev)
+        d_colors = torch.empty_like(colors)
+        d_extra = torch.empty((v, n), dtype=f32, device=dev) if cfg.has_extra else None
+        d_means2d = torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None
+        if n == 0 or v == 0:
+            return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d
+        scratch = torch.empty(v * n * _lib.SCREEN_GRAD_FLOATS, dtype=f32, device=dev)
+        g_color = g_color.contiguous().to(f32)
+        if cfg.has_extra:
+            g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
+                           else g_extra_img.contiguous().to(f32))
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        rc = self.lib.gsr_backward(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
+                                   _ptr(extra), _ptr(geom), _ptr(binb), _ptr(img), _ptr(g_color),
+                                   _ptr(g_extra_img if cfg.has_extra else None), _ptr(scratch), _ptr(d_means),
+                                   _ptr(d_cov6), _ptr(d_opac), _ptr(d_colors), _ptr(d_extra), _ptr(d_means2d), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_backward failed with code {rc}")
+        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d
+
+    def mark_visible(self, cfg: RasterConfig, viewbuf, means):
+        self._check_device(viewbuf, means)
+        present = torch.empty((cfg.num_sets, cfg.num_gaussians), dtype=torch.uint8, device=means.device)
+        dims = self._dims(cfg, 0)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(means.device).cuda_stream)
+        rc = self.lib.gsr_mark_visible(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(present), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_mark_visible failed with code {rc}")
+        return present.bool()
+
+
+def cfg_repr(dims) -> str:
+    return ", ".join(f"{n}={getattr(dims, n)}" for n, _ in dims._fields_)
+
+
+_BACKEND = None
+
+
+def get_backend():
+    """The process-wide raster backend (the HIP library).  Fails loudly if it cannot be loaded."""
+    global _BACKEND
+    if _BACKEND is None:
+        _BACKEND = HipBackend()
+    return _BACKEND
+
+
+def set_backend(backend):
+    """Install another backend object (same forward/backward/mark_visible methods).  Test hook only:
+    tests/ use it to drive the host-side wrappers on CPU tensors; the product never calls it."""
+    global _BACKEND
+    old, _BACKEND = _BACKEND, backend
+    return old
+
+
+# --------------------------------------------------------------------------------------------------
+# autograd
+# --------------------------------------------------------------------------------------------------
+class _RasterizeViews(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, cov6, opac, colors, extra, means2d, viewbuf, cfg: RasterConfig):
+        backend = get_backend()
+        color, extra_img, radii, saved = backend.forward(cfg, viewbuf, means, cov6, opac, colors, extra)
+        ctx.cfg = cfg
+        ctx.saved_ws = saved
+        ctx.backend = backend
+        ctx.want_means2d = means2d is not None
+        ctx.save_for_backward(means, cov6, opac, colors, extra if extra is not None else torch.empty(0), viewbuf)
+        ctx.mark_non_differentiable(radii)
+        if extra_img is None:
+            extra_img = torch.empty(0, device=color.device)
+            ctx.mark_non_differentiable(extra_img)
+        return color, extra_img, radii
+
+    @staticmethod
+    def backward(ctx, g_color, g_extra_img, _g_radii):
+        means, cov6, opac, colors, extra, viewbuf = ctx.saved_tensors
+        cfg = ctx.cfg
+        if not cfg.has_extra:
+            extra, g_extra_img = None, None
+        if g_color is None:
+            g_color = torch.zeros((cfg.num_views, 3, cfg.height, cfg.width), dtype=torch.float32, device=means.device)
+        d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
+            cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d)
+        ctx.saved_ws = None
+        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, None, None
+
+
+def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
+                    image_shape, sh_degree: int, use_sh: bool, views_per_set: int, extra: Optional[Tensor] = None,
+                    means2d: Optional[Tensor] = None, max_sh_eval: int = 4):
+    """Render V = num_sets * views_per_set views in one launch chain.
+
+    means (S,N,3), cov6 (S,N,6), opacities (S,N), colors (S,N,M,3) if use_sh else (S,N,3),
+    viewbuf (V,48) from `pack_views` (set-major), extra (V,N) optional 4th blended channel.
+    Returns (color (V,3,H,W), extra_img (V,H,W) | None, radii (V,N) int32).  Differentiable w.r.t. means,
+    cov6, opacities, colors, extra (and means2d receives the screen-space gradient); cameras get none,
+    like the reference operator.
+    """
+    s, n = means.shape[0], means.shape[1]
+    v = viewbuf.shape[0]
+    if v != s * views_per_set:
+        raise ValueError(f"{v} views != {s} sets x {views_per_set} views per set")
+    h, w = image_shape
+    f32 = torch.float32
+    means = means.to(f32).contiguous()
+    cov6 = cov6.to(f32).contiguous()
+    opacities = opacities.to(f32).contiguous()
+    colors = colors.to(f32).contiguous()
+    if extra is not None:
+        extra = extra.to(f32).contiguous()
+    m = colors.shape[2] if use_sh else 0
+    if use_sh and colors.dim() != 4:
+        raise ValueError("shs must be (sets, N, M, 3)")
+    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), extra is not None)
+    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg)
+    return color, (extra_img if extra is not None else None), radii
+
+
+def _cov3d_from_scale_rotation(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+    """[EXT] forward.cu computeCov3D as differentiable torch ops: quaternion (r,x,y,z), not normalised."""
+    r, x, y, z = rotations.unbind(-1)
+    rm = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                      2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)), -1).reshape(-1, 3, 3)
+    sc = scales * scale_modifier
+    sigma = rm @ torch.diag_embed(sc * sc) @ rm.transpose(-1, -2)
+    return torch.stack((sigma[:, 0, 0], sigma[:, 0, 1], sigma[:, 0, 2], sigma[:, 1, 1], sigma[:, 1, 2], sigma[:, 2, 2]), -1)
+
+
+class GaussianRasterizer(nn.Module):
+    """Per-view operator with the upstream call signature (reference cuda_splatting.py:113-124)."""
+
+    def __init__(self, raster_settings: GaussianRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def _viewbuf(self, device) -> Tensor:
+        rs = self.raster_settings
+
+        def scalar(x):
+            if torch.is_tensor(x):
+                return x.reshape(-1)[:1].to(device=device, dtype=torch.float32)
+            return torch.tensor([float(x)], dtype=torch.float32, device=device)
+
+        return pack_views(rs.viewmatrix.to(device)[None], rs.projmatrix.to(device)[None], rs.campos.to(device)[None],
+                          scalar(rs.tanfovx), scalar(rs.tanfovy), rs.bg.to(device)[None], None, float(rs.scale_modifier))
+
+    def markVisible(self, positions: Tensor) -> Tensor:
+        with torch.no_grad():
+            rs = self.raster_settings
+            cfg = RasterConfig(1, 1, 1, positions.shape[0], int(rs.image_height), int(rs.image_width), 0, 0)
+            return get_backend().mark_visible(cfg, self._viewbuf(positions.device), positions.float().contiguous()[None])[0]
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        rs = self.raster_settings
+        if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+            raise Exception("Please provide excatly one of either SHs or precomputed colors!")
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception("Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        if means3D.dim() != 2 or means3D.shape[1] != 3:
+            raise RuntimeError("means3D must have dimensions (num_points, 3)")
+        n = means3D.shape[0]
+        if cov3D_precomp is None:
+            cov3D_precomp = _cov3d_from_scale_rotation(scales.float(), rotations.float(), float(rs.scale_modifier))
+        use_sh = shs is not None
+        colors = shs if use_sh else colors_precomp
+        color, _, radii = rasterize_views(
+            means3D[None], cov3D_precomp.reshape(n, 6)[None], opacities.reshape(n)[None], colors[None],
+            self._viewbuf(means3D.device), image_shape=(int(rs.image_height), int(rs.image_width)),
+            sh_degree=int(rs.sh_degree), use_sh=use_sh, views_per_set=1,
+            means2d=means2D[None] if means2D is not None else None)
+        return color[0], radii[0]

@@ -1,0 +1,105 @@
+"""Deterministic PF3plat-shaped synthetic scenes (SURVEY.md §8d "Synthetic scene generator").
+
+There is no dataset and no encoder in this build; the bench and the parity tests need Gaussians
+whose screen-space footprint distribution looks like what PF3plat's `GaussianAdapter` emits
+(reference src/model/encoder/common/gaussian_adapter.py:48-111): pixel-aligned Gaussians
+un-projected from two context cameras, scale proportional to depth x pixel size, random unit
+quaternions, sigmoid opacities and SH coefficients masked towards the DC band.
+
+All randomness comes from one CPU `torch.Generator`, so a (seed, N, H, W) tuple names one scene
+on every machine; tensors are moved to `device` afterwards.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+from torch import Tensor
+
+from .types import Gaussians
+
+
+@dataclass
+class Scene:
+    gaussians: Gaussians  # batch = 1
+    extrinsics: Tensor  # (1, v, 4, 4) camera-to-world, OpenCV convention
+    intrinsics: Tensor  # (1, v, 3, 3) normalised
+    near: Tensor  # (1, v)
+    far: Tensor  # (1, v)
+    image_shape: tuple
+    background: Tensor  # (3,)
+
+    def to(self, device) -> "Scene":
+        g = self.gaussians
+        return Scene(
+            Gaussians(g.means.to(device), g.covariances.to(device), g.harmonics.to(device), g.opacities.to(device)),
+            self.extrinsics.to(device), self.intrinsics.to(device), self.near.to(device), self.far.to(device),
+            self.image_shape, self.background.to(device),
+        )
+
+
+def _quat_xyzw_to_matrix(q: Tensor) -> Tensor:
+    i, j, k, r = q.unbind(-1)
+    two_s = 2 / (q * q).sum(-1)
+    o = torch.stack(
+        (1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+         two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+         two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(*q.shape[:-1], 3, 3)
+
+
+def make_scene(seed: int, num_gaussians: int, image_shape=(256, 256), d_sh: int = 25, num_views: int = 1,
+               view_offsets=None, near: float = 1.0, far: float = 100.0, device="cpu") -> Scene:
+    """Seeded scene: Gaussians + `num_views` render cameras.
+
+    Render camera 0 is c2w = I; further views are shifted along x by `view_offsets` (default: evenly
+    spaced in [-0.25, 0.25], i.e. between the two source cameras at x = -0.5 / +0.5).
+    """
+    g = torch.Generator().manual_seed(int(seed))
+    h, w = image_shape
+    n = int(num_gaussians)
+    f = 0.86
+    k = torch.tensor([[f, 0, 0.5], [0, f, 0.5], [0, 0, 1]], dtype=torch.float32)
+
+    def rand(*s):
+        return torch.rand(*s, generator=g, dtype=torch.float32)
+
+    def randn(*s):
+        return torch.randn(*s, generator=g, dtype=torch.float32)
+
+    # two "context" cameras, half the Gaussians each
+    src_x = torch.where(torch.arange(n) < n // 2, -0.5, 0.5).to(torch.float32)
+    u = rand(n, 2)
+    ray = torch.stack(((u[:, 0] - 0.5) / f, (u[:, 1] - 0.5) / f, torch.ones(n)), -1)
+    ray = ray / ray.norm(dim=-1, keepdim=True)
+    depth = torch.exp(rand(n) * math.log(20.0))
+    means = ray * depth[:, None]
+    means[:, 0] += src_x
+    m = 0.1 * (1.0 / (f * w) + 1.0 / (f * h))
+    scales = (0.5 + 14.5 * torch.sigmoid(randn(n, 3))) * depth[:, None] * m
+    quat = randn(n, 4)
+    quat = quat / quat.norm(dim=-1, keepdim=True)
+    rot = _quat_xyzw_to_matrix(quat)
+    cov = rot @ torch.diag_embed(scales * scales) @ rot.transpose(-1, -2)
+    cov = 0.5 * (cov + cov.transpose(-1, -2))
+    opac = torch.sigmoid(randn(n))
+    deg = math.isqrt(d_sh) - 1
+    mask = torch.ones(d_sh)
+    for l in range(1, deg + 1):
+        mask[l * l:(l + 1) * (l + 1)] = 0.1 * 0.25 ** l
+    sh = randn(n, 3, d_sh) * mask
+
+    if view_offsets is None:
+        view_offsets = [0.0] if num_views == 1 else [(-0.25 + 0.5 * i / (num_views - 1)) for i in range(num_views)]
+    assert len(view_offsets) == num_views
+    c2w = torch.eye(4).repeat(num_views, 1, 1)
+    for i, ox in enumerate(view_offsets):
+        c2w[i, 0, 3] = float(ox)
+    scene = Scene(
+        Gaussians(means[None], cov[None], sh[None], opac[None]),
+        c2w[None], k.repeat(1, num_views, 1, 1),
+        torch.full((1, num_views), float(near)), torch.full((1, num_views), float(far)),
+        (h, w), torch.zeros(3),
+    )
+    return scene.to(device)

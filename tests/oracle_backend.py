@@ -1,0 +1,104 @@
+"""Test-only raster backend that answers `rasterize_views` with the CPU oracle.
+
+It has the same forward/backward/mark_visible methods as pf3plat_amd.rasterizer.HipBackend, works on
+CPU tensors, and evaluates the batched operator view by view exactly as the reference wrapper would
+feed the per-view rasterizer (means * scale, cov * scale^2, one call per view; gradients of views that
+share a Gaussian set are summed with the scale factors applied).  Used (a) to drive the host-side
+wrappers on CPU in `-m "not gpu"` tests and (b) as the checker the HIP path is compared with in the
+`-m gpu` tests.  Never imported by the product.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from oracle import OracleRasterizer
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, dtype=np.float32, threads: int = 1, max_sh_eval=None):
+        self.dtype = np.dtype(dtype)
+        self.threads = threads
+        self.max_sh_eval = max_sh_eval
+        self.calls = []  # per forward: list of per-view kwargs actually handed to the per-view rasterizer
+        self.record = False
+        self.last_stats = None
+
+    def _view_fields(self, viewbuf, v):
+        vb = viewbuf[v].detach().cpu().numpy().astype(np.float32)
+        return dict(viewmatrix=vb[0:16], projmatrix=vb[16:32], campos=vb[32:35], tanfovx=vb[35], tanfovy=vb[36],
+                    bg=vb[37:40], scale=vb[40], scale2=vb[41], scale_modifier=vb[42])
+
+    def forward(self, cfg, viewbuf, means, cov6, opac, colors, extra, capacity=None):
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
+        color = torch.zeros((V, 3, H, W), dtype=tdt)
+        extra_img = torch.zeros((V, H, W), dtype=tdt) if cfg.has_extra else None
+        radii = torch.zeros((V, N), dtype=torch.int32)
+        handles, percall, stats = [], [], []
+        for v in range(V):
+            s = v // cfg.views_per_set
+            f = self._view_fields(viewbuf, v)
+            # fp32 multiplies, as the reference wrapper does with torch (cuda_splatting.py:69-70)
+            m = (means[s].detach().cpu().numpy().astype(np.float32) * np.float32(f["scale"]))
+            c = (cov6[s].detach().cpu().numpy().astype(np.float32) * np.float32(f["scale2"]))
+            col = colors[s].detach().cpu().numpy()
+            kw = dict(height=H, width=W, tanfovx=float(f["tanfovx"]), tanfovy=float(f["tanfovy"]), bg=f["bg"],
+                      viewmatrix=f["viewmatrix"], projmatrix=f["projmatrix"], campos=f["campos"],
+                      sh_degree=cfg.sh_degree, means3D=m, opacities=opac[s].detach().cpu().numpy(), cov3D_precomp=c,
+                      extra=None if extra is None else extra[v].detach().cpu().numpy())
+            if cfg.sh_coeffs > 0:
+                kw["shs"] = col
+            else:
+                kw["colors_precomp"] = col
+            o = OracleRasterizer(self.dtype, threads=self.threads,
+                                 max_sh_eval=cfg.max_sh_eval if self.max_sh_eval is None else self.max_sh_eval)
+            res = o.forward(**kw)
+            color[v] = torch.from_numpy(res.color)
+            if cfg.has_extra:
+                extra_img[v] = torch.from_numpy(res.extra)
+            radii[v] = torch.from_numpy(res.radii)
+            handles.append((o, f))
+            stats.append(res)
+            if self.record:
+                percall.append(kw)
+        if self.record:
+            self.calls.append(percall)
+        self.last_stats = stats
+        return color, extra_img, radii, handles
+
+    def backward(self, cfg, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d):
+        tdt = torch.float32 if self.dtype == np.float32 else torch.float64
+        V, N, S = cfg.num_views, cfg.num_gaussians, cfg.num_sets
+        d_means = torch.zeros((S, N, 3), dtype=tdt)
+        d_cov6 = torch.zeros((S, N, 6), dtype=tdt)
+        d_opac = torch.zeros((S, N), dtype=tdt)
+        d_colors = torch.zeros(tuple(colors.shape), dtype=tdt)
+        d_extra = torch.zeros((V, N), dtype=tdt) if cfg.has_extra else None
+        d_m2d = torch.zeros((V, N, 3), dtype=tdt) if want_means2d else None
+        for v in range(V):
+            s = v // cfg.views_per_set
+            o, f = saved[v]
+            g = o.backward(g_color[v].detach().cpu().numpy(),
+                           None if g_extra_img is None or not cfg.has_extra else g_extra_img[v].detach().cpu().numpy())
+            d_means[s] += torch.from_numpy(g["means3D"]) * float(f["scale"])
+            d_cov6[s] += torch.from_numpy(g["cov3D_precomp"]) * float(f["scale2"])
+            d_opac[s] += torch.from_numpy(g["opacities"])
+            d_colors[s] += torch.from_numpy(g["colors"])
+            if cfg.has_extra:
+                d_extra[v] = torch.from_numpy(g["extra"])
+            if want_means2d:
+                d_m2d[v] = torch.from_numpy(g["means2D"])
+        return d_means, d_cov6, d_opac, d_colors, d_extra, d_m2d
+
+    def mark_visible(self, cfg, viewbuf, means):
+        out = torch.zeros((cfg.num_sets, cfg.num_gaussians), dtype=torch.bool)
+        for s in range(cfg.num_sets):
+            f = self._view_fields(viewbuf, s * cfg.views_per_set)
+            m = means[s].detach().cpu().numpy().astype(np.float32) * np.float32(f["scale"])
+            vm = f["viewmatrix"]
+            z = vm[2] * m[:, 0] + vm[6] * m[:, 1] + vm[10] * m[:, 2] + vm[14]
+            out[s] = torch.from_numpy(~(z <= np.float32(0.2)))
+        return out
