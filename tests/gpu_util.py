@@ -1,0 +1,95 @@
+"""Helpers for the `-m gpu` parity tests: run the HIP library through the product's operator surface and the
+CPU oracle on the same inputs, and decode the library's workspaces for stage-level comparisons."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from pf3plat_amd import rasterizer
+from pf3plat_amd.rasterizer import RasterConfig, pack_views
+from tests.oracle_backend import OracleBackend
+from tests.util import make_camera
+
+
+def viewbuf_from_cams(cams, bgs, scales=None, device="cpu"):
+    v = len(cams)
+    vm = torch.tensor(np.stack([c["viewmatrix"] for c in cams]).reshape(v, 4, 4), dtype=torch.float32)
+    pm = torch.tensor(np.stack([c["projmatrix"] for c in cams]).reshape(v, 4, 4), dtype=torch.float32)
+    cp = torch.tensor(np.stack([c["campos"] for c in cams]), dtype=torch.float32)
+    tx = torch.tensor([c["tanfovx"] for c in cams], dtype=torch.float32)
+    ty = torch.tensor([c["tanfovy"] for c in cams], dtype=torch.float32)
+    bg = torch.tensor(np.asarray(bgs, dtype=np.float32).reshape(v, 3))
+    sc = None if scales is None else torch.tensor(np.asarray(scales, dtype=np.float32))
+    return pack_views(vm, pm, cp, tx, ty, bg, sc).to(device)
+
+
+def decode_workspaces(backend, cfg: RasterConfig, saved):
+    """-> dict of numpy arrays: geom (V,N,12 f32 + bits), ranges (V,T,2), point_list, keys, final_T, n_contrib, status."""
+    dims, geom, binb, img = saved
+    lay = backend.workspace_layout(dims)
+    V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
+    sgx, sgy = 2 * ((W + 15) // 16), 2 * ((H + 15) // 16)
+    T = sgx * sgy
+    g = geom[: V * N * 48].view(torch.float32).reshape(V, N, 12).cpu().numpy()
+    bits = geom[: V * N * 48].view(torch.int32).reshape(V, N, 12)[:, :, 11].cpu().numpy()
+    b = binb.cpu()
+    st = b[:16]
+    num_pairs = int(st[:8].view(torch.int64).item())
+    ranges = b[lay["ranges"]: lay["ranges"] + V * T * 8].view(torch.int32).reshape(V, T, 2).numpy()
+    cap = int(dims.pair_capacity)
+    plist = b[lay["point_list"]: lay["point_list"] + cap * 4].view(torch.int32).numpy()[:num_pairs]
+    keys = b[lay["keys"]: lay["keys"] + cap * 8].view(torch.int64).numpy()[:num_pairs]
+    im = img.cpu()
+    final_T = im[lay["final_T"]: lay["final_T"] + V * H * W * 4].view(torch.float32).reshape(V, H, W).numpy()
+    n_contrib = im[lay["n_contrib"]: lay["n_contrib"] + V * H * W * 4].view(torch.int32).reshape(V, H, W).numpy()
+    return dict(geom=g, radius=bits & 0x0FFFFFFF, clamped=(bits >> 28) & 7, ranges=ranges, point_list=plist, keys=keys,
+                final_T=final_T, n_contrib=n_contrib, num_pairs=num_pairs, overflow=int(st[8:12].view(torch.int32).item()),
+                max_list=int(st[12:16].view(torch.int32).item()), sgx=sgx, sgy=sgy, T=T)
+
+
+def run_both(cfg: RasterConfig, viewbuf_cpu, means, cov6, opac, colors, extra=None, g_color=None, g_extra=None,
+             oracle_dtype=np.float32, want_means2d=True, capacity=None):
+    """Forward (+ backward if g_color is given) on the HIP backend and on the oracle.  Inputs are CPU torch tensors."""
+    dev = torch.device("cuda:0")
+    hip = rasterizer.HipBackend()
+    args_cpu = (means, cov6, opac, colors, extra)
+    args_gpu = tuple(None if a is None else a.to(dev).contiguous() for a in args_cpu)
+    vb_gpu = viewbuf_cpu.to(dev)
+    hc, he, hr, hsaved = hip.forward(cfg, vb_gpu, *args_gpu, capacity=capacity)
+    torch.cuda.synchronize()
+    ob = OracleBackend(dtype=oracle_dtype, threads=8)
+    oc, oe, orad, osaved = ob.forward(cfg, viewbuf_cpu, *args_cpu)
+    out = dict(hip=dict(color=hc.cpu().numpy(), extra=None if he is None else he.cpu().numpy(), radii=hr.cpu().numpy(),
+                        ws=decode_workspaces(hip, cfg, hsaved), status=hip.last_status),
+               oracle=dict(color=oc.numpy(), extra=None if oe is None else oe.numpy(), radii=orad.numpy(), handles=osaved,
+                           stats=ob.last_stats))
+    if g_color is not None:
+        hg = hip.backward(cfg, hsaved, vb_gpu, *args_gpu, g_color.to(dev), None if g_extra is None else g_extra.to(dev),
+                          want_means2d)
+        torch.cuda.synchronize()
+        og = ob.backward(cfg, osaved, viewbuf_cpu, *args_cpu, g_color, g_extra, want_means2d)
+        names = ("means", "cov6", "opac", "colors", "extra", "means2d")
+        out["hip"]["grads"] = {n: (None if t is None else t.cpu().numpy()) for n, t in zip(names, hg)}
+        out["oracle"]["grads"] = {n: (None if t is None else t.numpy()) for n, t in zip(names, og)}
+    return out
+
+
+def scene_tensors(scene, use_sh=True):
+    """pf3plat_amd.synthetic.Scene (batch 1) -> (means (1,N,3), cov6 (1,N,6), opac (1,N), colors (1,N,M,3))."""
+    g = scene.gaussians
+    cov = g.covariances
+    cov6 = torch.stack((cov[..., 0, 0], cov[..., 0, 1], cov[..., 0, 2], cov[..., 1, 1], cov[..., 1, 2], cov[..., 2, 2]), -1)
+    colors = g.harmonics.permute(0, 1, 3, 2).contiguous()
+    if not use_sh:
+        colors = colors[:, :, 0, :].contiguous()
+    return g.means.contiguous(), cov6.contiguous(), g.opacities.contiguous(), colors
+
+
+def scene_viewbuf(scene, scale_invariant=True):
+    """Camera records of a synthetic Scene, built by the product's own camera set-up."""
+    from pf3plat_amd.splatting import _cameras
+
+    s, v = scene.extrinsics.shape[:2]
+    vm, fp, cp, tx, ty, sc = _cameras(scene.extrinsics.reshape(s * v, 4, 4), scene.intrinsics.reshape(s * v, 3, 3),
+                                      scene.near.reshape(s * v), scene.far.reshape(s * v), scale_invariant)
+    return pack_views(vm, fp, cp, tx, ty, scene.background.reshape(1, 3).expand(s * v, 3), sc)

@@ -1,0 +1,138 @@
+"""Stage-level comparison functions HIP-vs-oracle (numpy).  Each returns a dict of metrics and raises AssertionError
+with the numbers when a bound is violated.  Used by tests/test_gpu_*.py and tools/gpu_bringup.py."""
+from __future__ import annotations
+
+import numpy as np
+
+from tests.util import psnr, rel_l2
+
+TOL = 1e-4  # north_star: "within 1e-4 relative fp32"
+
+
+def check_preprocess(res, cfg, v=0):
+    """Projected records vs oracle geometry for view v."""
+    ws = res["hip"]["ws"]
+    o, _ = res["oracle"]["handles"][v]
+    geo = o.geometry()
+    g = ws["geom"][v]
+    m = {}
+    rad_h, rad_o = ws["radius"][v], res["oracle"]["radii"][v]
+    m["radii_mismatch"] = int((rad_h != rad_o).sum())
+    m["radii_out_mismatch"] = int((res["hip"]["radii"][v] != rad_o).sum())
+    vis = (rad_o > 0) & (rad_h > 0)
+    m["n_visible"] = int((rad_o > 0).sum())
+    if vis.any():
+        hx = g[vis]
+        pairs = {
+            "xy": (hx[:, 0:2], geo["xy"][vis]),
+            "conic": (np.stack([hx[:, 2], hx[:, 3], hx[:, 4]], -1), geo["conic_opacity"][vis][:, :3]),
+            "opacity": (hx[:, 5], geo["conic_opacity"][vis][:, 3]),
+            "rgb": (np.stack([hx[:, 6], hx[:, 7], hx[:, 8]], -1), geo["rgb"][vis]),
+            "depth": (hx[:, 10], geo["depth"][vis]),
+        }
+        for k, (a, b) in pairs.items():
+            m[k + "_rel"] = rel_l2(a, b)
+            m[k + "_exact_frac"] = float((a == b).mean())
+        m["clamped_mismatch"] = int((ws["clamped"][v][vis] != (geo["clamped"][vis] * np.array([1, 2, 4])).sum(-1)).sum())
+    assert m["radii_mismatch"] <= max(2, int(2e-5 * cfg.num_gaussians)), m
+    assert m["radii_out_mismatch"] == m["radii_mismatch"], m
+    for k in ("xy", "conic", "opacity", "rgb", "depth"):
+        if k + "_rel" in m:
+            assert m[k + "_rel"] < 1e-5, (k, m)
+    return m
+
+
+def _contributing(geo, ids, px0, py0, W, H):
+    """Which of `ids` reach alpha >= 1/255 (with power <= 0) at some pixel of the 8x8 tile at (px0, py0)? fp32 numpy."""
+    xs = np.arange(px0, min(px0 + 8, W), dtype=np.float32)
+    ys = np.arange(py0, min(py0 + 8, H), dtype=np.float32)
+    if len(xs) == 0 or len(ys) == 0 or len(ids) == 0:
+        return np.zeros(len(ids), bool)
+    xy = geo["xy"][ids].astype(np.float32)
+    co = geo["conic_opacity"][ids].astype(np.float32)
+    dx = xy[:, 0][:, None, None] - xs[None, None, :]
+    dy = xy[:, 1][:, None, None] - ys[None, :, None]
+    power = np.float32(-0.5) * (co[:, 0, None, None] * dx * dx + co[:, 2, None, None] * dy * dy) - co[:, 1, None, None] * dx * dy
+    alpha = np.minimum(np.float32(0.99), co[:, 3, None, None] * np.exp(power))
+    ok = (power <= 0) & (alpha >= np.float32(1.0 / 255.0))
+    return ok.reshape(len(ids), -1).any(1)
+
+
+def check_tile_lists(res, cfg, v=0, max_tiles=None, rng=None):
+    """Each 8x8 tile's list is sorted by (depth, id), is a subset of the reference's 16x16-tile list for the parent
+    tile, and contains every splat of that list that can contribute in the tile (so dropping the rest changes nothing)."""
+    ws = res["hip"]["ws"]
+    o, _ = res["oracle"]["handles"][v]
+    geo = o.geometry()
+    binn = o.binning()
+    W, H = cfg.width, cfg.height
+    gx16 = (W + 15) // 16
+    sgx, T = ws["sgx"], ws["T"]
+    depth_bits = geo["depth"].astype(np.float32).view(np.uint32).astype(np.int64)
+    tiles = np.arange(T)
+    if max_tiles is not None and T > max_tiles:
+        tiles = (rng or np.random.default_rng(0)).choice(T, max_tiles, replace=False)
+    m = dict(unsorted=0, not_subset=0, missing=0, pairs=0, pairs16=int(len(binn["point_list"])), checked_tiles=len(tiles),
+             extra_kept=0)
+    for t in tiles:
+        tx, ty = int(t % sgx), int(t // sgx)
+        a, b = ws["ranges"][v, t]
+        ids = ws["point_list"][a:b].astype(np.int64)
+        m["pairs"] += len(ids)
+        if tx * 8 >= W or ty * 8 >= H:
+            assert len(ids) == 0, ("tile outside image has entries", t)
+            continue
+        key = depth_bits[ids] * (1 << 32) + ids
+        m["unsorted"] += int((np.diff(key) <= 0).sum())
+        p = (ty // 2) * gx16 + (tx // 2)
+        pa, pb = binn["ranges"][p]
+        parent = binn["point_list"][pa:pb].astype(np.int64)
+        m["not_subset"] += int((~np.isin(ids, parent)).sum())
+        need = parent[_contributing(geo, parent, tx * 8, ty * 8, W, H)]
+        m["missing"] += int((~np.isin(need, ids)).sum())
+        m["extra_kept"] += len(ids) - len(need)
+    assert m["unsorted"] == 0 and m["not_subset"] == 0 and m["missing"] == 0, m
+    return m
+
+
+def check_image(res, cfg, tol=TOL):
+    m = {}
+    hc, oc = res["hip"]["color"], res["oracle"]["color"]
+    m["color_rel_l2"] = rel_l2(hc, oc)
+    d = np.abs(hc.astype(np.float64) - oc)
+    m["color_max_abs"] = float(d.max()) if d.size else 0.0
+    m["outlier_pixels_1e-4"] = int((d.max(1) > 1e-4).sum()) if d.size else 0
+    m["psnr_hip_vs_oracle"] = psnr(hc, oc)
+    if res["hip"]["extra"] is not None:
+        m["extra_rel_l2"] = rel_l2(res["hip"]["extra"], res["oracle"]["extra"])
+    assert np.isfinite(hc).all(), "non-finite pixels"
+    assert m["color_rel_l2"] < tol, m
+    if "extra_rel_l2" in m:
+        assert m["extra_rel_l2"] < tol, m
+    npx = hc.shape[0] * hc.shape[2] * hc.shape[3]
+    assert m["outlier_pixels_1e-4"] <= max(4, int(2e-3 * npx)), m
+    return m
+
+
+def check_image_state(res, cfg, v=0):
+    ws = res["hip"]["ws"]
+    o, _ = res["oracle"]["handles"][v]
+    st = o.image_state()
+    m = {"final_T_rel": rel_l2(ws["final_T"][v], st["final_T"])}
+    assert m["final_T_rel"] < 1e-4, m
+    return m
+
+
+def check_grads(res, cfg, tol=TOL):
+    m = {}
+    for k, hv in res["hip"]["grads"].items():
+        ov = res["oracle"]["grads"][k]
+        if hv is None or ov is None:
+            continue
+        assert np.isfinite(hv).all(), f"non-finite gradient {k}"
+        m[k + "_rel_l2"] = rel_l2(hv, ov)
+        m[k + "_norm"] = float(np.linalg.norm(ov))
+    for k, val in m.items():
+        if k.endswith("_rel_l2") and m[k.replace("_rel_l2", "_norm")] > 0:
+            assert val < tol, (k, m)
+    return m
