@@ -1,0 +1,275 @@
+#!/usr/bin/env python
+"""bench.py — the hot path's headline benchmark (BASELINE.json metric) on N MI355X GPUs of one node.
+
+A "step" is one forward raster of ONE 256x256 view of a 300 000-Gaussian synthetic PF3plat-shaped scene
+(BASELINE.json configs[1]; scene seed 2 + rank) through the C ABI (gsr_forward), inputs already resident in
+HBM.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier + torch.cuda.synchronize();
+MAX over ranks; rank 0 prints ONE JSON line.  `value` = views rendered by all ranks / that time.
+
+N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL).  Views shard one scene per rank with no
+data-path collective; the rendered views of the K steps are all-gathered ONCE at the end of the timed region
+(one fused RCCL collective over xGMI, north_star), so scaling is "weak".
+
+After the timed region (never inside it): fwd+bwd timing (configs[2]), per-stage HIP-event timing of the same
+launch chain for the roofline object, a parity spot check and the CPU baseline (oracle, rank 0, N == 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+N_GAUSS, H, W, D_SH = 300_000, 256, 256, 25
+
+
+def reference_rect_stats(plan, cfg):
+    """N_v and R16 (sum of 16x16 tiles touched under the reference's ceil(3 sigma) rect rule) from the projected
+    records the forward left in HBM — the quantities SURVEY.md §8d's algorithmic-bytes formula is written in."""
+    n = cfg.num_gaussians
+    g = plan["geom"][: n * 48].view(torch.float32).reshape(n, 12)
+    r = (plan["geom"][: n * 48].view(torch.int32).reshape(n, 12)[:, 11] & 0x0FFFFFFF)
+    vis = r > 0
+    x, y, rf = g[:, 0], g[:, 1], r.to(torch.float32)
+    gx, gy = (cfg.width + 15) // 16, (cfg.height + 15) // 16
+
+    def cl(v, hi):
+        return torch.clamp(torch.trunc(torch.clamp(v, -1e9, 1e9)), 0, hi)
+
+    area = (cl((x + rf + 15) / 16, gx) - cl((x - rf) / 16, gx)) * (cl((y + rf + 15) / 16, gy) - cl((y - rf) / 16, gy))
+    return int(vis.sum().item()), int(area[vis].sum().item())
+
+
+def algorithmic_bytes(n, nv, r16, hw, k_sh, save_state=True):
+    """SURVEY.md §8d FWD_BYTES split by stage."""
+    kc = 12 * k_sh
+    pre = 12 * n + nv * (24 + 4 + kc) + nv * 40
+    binning = r16 * 16
+    blend = r16 * 36 + hw * (12 + (8 if save_state else 0))
+    return {"preprocess": pre, "binning": binning, "blend": blend, "total": pre + binning + blend}
+
+
+def backward_bytes(n, nv, r16, hw, k_sh):
+    kc = 12 * k_sh
+    return hw * (12 + 8) + r16 * (8 + 36) + nv * 80 + nv * (12 + 24 + kc) + n * (12 + 24 + 4 + kc)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches only (no HIP-graph replay)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gaussians", type=int, default=N_GAUSS, help=argparse.SUPPRESS)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from pf3plat_amd import synthetic
+    from pf3plat_amd.distributed import gather_views
+    from pf3plat_amd.rasterizer import HipBackend, RasterConfig
+
+    K, Wm, n = args.steps, args.warmup, args.gaussians
+    scene = synthetic.make_scene(2 + rank, n, (H, W), d_sh=D_SH)
+    means, cov6, opac, shs = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(scene))
+    viewbuf = synthetic.scene_viewbuf(scene).to(dev)
+    cfg = RasterConfig(1, 1, 1, n, H, W, 4, D_SH, 4, False)
+    be = HipBackend()
+
+    # size the pair workspace once (blocking status read, outside any timed region)
+    plan = be.make_plan(cfg, dev, capacity=8 * n, backward=True)
+    be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+    st = be.read_status(plan)
+    if st["overflow"]:
+        plan = be.make_plan(cfg, dev, capacity=int(st["num_pairs"] * 1.1), backward=True)
+    else:
+        plan = be.make_plan(cfg, dev, capacity=int(st["num_pairs"] * 1.1) + 4096, backward=True)
+
+    def step():
+        be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- optional HIP-graph capture of one step (launch-bound chain of 6 kernels + 1 memset)
+    graph = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            g.replay()
+            torch.cuda.synchronize()
+            graph = g
+        except Exception as e:  # pragma: no cover - capture support is probed, eager is the fallback
+            print(f"[bench] HIP-graph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def timed(fn, k):
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            fn()
+        if world > 1:
+            keep.append(gather_views(plan["color"]))  # the one exchange step: fused all-gather at the end
+        barrier()
+        return time.perf_counter() - t0
+
+    keep = []
+    run = (graph.replay if graph is not None else step)
+    for _ in range(Wm):
+        run()
+    dt = timed(run, K)
+    eager_dt = None
+    if graph is not None:
+        for _ in range(min(Wm, 5)):
+            step()
+        eager_dt = timed(step, K)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    status = be.read_status(plan)
+    assert not status["overflow"], status
+
+    result = {
+        "metric": "rendered views/sec, 300k Gaussians @ 256x256 (fwd raster); bwd ms and HBM GB/s vs roofline alongside",
+        "value": world * K / dt, "unit": "views/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"configs[1]: {n} Gaussians (SH degree 4, 25 coeffs), 1 view {H}x{W}, fwd-only raster, "
+                               "one scene per GPU (seed 2+rank), inputs resident in HBM",
+                   "launch": "hip_graph_replay" if graph is not None else "eager",
+                   "parallelism": f"views sharded 1 scene/GPU x{world}" + (", one fused RCCL all-gather of rendered views at the end" if world > 1 else ""),
+                   "num_pairs_8x8": status["num_pairs"], "max_tile_list": status["max_list"]},
+    }
+    if eager_dt is not None:
+        result["eager_ms_per_step"] = 1e3 * eager_dt / K
+
+    if rank == 0:
+        # ---- per-stage HIP-event timing of the same chain (events on the launch stream), after the timed region
+        reps = max(20, min(K, 100))
+        acc = {}
+        for _ in range(reps):
+            ms = be.run_forward(plan, viewbuf, means, cov6, opac, shs, profile=True)
+            for k_, v_ in ms.items():
+                acc[k_] = acc.get(k_, 0.0) + v_ / reps
+        nv, r16 = reference_rect_stats(plan, cfg)
+        ab = algorithmic_bytes(n, nv, r16, H * W, D_SH)
+        stage_bytes = {"preprocess": ab["preprocess"], "tile_scan": 0, "emit": ab["binning"] // 2, "sort": ab["binning"] // 2,
+                       "blend": ab["blend"]}
+        dom = max(acc, key=acc.get)
+        chain_ms = sum(acc.values())
+        ach = stage_bytes[dom] / (acc[dom] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": {"preprocess": "gsr::k_preprocess", "tile_scan": "gsr::k_tile_scan",
+                                                         "emit": "gsr::k_emit", "sort": "gsr::k_sort_tiles",
+                                                         "blend": "gsr::k_blend_fwd"}[dom],
+                              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": None, "algorithmic_bytes": stage_bytes[dom], "avg_ms": acc[dom]}
+        result["roofline_chain"] = {"bound": "hbm", "achieved": ab["total"] / (dt / K) / 1e9,
+                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab["total"] / (dt / K) / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes": ab["total"], "N": n, "N_v": nv, "R16": r16}
+        result["stage_ms"] = {k_: round(v_, 5) for k_, v_ in acc.items()}
+        result["stage_ms"]["sum_with_event_gaps"] = round(chain_ms, 5)
+
+        # ---- fwd + bwd (configs[2]): dense seeded dL/dcolor
+        gen = torch.Generator().manual_seed(3)
+        g_color = torch.rand((1, 3, H, W), generator=gen).to(dev)
+
+        def fb():
+            be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+            be.run_backward(plan, viewbuf, means, cov6, opac, shs, None, g_color)
+
+        for _ in range(5):
+            fb()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kb = max(10, K // 4)
+        for _ in range(kb):
+            fb()
+        torch.cuda.synchronize()
+        fb_ms = 1e3 * (time.perf_counter() - t0) / kb
+        bacc = {}
+        for _ in range(20):
+            ms = be.run_backward(plan, viewbuf, means, cov6, opac, shs, None, g_color, profile=True)
+            for k_, v_ in ms.items():
+                bacc[k_] = bacc.get(k_, 0.0) + v_ / 20
+        bwd_ms = sum(bacc.values())
+        bb = backward_bytes(n, nv, r16, H * W, D_SH)
+        result["bwd_ms"] = bwd_ms
+        result["fwd_bwd_ms"] = fb_ms
+        result["bwd_stage_ms"] = {k_: round(v_, 5) for k_, v_ in bacc.items()}
+        result["roofline_bwd"] = {"bound": "hbm", "achieved": bb / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": bb / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": bb}
+
+        # ---- CPU baseline (the oracle = "port"; the reference has no CPU splatting path) + parity spot check
+        if world == 1 and not args.no_cpu_baseline:
+            from tests.oracle_backend import OracleBackend
+            from oracle import load_oracle
+
+            cores = max(1, min(os.cpu_count() or 1, load_oracle().gsro_max_threads()))
+            cpu_args = tuple(t.cpu() for t in (means, cov6, opac, shs))
+            ob1 = OracleBackend(threads=1)
+            t0 = time.perf_counter()
+            oc, _, _, _ = ob1.forward(cfg, viewbuf.cpu(), *cpu_args, None)
+            t1 = time.perf_counter() - t0
+            obn = OracleBackend(threads=cores)
+            reps_cpu, tn = 0, 0.0
+            while tn < 8.0 and reps_cpu < 8:
+                t0 = time.perf_counter()
+                obn.forward(cfg, viewbuf.cpu(), *cpu_args, None)
+                tn += time.perf_counter() - t0
+                reps_cpu += 1
+            st_o = ob1.last_stats[0]
+            assert (st_o.n_visible, st_o.r16) == (nv, r16), ((st_o.n_visible, st_o.r16), (nv, r16))
+            result["cpu_baseline"] = {
+                "value": reps_cpu / tn, "unit": "views/s", "cores": cores, "kind": "port",
+                "sample": f"{reps_cpu} forward views of the same 300k/256x256 scene on {cores} threads (oracle C++ fp32, "
+                          f"OpenMP; includes the host-side copy of inputs); 1 thread: {1.0 / t1:.3f} views/s",
+                "one_thread_views_per_s": 1.0 / t1}
+            be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+            torch.cuda.synchronize()
+            hc = plan["color"].cpu().numpy()
+            on = oc.numpy()
+            result["parity"] = {"color_rel_l2_vs_oracle": float(np.linalg.norm(hc - on) / np.linalg.norm(on)),
+                                "max_abs": float(np.abs(hc - on).max())}
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -114,6 +114,27 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
 int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present,
                      void* stream);
 
+/* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
+ * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
+ * Forward stages: 0 preprocess(+tile counts) 1 tile scans 2 emit 3 per-tile sort 4 blend.
+ * Backward stages: 0 blend backward 1 preprocess backward. */
+#define GSR_FWD_STAGES 5
+#define GSR_BWD_STAGES 2
+int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                        const float* opacities, const float* colors, const float* extra, float* out_color,
+                        float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream,
+                        float* stage_ms /* [GSR_FWD_STAGES] host */);
+int gsr_backward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                         const float* opacities, const float* colors, const float* extra, const void* geom,
+                         const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
+                         void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream,
+                         float* stage_ms /* [GSR_BWD_STAGES] host */);
+
+/* Debug aid for tests: byte offsets of the sub-buffers inside `bin` (status, counts, tile_total, ranges, keys,
+ * point_list) and `img` (final_T, n_contrib). */
+int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8);
+
 #ifdef __cplusplus
 }
 #endif

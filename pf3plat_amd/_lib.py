@@ -92,6 +92,11 @@ def load():
     lib.gsr_backward.argtypes = [dp] + [vp] * 19
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.gsr_forward_profile.restype = ctypes.c_int
+    lib.gsr_forward_profile.argtypes = [dp] + [vp] * 13 + [fp]
+    lib.gsr_backward_profile.restype = ctypes.c_int
+    lib.gsr_backward_profile.argtypes = [dp] + [vp] * 19 + [fp]
     if lib.gsr_abi_version() != GSR_ABI_VERSION:
         raise RuntimeError(f"libgsr_hip.so ABI {lib.gsr_abi_version()} != expected {GSR_ABI_VERSION}; rebuild")
     _lib = lib
@@ -100,5 +105,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
-    "gsr_backward", "gsr_mark_visible",
+    "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile",
 )
+FWD_STAGES = ("preprocess", "tile_scan", "emit", "sort", "blend")
+BWD_STAGES = ("blend_bwd", "preprocess_bwd")

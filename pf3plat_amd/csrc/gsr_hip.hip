@@ -26,7 +26,7 @@
 
 #include "../../include/gsr.h"
 
-namespace {
+namespace gsr {
 
 constexpr int kNRep = 64;         // replicated tile counters (= one wavefront scans a tile's replicas)
 constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
@@ -58,9 +58,9 @@ struct Layout {
   size_t o_finalT, o_ncontrib;                                   // in img
 };
 
-inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-Layout make_layout(const GsrDims& d) {
+static Layout make_layout(const GsrDims& d) {
   Layout L;
   const Grid g = make_grid(d.width, d.height);
   const size_t V = d.num_views, N = d.num_gaussians, VT = V * (size_t)g.T;
@@ -893,7 +893,7 @@ __global__ __launch_bounds__(256) void k_mark_visible(const Params p, uint8_t* p
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-bool dims_ok(const GsrDims* d) {
+static bool dims_ok(const GsrDims* d) {
   if (!d || d->abi_version != GSR_ABI_VERSION) return false;
   if (d->num_views < 0 || d->num_sets < 0 || d->views_per_set < 0 || d->num_gaussians < 0) return false;
   if ((int64_t)d->num_sets * d->views_per_set != d->num_views) return false;
@@ -905,7 +905,7 @@ bool dims_ok(const GsrDims* d) {
   return true;
 }
 
-Params base_params(const GsrDims* d, const GsrView* views, const float* means, const float* cov6, const float* opac,
+static Params base_params(const GsrDims* d, const GsrView* views, const float* means, const float* cov6, const float* opac,
                    const float* colors, const float* extra, void* geom, void* bin, void* img) {
   Params p{};
   p.d = *d;
@@ -931,7 +931,11 @@ Params base_params(const GsrDims* d, const GsrView* views, const float* means, c
     if ((expr) != hipSuccess) return GSR_ERR_LAUNCH; \
   } while (0)
 
-}  // namespace
+}  // namespace gsr
+
+using namespace gsr;
+
+static hipEvent_t* g_bwd_events = nullptr;
 
 extern "C" {
 
@@ -960,11 +964,11 @@ int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8) {
   return GSR_OK;
 }
 
-int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
-                const float* opacities, const float* colors, const float* extra, float* out_color,
-                float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream_) {
+static int forward_impl(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                        const float* opacities, const float* colors, const float* extra, float* out_color,
+                        float* out_extra, int32_t* radii, void* geom, void* bin, void* img, hipStream_t st,
+                        hipEvent_t* ev) {
   if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
-  hipStream_t st = static_cast<hipStream_t>(stream_);
   const GsrDims& d = *dims;
   const size_t V = d.num_views, N = d.num_gaussians, HW = (size_t)d.height * d.width;
   if (V == 0) return GSR_OK;
@@ -982,17 +986,57 @@ int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, c
   }
   if (!means || !cov6 || !opacities || !colors || !radii || !geom) return GSR_ERR_INVALID_ARGUMENT;
   const size_t VT = V * (size_t)p.g.T;
+  int e = 0;
+#define GSR_MARK() do { if (ev) GSR_CHECK(hipEventRecord(ev[e++], st)); } while (0)
+  GSR_MARK();
   GSR_CHECK(hipMemsetAsync(p.counts, 0, VT * kNRep * sizeof(uint32_t), st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
   hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + 63) / 64), (unsigned)V), dim3(64), shmem, st, p);
+  GSR_MARK();
   hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT * 64 + 255) / 256)), dim3(256), 0, st, p);
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
+  GSR_MARK();
   hipLaunchKernelGGL(k_emit, dim3((unsigned)((N + 255) / 256), (unsigned)V), dim3(256), 0, st, p);
+  GSR_MARK();
   hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(64), 0, st, p);
+  GSR_MARK();
   hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  GSR_MARK();
+#undef GSR_MARK
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
+}
+
+int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                const float* opacities, const float* colors, const float* extra, float* out_color,
+                float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream_) {
+  return forward_impl(dims, views, means, cov6, opacities, colors, extra, out_color, out_extra, radii, geom, bin, img,
+                      static_cast<hipStream_t>(stream_), nullptr);
+}
+
+// Measurement aid (bench.py): the same launch chain with a HIP event recorded on `stream` between its stages;
+// synchronises the stream and returns the GSR_FWD_STAGES stage durations in milliseconds
+// (preprocess+count, tile scan, emit, sort, blend).  Never used on the product path.
+int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                        const float* opacities, const float* colors, const float* extra, float* out_color,
+                        float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream_,
+                        float* stage_ms) {
+  if (!stage_ms) return GSR_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  hipEvent_t ev[GSR_FWD_STAGES + 1];
+  for (int i = 0; i <= GSR_FWD_STAGES; ++i) GSR_CHECK(hipEventCreate(&ev[i]));
+  int rc = forward_impl(dims, views, means, cov6, opacities, colors, extra, out_color, out_extra, radii, geom, bin, img,
+                        st, ev);
+  if (rc == GSR_OK && dims->num_views > 0 && dims->num_gaussians > 0) {
+    if (hipStreamSynchronize(st) != hipSuccess) rc = GSR_ERR_LAUNCH;
+    for (int i = 0; i < GSR_FWD_STAGES && rc == GSR_OK; ++i)
+      if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = GSR_ERR_LAUNCH;
+  } else {
+    for (int i = 0; i < GSR_FWD_STAGES; ++i) stage_ms[i] = 0.f;
+  }
+  for (int i = 0; i <= GSR_FWD_STAGES; ++i) (void)hipEventDestroy(ev[i]);
+  return rc;
 }
 
 int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
@@ -1014,13 +1058,43 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   p.scratch = static_cast<float*>(scratch);
   p.dL_dmeans = dL_dmeans; p.dL_dcov6 = dL_dcov6; p.dL_dopac = dL_dopacities; p.dL_dcolors = dL_dcolors;
   p.dL_dextra = d.has_extra ? dL_dextra : nullptr; p.dL_dmeans2D = dL_dmeans2D;
+  hipEvent_t* ev = g_bwd_events;
+  int e = 0;
+  if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipMemsetAsync(scratch, 0, V * N * GSR_SCREEN_GRAD_FLOATS * sizeof(float), st));
   hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)2 * 64 * ldstride * sizeof(float) : 0;
   hipLaunchKernelGGL(k_preprocess_bwd, dim3((unsigned)((N + 63) / 64), (unsigned)d.num_sets), dim3(64), shmem, st, p);
+  if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
+}
+
+// Measurement aid (bench.py): gsr_backward with events between its two stages (blend backward, preprocess backward);
+// synchronises the stream.  Not thread-safe (uses a process-wide event slot); never used on the product path.
+int gsr_backward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                         const float* opacities, const float* colors, const float* extra, const void* geom,
+                         const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
+                         void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_, float* stage_ms) {
+  if (!stage_ms) return GSR_ERR_INVALID_ARGUMENT;
+  hipStream_t st = static_cast<hipStream_t>(stream_);
+  hipEvent_t ev[GSR_BWD_STAGES + 1];
+  for (int i = 0; i <= GSR_BWD_STAGES; ++i) GSR_CHECK(hipEventCreate(&ev[i]));
+  g_bwd_events = ev;
+  int rc = gsr_backward(dims, views, means, cov6, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img,
+                        scratch, dL_dmeans, dL_dcov6, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_);
+  g_bwd_events = nullptr;
+  for (int i = 0; i < GSR_BWD_STAGES; ++i) stage_ms[i] = 0.f;
+  if (rc == GSR_OK && dims->num_views > 0 && dims->num_gaussians > 0) {
+    if (hipStreamSynchronize(st) != hipSuccess) rc = GSR_ERR_LAUNCH;
+    for (int i = 0; i < GSR_BWD_STAGES && rc == GSR_OK; ++i)
+      if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = GSR_ERR_LAUNCH;
+  }
+  for (int i = 0; i <= GSR_BWD_STAGES; ++i) (void)hipEventDestroy(ev[i]);
+  return rc;
 }
 
 int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present, void* stream_) {

@@ -130,39 +130,97 @@ class HipBackend:
             return int(hint * 1.25) + 4096
         return cfg.num_views * max(8 * cfg.num_gaussians, 1 << 18)
 
+    # ---- plans: outputs + workspaces allocated once, launch chains enqueued many times (bench / HIP-graph capture)
+    def make_plan(self, cfg: RasterConfig, device, capacity: int, backward: bool = False, colors_shape=None) -> dict:
+        v, h, w, n, s = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians, cfg.num_sets
+        f32, u8 = torch.float32, torch.uint8
+        dims = self._dims(cfg, capacity)
+        gb, bb, ib = self.workspace_sizes(dims)
+        plan = dict(
+            cfg=cfg, dims=dims, device=device,
+            color=torch.empty((v, 3, h, w), dtype=f32, device=device),
+            extra_img=torch.empty((v, h, w), dtype=f32, device=device) if cfg.has_extra else None,
+            radii=torch.empty((v, n), dtype=torch.int32, device=device),
+            geom=torch.empty(gb, dtype=u8, device=device), bin=torch.empty(bb, dtype=u8, device=device),
+            img=torch.empty(ib, dtype=u8, device=device),
+        )
+        if backward:
+            if colors_shape is None:
+                colors_shape = (s, n, cfg.sh_coeffs, 3) if cfg.sh_coeffs > 0 else (s, n, 3)
+            plan.update(
+                scratch=torch.empty(max(1, v * n * _lib.SCREEN_GRAD_FLOATS), dtype=f32, device=device),
+                d_means=torch.empty((s, n, 3), dtype=f32, device=device),
+                d_cov6=torch.empty((s, n, 6), dtype=f32, device=device),
+                d_opac=torch.empty((s, n), dtype=f32, device=device),
+                d_colors=torch.empty(colors_shape, dtype=f32, device=device),
+                d_extra=torch.empty((v, n), dtype=f32, device=device) if cfg.has_extra else None,
+                d_means2d=torch.empty((v, n, 3), dtype=f32, device=device),
+            )
+        return plan
+
+    def run_forward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra=None, profile: bool = False):
+        """Enqueue one forward launch chain on the current stream.  profile=True returns per-stage ms (synchronises)."""
+        stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
+        args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
+                _ptr(plan["color"]), _ptr(plan["extra_img"]), _ptr(plan["radii"]), _ptr(plan["geom"]), _ptr(plan["bin"]),
+                _ptr(plan["img"]), stream)
+        if profile:
+            ms = (ctypes.c_float * len(_lib.FWD_STAGES))()
+            rc = self.lib.gsr_forward_profile(*args, ms)
+        else:
+            ms = None
+            rc = self.lib.gsr_forward(*args)
+        if rc != 0:
+            raise RuntimeError(f"gsr_forward failed with code {rc}")
+        return None if ms is None else dict(zip(_lib.FWD_STAGES, [float(x) for x in ms]))
+
+    def run_backward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img=None,
+                     want_means2d: bool = True, profile: bool = False):
+        cfg = plan["cfg"]
+        stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
+        args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
+                _ptr(plan["geom"]), _ptr(plan["bin"]), _ptr(plan["img"]), _ptr(g_color),
+                _ptr(g_extra_img if cfg.has_extra else None), _ptr(plan["scratch"]), _ptr(plan["d_means"]),
+                _ptr(plan["d_cov6"]), _ptr(plan["d_opac"]), _ptr(plan["d_colors"]), _ptr(plan["d_extra"]),
+                _ptr(plan["d_means2d"] if want_means2d else None), stream)
+        if profile:
+            ms = (ctypes.c_float * len(_lib.BWD_STAGES))()
+            rc = self.lib.gsr_backward_profile(*args, ms)
+        else:
+            ms = None
+            rc = self.lib.gsr_backward(*args)
+        if rc != 0:
+            raise RuntimeError(f"gsr_backward failed with code {rc}")
+        return None if ms is None else dict(zip(_lib.BWD_STAGES, [float(x) for x in ms]))
+
+    @staticmethod
+    def read_status(plan: dict) -> dict:
+        """Blocking read of the status block of the plan's last forward."""
+        st = plan["bin"][:16].cpu()
+        return {"num_pairs": int(st[:8].view(torch.int64).item()), "overflow": int(st[8:12].view(torch.int32).item()),
+                "max_list": int(st[12:16].view(torch.int32).item())}
+
+    # ---- autograd-facing calls: fresh outputs/workspaces per call, kept alive for backward
     def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None):
         self._check_device(viewbuf, means, cov6, opac, colors, extra)
         dev = viewbuf.device
         v, h, w, n = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians
         cap = self._default_capacity(cfg) if capacity is None else int(capacity)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        color = torch.empty((v, 3, h, w), dtype=torch.float32, device=dev)
-        extra_img = torch.empty((v, h, w), dtype=torch.float32, device=dev) if cfg.has_extra else None
-        radii = torch.empty((v, n), dtype=torch.int32, device=dev)
         for attempt in range(3):
-            dims = self._dims(cfg, cap)
-            gb, bb, ib = self.workspace_sizes(dims)
-            geom = torch.empty(gb, dtype=torch.uint8, device=dev)
-            binb = torch.empty(bb, dtype=torch.uint8, device=dev)
-            img = torch.empty(ib, dtype=torch.uint8, device=dev)
-            rc = self.lib.gsr_forward(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac),
-                                      _ptr(colors), _ptr(extra), _ptr(color), _ptr(extra_img), _ptr(radii),
-                                      _ptr(geom), _ptr(binb), _ptr(img), stream)
-            if rc != 0:
-                raise RuntimeError(f"gsr_forward failed with code {rc}")
-            saved = (dims, geom, binb, img)
-            if self.defer_status or n == 0:
-                if n > 0:
-                    self.pending.append(binb[:16])
-                return color, extra_img, radii, saved
-            st = binb[:16].cpu()  # one small D2H read (the reference extension also reads its pair count back)
-            num_pairs = int(st[:8].view(torch.int64).item())
-            overflow = int(st[8:12].view(torch.int32).item())
-            self.last_status = {"num_pairs": num_pairs, "overflow": overflow, "max_list": int(st[12:16].view(torch.int32).item())}
-            self.capacity_hint[(v, n, h, w)] = num_pairs
-            if not overflow:
-                return color, extra_img, radii, saved
-            cap = int(num_pairs * 1.05) + 4096
+            plan = self.make_plan(cfg, dev, cap)
+            self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra)
+            saved = (plan["dims"], plan["geom"], plan["bin"], plan["img"])
+            out = (plan["color"], plan["extra_img"], plan["radii"], saved)
+            if self.defer_status or n == 0 or v == 0:
+                if n > 0 and v > 0:
+                    self.pending.append(plan["bin"][:16])
+                return out
+            # one small D2H read (the reference extension also reads its pair count back to the host)
+            self.last_status = st = self.read_status(plan)
+            self.capacity_hint[(v, n, h, w)] = st["num_pairs"]
+            if not st["overflow"]:
+                return out
+            cap = int(st["num_pairs"] * 1.05) + 4096
         raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
 
     def check_pending(self):
@@ -179,30 +237,21 @@ class HipBackend:
                  want_means2d: bool):
         dims, geom, binb, img = saved
         dev = viewbuf.device
-        v, n = cfg.num_views, cfg.num_gaussians
-        s = cfg.num_sets
+        v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         f32 = torch.float32
-        d_means = torch.empty((s, n, 3), dtype=f32, device=dev)
-        d_cov6 = torch.empty((s, n, 6), dtype=f32, device=dev)
-        d_opac = torch.empty((s, n), dtype=f32, device=dev)
-        d_colors = torch.empty_like(colors)
-        d_extra = torch.empty((v, n), dtype=f32, device=dev) if cfg.has_extra else None
-        d_means2d = torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None
-        if n == 0 or v == 0:
-            return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d
-        scratch = torch.empty(v * n * _lib.SCREEN_GRAD_FLOATS, dtype=f32, device=dev)
-        g_color = g_color.contiguous().to(f32)
-        if cfg.has_extra:
-            g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
-                           else g_extra_img.contiguous().to(f32))
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        rc = self.lib.gsr_backward(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors),
-                                   _ptr(extra), _ptr(geom), _ptr(binb), _ptr(img), _ptr(g_color),
-                                   _ptr(g_extra_img if cfg.has_extra else None), _ptr(scratch), _ptr(d_means),
-                                   _ptr(d_cov6), _ptr(d_opac), _ptr(d_colors), _ptr(d_extra), _ptr(d_means2d), stream)
-        if rc != 0:
-            raise RuntimeError(f"gsr_backward failed with code {rc}")
-        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d
+        plan = dict(cfg=cfg, dims=dims, device=dev, geom=geom, bin=binb, img=img,
+                    scratch=torch.empty(max(1, v * n * _lib.SCREEN_GRAD_FLOATS), dtype=f32, device=dev),
+                    d_means=torch.empty((s, n, 3), dtype=f32, device=dev), d_cov6=torch.empty((s, n, 6), dtype=f32, device=dev),
+                    d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
+                    d_extra=torch.empty((v, n), dtype=f32, device=dev) if cfg.has_extra else None,
+                    d_means2d=torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None)
+        if n > 0 and v > 0:
+            g_color = g_color.contiguous().to(f32)
+            if cfg.has_extra:
+                g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
+                               else g_extra_img.contiguous().to(f32))
+            self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d)
+        return plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
 
     def mark_visible(self, cfg: RasterConfig, viewbuf, means):
         self._check_device(viewbuf, means)

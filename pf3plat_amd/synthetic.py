@@ -103,3 +103,26 @@ def make_scene(seed: int, num_gaussians: int, image_shape=(256, 256), d_sh: int 
         (h, w), torch.zeros(3),
     )
     return scene.to(device)
+
+
+def scene_operator_inputs(scene: Scene, use_sh: bool = True):
+    """Scene (batch 1) -> the raw operator tensors of `rasterize_views`:
+    means (1,N,3), cov6 (1,N,6), opacities (1,N), colors (1,N,M,3) [or (1,N,3) DC-only when use_sh is False]."""
+    g = scene.gaussians
+    cov = g.covariances
+    cov6 = torch.stack((cov[..., 0, 0], cov[..., 0, 1], cov[..., 0, 2], cov[..., 1, 1], cov[..., 1, 2], cov[..., 2, 2]), -1)
+    colors = g.harmonics.permute(0, 1, 3, 2).contiguous()
+    if not use_sh:
+        colors = colors[:, :, 0, :].contiguous()
+    return g.means.contiguous(), cov6.contiguous(), g.opacities.contiguous(), colors
+
+
+def scene_viewbuf(scene: Scene, scale_invariant: bool = True) -> Tensor:
+    """Camera records (V, 48) of a Scene, built by the same camera set-up `render_cuda` uses."""
+    from .rasterizer import pack_views
+    from .splatting import _cameras
+
+    s, v = scene.extrinsics.shape[:2]
+    vm, fp, cp, tx, ty, sc = _cameras(scene.extrinsics.reshape(s * v, 4, 4), scene.intrinsics.reshape(s * v, 3, 3),
+                                      scene.near.reshape(s * v), scene.far.reshape(s * v), scale_invariant)
+    return pack_views(vm, fp, cp, tx, ty, scene.background.reshape(1, 3).expand(s * v, 3), sc)

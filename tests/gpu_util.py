@@ -75,21 +75,12 @@ def run_both(cfg: RasterConfig, viewbuf_cpu, means, cov6, opac, colors, extra=No
 
 
 def scene_tensors(scene, use_sh=True):
-    """pf3plat_amd.synthetic.Scene (batch 1) -> (means (1,N,3), cov6 (1,N,6), opac (1,N), colors (1,N,M,3))."""
-    g = scene.gaussians
-    cov = g.covariances
-    cov6 = torch.stack((cov[..., 0, 0], cov[..., 0, 1], cov[..., 0, 2], cov[..., 1, 1], cov[..., 1, 2], cov[..., 2, 2]), -1)
-    colors = g.harmonics.permute(0, 1, 3, 2).contiguous()
-    if not use_sh:
-        colors = colors[:, :, 0, :].contiguous()
-    return g.means.contiguous(), cov6.contiguous(), g.opacities.contiguous(), colors
+    from pf3plat_amd.synthetic import scene_operator_inputs
+
+    return scene_operator_inputs(scene, use_sh)
 
 
 def scene_viewbuf(scene, scale_invariant=True):
-    """Camera records of a synthetic Scene, built by the product's own camera set-up."""
-    from pf3plat_amd.splatting import _cameras
+    from pf3plat_amd.synthetic import scene_viewbuf as _svb
 
-    s, v = scene.extrinsics.shape[:2]
-    vm, fp, cp, tx, ty, sc = _cameras(scene.extrinsics.reshape(s * v, 4, 4), scene.intrinsics.reshape(s * v, 3, 3),
-                                      scene.near.reshape(s * v), scene.far.reshape(s * v), scale_invariant)
-    return pack_views(vm, fp, cp, tx, ty, scene.background.reshape(1, 3).expand(s * v, 3), sc)
+    return _svb(scene, scale_invariant)

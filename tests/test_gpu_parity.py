@@ -1,0 +1,221 @@
+"""`-m gpu` parity tests proper: the HIP path, called through the C ABI (ctypes, raw device pointers), against the CPU
+oracle on the same seeded inputs.  Tolerance: north_star's 1e-4 relative fp32 (rel-L2 per tensor), written in
+tests/parity_checks.py; projection/EWA/SH records are additionally expected to be (nearly) bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from pf3plat_amd import synthetic
+from pf3plat_amd.rasterizer import RasterConfig
+from tests import gpu_util, parity_checks
+from tests.util import look_at_c2w, make_camera, random_small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene_case(seed, n, hw, views=1, use_sh=True, with_extra=True, grads=True, d_sh=25, scale_invariant=True, near=1.0):
+    sc = synthetic.make_scene(seed, n, hw, num_views=views, d_sh=d_sh, near=near)
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc, use_sh)
+    vb = gpu_util.scene_viewbuf(sc, scale_invariant)
+    h, w = hw
+    rng = np.random.default_rng(seed)
+    extra = torch.tensor(rng.uniform(0.5, 2.0, (views, n)).astype(np.float32)) if with_extra else None
+    deg = int(round(d_sh ** 0.5)) - 1
+    cfg = RasterConfig(views, 1, views, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra)
+    gc = torch.tensor(rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32)) if grads else None
+    ge = torch.tensor(rng.uniform(0, 1, (views, h, w)).astype(np.float32)) if (grads and with_extra) else None
+    return cfg, gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge)
+
+
+def _all_checks(cfg, res, lists=True, max_tiles=256):
+    for v in range(cfg.num_views):
+        parity_checks.check_preprocess(res, cfg, v)
+        if lists:
+            parity_checks.check_tile_lists(res, cfg, v, max_tiles=max_tiles)
+        parity_checks.check_image_state(res, cfg, v)
+    parity_checks.check_image(res, cfg)
+    if "grads" in res["hip"]:
+        parity_checks.check_grads(res, cfg)
+
+
+def test_config1_1k_gaussians_64x64():
+    cfg, res = _scene_case(1, 1000, (64, 64))
+    _all_checks(cfg, res)
+    assert res["oracle"]["stats"][0].n_visible > 900
+
+
+def test_precomputed_colours_no_extra():
+    cfg, res = _scene_case(11, 2000, (64, 64), use_sh=False, with_extra=False, d_sh=1)
+    _all_checks(cfg, res)
+
+
+@pytest.mark.parametrize("d_sh", [1, 4, 9, 16])
+def test_lower_sh_degrees(d_sh):
+    cfg, res = _scene_case(12 + d_sh, 1500, (48, 48), d_sh=d_sh)
+    _all_checks(cfg, res, lists=False)
+
+
+@pytest.mark.parametrize("hw", [(45, 70), (17, 33), (8, 8), (100, 24)])
+def test_ragged_image_sizes(hw):
+    cfg, res = _scene_case(4, 3000, hw)
+    _all_checks(cfg, res)
+
+
+def test_three_views_share_one_gaussian_set_with_per_view_scale():
+    """Fused multi-view path: Gaussians read once, gradients of the three views summed in-kernel, and the
+    scale-invariant factor (near = 2.5 => scale 0.4) applied on load with its chain rule in backward."""
+    cfg, res = _scene_case(5, 5000, (64, 64), views=3, near=2.5)
+    _all_checks(cfg, res)
+
+
+def test_two_sets_of_two_views():
+    sc_a, sc_b = synthetic.make_scene(21, 2000, (48, 48), num_views=2), synthetic.make_scene(22, 2000, (48, 48), num_views=2)
+    ta, tb = gpu_util.scene_tensors(sc_a), gpu_util.scene_tensors(sc_b)
+    means, cov6, opac, colors = (torch.cat([a, b]) for a, b in zip(ta, tb))
+    vb = torch.cat([gpu_util.scene_viewbuf(sc_a), gpu_util.scene_viewbuf(sc_b)])
+    cfg = RasterConfig(4, 2, 2, 2000, 48, 48, 4, 25, 4, False)
+    rng = np.random.default_rng(0)
+    gc = torch.tensor(rng.uniform(0, 1, (4, 3, 48, 48)).astype(np.float32))
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, None)
+    _all_checks(cfg, res, lists=False)
+
+
+def test_20k_gaussians_128x128():
+    cfg, res = _scene_case(6, 20000, (128, 128))
+    _all_checks(cfg, res)
+
+
+def test_config2_config3_full_size_300k_256x256():
+    """BASELINE configs[1]/[2] at full size: forward image, saved state, and all gradients vs the oracle
+    (the oracle finishes this in a few seconds on the host cores)."""
+    cfg, res = _scene_case(2, 300000, (256, 256))
+    _all_checks(cfg, res, max_tiles=128)
+    st = res["oracle"]["stats"][0]
+    assert st.n_visible > 250000 and st.r16 > 800000
+    assert res["hip"]["status"]["num_pairs"] < 2 * st.r16  # tight 8x8 culling keeps the pair count near R16
+
+
+def test_against_fp64_oracle_gradients():
+    cfg, _ = _scene_case(7, 10, (8, 8), grads=False)  # warm-up / plumbing
+    sc = synthetic.make_scene(8, 4000, (64, 64))
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    cfg = RasterConfig(1, 1, 1, 4000, 64, 64, 4, 25, 4, False)
+    rng = np.random.default_rng(1)
+    gc = torch.tensor(rng.uniform(0, 1, (1, 3, 64, 64)).astype(np.float32))
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, None, oracle_dtype=np.float64)
+    parity_checks.check_image(res, cfg)
+    parity_checks.check_grads(res, cfg)
+
+
+# ------------------------------------------------------------------ edge cases the domain has
+def _custom(n_fn, hw=(32, 32), sh_coeffs=0, bg=(0.2, 0.4, 0.6), cam=None, grads=True, capacity=None):
+    p = n_fn()
+    n = p["means"].shape[0]
+    cam = cam or make_camera()
+    vb = gpu_util.viewbuf_from_cams([cam], [bg])
+    cfg = RasterConfig(1, 1, 1, n, hw[0], hw[1], {0: 0, 1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[sh_coeffs], sh_coeffs, 4, False)
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))[None]
+    rng = np.random.default_rng(0)
+    gc = torch.tensor(rng.uniform(0, 1, (1, 3, *hw)).astype(np.float32)) if grads else None
+    return cfg, gpu_util.run_both(cfg, vb, t(p["means"]), t(p["cov6"]), t(p["opac"]), t(p["colors"]), None, gc, None,
+                                  capacity=capacity)
+
+
+def test_empty_input_renders_zeros():
+    cfg, res = _custom(lambda: dict(means=np.zeros((0, 3)), cov6=np.zeros((0, 6)), opac=np.zeros((0,)), colors=np.zeros((0, 3))),
+                       grads=False)
+    assert np.all(res["hip"]["color"] == 0) and np.all(res["oracle"]["color"] == 0)
+
+
+def test_single_gaussian_and_all_culled():
+    one = lambda: dict(means=np.array([[0.1, -0.1, 4.0]]), cov6=np.array([[0.05, 0, 0, 0.05, 0, 0.05]]), opac=np.array([0.7]),
+                       colors=np.array([[0.9, 0.5, 0.1]]))
+    cfg, res = _custom(one)
+    _all_checks(cfg, res)
+    behind = lambda: dict(means=np.array([[0, 0, -3.0], [0, 0, 0.19], [500.0, 0, 4.0]]), cov6=np.tile([[0.05, 0, 0, 0.05, 0, 0.05]], (3, 1)),
+                          opac=np.full(3, 0.7), colors=np.ones((3, 3)))
+    cfg, res = _custom(behind)
+    assert np.all(res["hip"]["radii"] == 0)
+    np.testing.assert_allclose(res["hip"]["color"], res["oracle"]["color"])
+    for k, g in res["hip"]["grads"].items():
+        if g is not None:
+            assert np.all(g == 0), k
+
+
+def test_depth_ties_break_by_index_and_duplicates():
+    def dup():
+        sc = random_small_scene(3, 30, sh_coeffs=0, dtype=np.float32)
+        for k in ("means", "cov6", "opac"):
+            sc[k] = np.concatenate([sc[k], sc[k]])  # exact duplicates => exact depth ties
+        sc["colors"] = np.concatenate([sc["colors"], 1 - sc["colors"]])
+        return sc
+    cfg, res = _custom(dup)
+    _all_checks(cfg, res)
+
+
+def test_opacity_below_threshold_and_alpha_cap():
+    def f():
+        sc = random_small_scene(4, 60, sh_coeffs=0, dtype=np.float32)
+        sc["opac"][:20] = 1.0 / 255.0 - 1e-5  # can never reach alpha >= 1/255
+        sc["opac"][20:40] = 1.0  # alpha capped at 0.99
+        return sc
+    cfg, res = _custom(f)
+    _all_checks(cfg, res)
+    assert np.all(res["hip"]["grads"]["opac"][0, :20] == 0)
+
+
+def test_huge_gaussians_long_tile_lists_use_global_sort_path():
+    """Every Gaussian covers the whole image => per-tile lists of 6000 > the 4096-entry LDS sort => global-memory sort path."""
+    def f():
+        rng = np.random.default_rng(5)
+        n = 6000
+        means = np.stack([rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n), rng.uniform(2, 6, n)], -1)
+        cov6 = np.tile([[9.0, 0, 0, 9.0, 0, 9.0]], (n, 1))
+        return dict(means=means, cov6=cov6, opac=rng.uniform(0.01, 0.05, n), colors=rng.uniform(0, 1, (n, 3)))
+    cfg, res = _custom(f, hw=(16, 16))
+    assert res["hip"]["status"]["max_list"] > 4096
+    _all_checks(cfg, res)
+
+
+def test_pair_workspace_overflow_is_detected_and_retried():
+    sc = synthetic.make_scene(9, 5000, (64, 64))
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    cfg = RasterConfig(1, 1, 1, 5000, 64, 64, 4, 25, 4, False)
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, capacity=100)  # far too small: first attempt overflows
+    assert res["hip"]["status"]["overflow"] == 0 and res["hip"]["status"]["num_pairs"] > 100
+    parity_checks.check_image(res, cfg)
+
+
+def test_rotated_camera_nonzero_background_sh():
+    def f():
+        return random_small_scene(6, 500, sh_coeffs=25, dtype=np.float32, spread=2.0)
+    cam = make_camera(look_at_c2w((0.8, -0.5, -1.0)), fx=0.7, fy=0.9, near=0.5, dtype=np.float32)
+    cfg, res = _custom(f, hw=(40, 56), sh_coeffs=25, cam=cam, bg=(0.9, 0.1, 0.5))
+    _all_checks(cfg, res)
+
+
+def test_max_sh_eval_3_ignores_band_4():
+    sc = synthetic.make_scene(10, 1500, (48, 48))
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    cfg = RasterConfig(1, 1, 1, 1500, 48, 48, 4, 25, 3, False)
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors)
+    parity_checks.check_preprocess(res, cfg)
+    parity_checks.check_image(res, cfg)
+
+
+def test_forward_is_deterministic_and_backward_nearly():
+    sc = synthetic.make_scene(13, 8000, (64, 64))
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    cfg = RasterConfig(1, 1, 1, 8000, 64, 64, 4, 25, 4, False)
+    gc = torch.rand((1, 3, 64, 64), generator=torch.Generator().manual_seed(0))
+    a = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, None)
+    b = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, None)
+    np.testing.assert_array_equal(a["hip"]["color"], b["hip"]["color"])
+    np.testing.assert_array_equal(a["hip"]["ws"]["point_list"], b["hip"]["ws"]["point_list"])
+    for k in ("means", "cov6", "opac", "colors"):
+        d = np.abs(a["hip"]["grads"][k] - b["hip"]["grads"][k]).max()
+        assert d <= 1e-5 * np.abs(a["hip"]["grads"][k]).max(), k  # fp32 atomics: order-dependent rounding only
