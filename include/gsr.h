@@ -41,6 +41,13 @@ extern "C" {
 #define GSR_ERR_LAUNCH (-2)
 #define GSR_ERR_UNSUPPORTED (-3)
 #define GSR_ABI_VERSION 1
+/* GsrDims.flags bits >= 8 are measurement-only ablation switches (tools/ablate.py): they make results WRONG on purpose
+ * to time a kernel without one of its parts.  Never set on the product path. */
+#define GSR_FLAG_ABLATE_NO_COUNT 0x100       /* preprocess: skip the per-tile pair counting atomics */
+#define GSR_FLAG_ABLATE_NO_SH 0x200          /* preprocess: skip SH staging + evaluation */
+#define GSR_FLAG_ABLATE_EMIT_NO_STORE 0x400  /* emit: skip the key stores */
+#define GSR_FLAG_ABLATE_EMIT_NO_ATOMIC 0x800 /* emit: skip the slot atomics */
+#define GSR_FLAG_ABLATE_NO_GEOM_STORE 0x1000 /* preprocess: skip the projected-record store */
 
 /* One camera = the non-tensor fields of upstream's GaussianRasterizationSettings
  * (constructed at cuda_splatting.py:99-112), 48 floats = 192 bytes. */

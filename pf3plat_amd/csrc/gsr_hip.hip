@@ -28,15 +28,22 @@
 
 namespace gsr {
 
-constexpr int kNRep = 64;         // replicated tile counters (= one wavefront scans a tile's replicas)
+constexpr int kChunk = 2048;      // Gaussians per binning workgroup = one row of the per-view count matrix
+constexpr int kBinThreads = 1024; // threads of a binning workgroup (count / emit)
+constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup (32 KiB)
 constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
+constexpr int kSortThreads = 256; // threads cooperating on one tile's sort
 constexpr float kNear = 0.2f;     // [EXT] auxiliary.h in_frustum: p_view.z <= 0.2f culls
 
-struct __attribute__((aligned(16))) GeomRec {  // 48 B per (view, Gaussian)
+struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one record = half a cache line
   float4 q0;  // x, y, conic a, conic b
   float4 q1;  // conic c, opacity, r, g
   float4 q2;  // b, extra, depth, bits(radius | clamped << 28)
+  float4 q3;  // bits: hit mask lo, hit mask hi, window origin (sx0 | sy0 << 12 | big << 31), depth
 };
+// q3: the 8x8 tiles this splat must be listed in, as a 64-bit mask over the 8x8-tile window whose top-left tile is
+// (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); computed once in preprocess, consumed by count and emit.
+// Footprints wider than 8 tiles set `big` and are re-derived from q0/q1 by the binning kernels.
 
 struct Grid {
   int W, H, gx16, gy16, sgx, sgy, sw, sh, T;  // sw/sh: 8x8 tiles that contain at least one pixel
@@ -68,7 +75,8 @@ static Layout make_layout(const GsrDims& d) {
   L.geom_bytes = align_up(V * N * sizeof(GeomRec), 256);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
-  L.o_counts = o; o = align_up(o + VT * kNRep * 4, 256);
+  const size_t rows = (N + kChunk - 1) / kChunk;
+  L.o_counts = o; o = align_up(o + VT * (rows > 0 ? rows : 1) * 4, 256);
   L.o_total = o; o = align_up(o + VT * 4, 256);
   L.o_ranges = o; o = align_up(o + VT * 8, 256);
   L.o_keys = o; o = align_up(o + cap * 8, 256);
@@ -84,6 +92,7 @@ static Layout make_layout(const GsrDims& d) {
 struct Params {
   GsrDims d;
   Grid g;
+  int rows;  // binning chunks per view = ceil(N / kChunk)
   const GsrView* views;
   const float *means, *cov6, *opac, *colors, *extra;
   float* out_color;
@@ -232,7 +241,7 @@ __device__ __forceinline__ void cov2d_parts(const float mx, const float my, cons
 // axis-aligned bounds of the ellipse {q <= tau}, q = a dx^2 + 2 b dx dy + c dy^2, tau = 2 ln(255 o):
 // outside it alpha = o exp(-q/2) < 1/255 and the blend would skip the pixel anyway.
 struct Foot {
-  float cx, cy, A, B, C, tau;
+  float cx, cy, A, B, C, tau, nBiC, nBiA;  // nBiC = -B/C, nBiA = -B/A
   bool convex;
   int sx0, sx1, sy0, sy1;
 };
@@ -249,6 +258,7 @@ __device__ __forceinline__ void ref_rect16(float x, float y, float r, const Grid
 __device__ __forceinline__ Foot make_foot(float x, float y, float A, float B, float C, float o, float r, const Grid& g) {
   Foot f;
   f.cx = x; f.cy = y; f.A = A; f.B = B; f.C = C;
+  f.nBiC = -B / C; f.nBiA = -B / A;
   int rx0, ry0, rx1, ry1;
   ref_rect16(x, y, r, g, rx0, ry0, rx1, ry1);
   f.sx0 = 2 * rx0; f.sy0 = 2 * ry0;
@@ -277,11 +287,11 @@ __device__ __forceinline__ bool subtile_hit(const Foot& f, int sx, int sy, const
   const bool inx = (dx0 <= 0.f) && (dx1 >= 0.f), iny = (dy0 <= 0.f) && (dy1 >= 0.f);
   if (inx && iny) return true;
   auto qx = [&](float dxe) {
-    const float ys = fminf(fmaxf(-f.B * dxe / f.C, dy0), dy1);
+    const float ys = fminf(fmaxf(f.nBiC * dxe, dy0), dy1);
     return f.A * dxe * dxe + 2.f * f.B * dxe * ys + f.C * ys * ys;
   };
   auto qy = [&](float dye) {
-    const float xs = fminf(fmaxf(-f.B * dye / f.A, dx0), dx1);
+    const float xs = fminf(fmaxf(f.nBiA * dye, dx0), dx1);
     return f.A * xs * xs + 2.f * f.B * xs * dye + f.C * dye * dye;
   };
   const float qmin = fminf(fminf(qx(dx0), qx(dx1)), fminf(qy(dy0), qy(dy1)));
@@ -325,9 +335,13 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: preprocess — projection, EWA covariance, conic, radius, SH -> RGB, per-tile pair counts
-// ([EXT] forward.cu preprocessCUDA; oracle preprocess()).  One wavefront per 64 Gaussians of a view.
+// K1: preprocess — projection, EWA covariance, conic, radius, SH -> RGB ([EXT] forward.cu preprocessCUDA;
+// oracle preprocess()).  One wavefront per 64 Gaussians of a view.  The wave's 64 x 3M SH floats (19 200 B at
+// M = 25) are requested first, as 16-byte coalesced loads into registers, so that HBM latency overlaps the
+// projection math; they are then transposed through LDS (row stride 3M floats, odd => conflict-free).
 // ------------------------------------------------------------------------------------------------
+constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's SH rows (64 * 75 / 4 / 64 = 18.75)
+
 __global__ __launch_bounds__(64) void k_preprocess(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x, v = blockIdx.y;
@@ -339,6 +353,22 @@ __global__ __launch_bounds__(64) void k_preprocess(const Params p) {
   const Grid& g = p.g;
   const bool in_range = i < N;
   const size_t gi = (size_t)set * N + (in_range ? i : 0), oi = (size_t)v * N + (in_range ? i : 0);
+
+  // ---- SH prefetch (fast path: rows contiguous in LDS, 16-byte aligned source)
+  const int M = (p.d.flags & GSR_FLAG_ABLATE_NO_SH) ? 0 : p.d.sh_coeffs;
+  const int rowf = 3 * M, ldstride = rowf | 1;
+  const int cnt = min(64, N - g0);
+  const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
+  const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
+  const bool sh_fast = (M > 0) && (ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0);
+  float4 pre[kShPre];
+  if (sh_fast) {
+#pragma unroll
+    for (int q = 0; q < kShPre; ++q) {
+      const int k = lane + 64 * q;
+      pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
+    }
+  }
 
   bool vis = in_range;
   float mx = 0, my = 0, mz = 0, cov6[6] = {0, 0, 0, 0, 0, 0}, op = 0;
@@ -376,14 +406,21 @@ __global__ __launch_bounds__(64) void k_preprocess(const Params p) {
     vis = (rx1 - rx0) * (ry1 - ry0) != 0;
   }
 
-  // colour
-  const int M = p.d.sh_coeffs;
+  // ---- colour
   float cr = 0, cg = 0, cb = 0;
   uint32_t clampbits = 0;
   if (M > 0) {
     if (__any(vis)) {
-      const int rowf = 3 * M, ldstride = rowf | 1;
-      stage_rows(lds, p.colors + ((size_t)set * N + g0) * rowf, min(64, N - g0), rowf, ldstride, lane);
+      if (sh_fast) {
+#pragma unroll
+        for (int q = 0; q < kShPre; ++q) {
+          const int k = lane + 64 * q;
+          if (k < sh_n4) reinterpret_cast<float4*>(lds)[k] = pre[q];
+        }
+        for (int k = (sh_n4 << 2) + lane; k < sh_total; k += 64) lds[k] = sh_src[k];
+      } else {
+        stage_rows(lds, sh_src, cnt, rowf, ldstride, lane);
+      }
       __syncthreads();
       if (vis) {
         const float* sh = lds + lane * ldstride;
@@ -399,7 +436,7 @@ __global__ __launch_bounds__(64) void k_preprocess(const Params p) {
         cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
       }
     }
-  } else if (vis) {
+  } else if (vis && p.d.sh_coeffs == 0) {
     cr = p.colors[3 * gi + 0]; cg = p.colors[3 * gi + 1]; cb = p.colors[3 * gi + 2];
   }
 
@@ -411,36 +448,118 @@ __global__ __launch_bounds__(64) void k_preprocess(const Params p) {
     rec.q0 = vis ? make_float4(px, py, conA, conB) : make_float4(0, 0, 0, 0);
     rec.q1 = vis ? make_float4(conC, op, cr, cg) : make_float4(0, 0, 0, 0);
     rec.q2 = make_float4(vis ? cb : 0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius | (clampbits << 28)));
-    p.geom[oi] = rec;
-    if (vis) {
+    unsigned long long mask = 0ull;
+    uint32_t origin = 0u;
+    if (vis && !(p.d.flags & GSR_FLAG_ABLATE_NO_COUNT)) {
       const Foot f = make_foot(px, py, conA, conB, conC, op, my_radius, g);
-      const uint32_t rep = (uint32_t)(i >> 6) & (kNRep - 1);
-      uint32_t* cnt = p.counts + (size_t)v * g.T * kNRep + rep;
-      for (int sy = f.sy0; sy < f.sy1; ++sy)
-        for (int sx = f.sx0; sx < f.sx1; ++sx)
-          if (subtile_hit(f, sx, sy, g)) atomicAdd(cnt + (size_t)(sy * g.sgx + sx) * kNRep, 1u);
+      if (f.sx1 > f.sx0 && f.sy1 > f.sy0) {
+        origin = (uint32_t)f.sx0 | ((uint32_t)f.sy0 << 12);
+        if (f.sx1 - f.sx0 <= 8 && f.sy1 - f.sy0 <= 8) {
+          for (int sy = f.sy0; sy < f.sy1; ++sy)
+            for (int sx = f.sx0; sx < f.sx1; ++sx)
+              if (subtile_hit(f, sx, sy, g)) mask |= 1ull << ((sy - f.sy0) * 8 + (sx - f.sx0));
+        } else {
+          origin |= 0x80000000u;
+        }
+      }
     }
+    rec.q3 = make_float4(__uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)), __uint_as_float(origin),
+                         vis ? pvz : 0.f);
+    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE)) p.geom[oi] = rec;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2a: per-tile exclusive scan over the 64 counter replicas (one wavefront per tile)
-// K2b: exclusive scan over all (view, tile) totals -> list ranges, pair total, overflow flag
+// Binning = counting sort of (8x8 tile, splat) pairs by tile WITHOUT global atomics (device-scope atomics
+// measured ~25 G/s on MI355X: 50 us per pass at 1.25 M pairs).  A workgroup owns a chunk of kChunk Gaussians
+// of one view and histograms its pairs per tile in LDS:
+//   K2 count : counts[v][chunk][tile] = pairs of this chunk in this tile        (LDS atomics, coalesced row store)
+//   K3a      : per (v, tile) exclusive scan down the chunk rows, tile totals     (column scan)
+//   K3b      : exclusive scan over all (v, tile) totals -> list ranges, pair total, overflow flag
+//   K4 emit  : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
+// Count and emit walk the same footprints with the same code, so slots match counts exactly.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_tile_prefix(const Params p) {
-  const size_t w = ((size_t)blockIdx.x * 256 + threadIdx.x) >> 6;
-  const int lane = threadIdx.x & 63;
-  const size_t VT = (size_t)p.d.num_views * p.g.T;
-  if (w >= VT) return;
-  const uint32_t c = p.counts[w * kNRep + lane];
-  uint32_t s = c;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)s, o, 64);
-    if (lane >= o) s += t;
+template <class F>
+__device__ __forceinline__ void for_each_pair(const Params& p, int v, int row, int tid, int t0, int t1, F&& f) {
+  const int N = p.d.num_gaussians;
+  const Grid& g = p.g;
+  const int end = min(N, (row + 1) * kChunk);
+  for (int i = row * kChunk + tid; i < end; i += kBinThreads) {
+    const GeomRec* rec = p.geom + (size_t)v * N + i;
+    const float4 q3 = rec->q3;
+    const uint32_t origin = __float_as_uint(q3.z);
+    unsigned long long m = ((unsigned long long)__float_as_uint(q3.y) << 32) | __float_as_uint(q3.x);
+    const int sx0 = (int)(origin & 0xfffu), sy0 = (int)((origin >> 12) & 0xfffu);
+    while (m) {
+      const int b = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int t = (sy0 + (b >> 3)) * g.sgx + sx0 + (b & 7);
+      if (t >= t0 && t < t1) f(i, t, q3.w);
+    }
+    if (origin & 0x80000000u) {  // footprint wider than the 8x8-tile mask window: walk it
+      const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
+      const Foot ft = make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
+      for (int sy = ft.sy0; sy < ft.sy1; ++sy)
+        for (int sx = ft.sx0; sx < ft.sx1; ++sx) {
+          const int t = sy * g.sgx + sx;
+          if (t >= t0 && t < t1 && subtile_hit(ft, sx, sy, g)) f(i, t, q3.w);
+        }
+    }
   }
-  p.counts[w * kNRep + lane] = s - c;
-  if (lane == 63) p.tile_total[w] = s;
+}
+
+__global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
+  __shared__ uint32_t hist[kTileWindow];
+  const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
+  const int T = p.g.T;
+  uint32_t* out = p.counts + ((size_t)v * p.rows + row) * T;
+  for (int t0 = 0; t0 < T; t0 += kTileWindow) {
+    const int t1 = min(T, t0 + kTileWindow);
+    for (int k = tid; k < t1 - t0; k += kBinThreads) hist[k] = 0;
+    __syncthreads();
+    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_COUNT))
+      for_each_pair(p, v, row, tid, t0, t1, [&](int, int t, float) { atomicAdd(&hist[t - t0], 1u); });
+    __syncthreads();
+    for (int k = tid; k < t1 - t0; k += kBinThreads) out[t0 + k] = hist[k];
+    __syncthreads();
+  }
+}
+
+// One workgroup = 64 consecutive (view, tile) columns x 16 row groups; two passes over the column (sum, then
+// write exclusive prefixes), partial sums exchanged through LDS.
+__global__ __launch_bounds__(1024) void k_tile_prefix(const Params p) {
+  __shared__ uint32_t part[16][64];
+  const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const size_t VT = (size_t)p.d.num_views * p.g.T;
+  const size_t col = (size_t)blockIdx.x * 64 + cx;
+  const int R = p.rows, T = p.g.T;
+  const int rpg = (R + 15) / 16, r0 = rg * rpg, r1 = min(R, r0 + rpg);
+  const bool ok = col < VT;
+  const size_t v = ok ? col / T : 0, t = ok ? col - v * T : 0;
+  uint32_t* base = p.counts + (v * R) * (size_t)T + t;
+  uint32_t sum = 0;
+  if (ok) {
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) sum += base[(size_t)r * T];
+  }
+  part[rg][cx] = sum;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const uint32_t x = part[k][cx];
+    run += (k < rg) ? x : 0u;
+    total += x;
+  }
+  if (ok) {
+#pragma unroll 8
+    for (int r = r0; r < r1; ++r) {
+      const uint32_t c = base[(size_t)r * T];
+      base[(size_t)r * T] = run;
+      run += c;
+    }
+    if (rg == 0) p.tile_total[col] = total;
+  }
 }
 
 __global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
@@ -483,95 +602,214 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// K3: emit (depth bits : Gaussian index) keys into each tile's list segment (order inside a segment is
-// arbitrary here; K4 sorts it).  Recomputes the footprint from the stored record with the same code as K1.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_emit(const Params p) {
+__global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
+  __shared__ uint32_t cursor[kTileWindow];
   if (p.status->overflow) return;
-  const int v = blockIdx.y;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const int N = p.d.num_gaussians;
-  if (i >= N) return;
-  const Grid& g = p.g;
-  const GeomRec* rec = p.geom + (size_t)v * N + i;
-  const float4 q2 = rec->q2;
-  const uint32_t radius = __float_as_uint(q2.w) & 0x0fffffffu;
-  if (radius == 0) return;
-  const float4 q0 = rec->q0, q1 = rec->q1;
-  const Foot f = make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)radius, g);
-  const uint32_t rep = (uint32_t)(i >> 6) & (kNRep - 1);
-  const unsigned long long key = ((unsigned long long)__float_as_uint(q2.z) << 32) | (uint32_t)i;
-  for (int sy = f.sy0; sy < f.sy1; ++sy)
-    for (int sx = f.sx0; sx < f.sx1; ++sx)
-      if (subtile_hit(f, sx, sy, g)) {
-        const size_t vt = (size_t)v * g.T + (size_t)(sy * g.sgx + sx);
-        const uint32_t slot = p.ranges[vt].x + atomicAdd(p.counts + vt * kNRep + rep, 1u);
-        if (slot < p.ranges[vt].y) p.keys[slot] = key;
-      }
+  const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
+  const int T = p.g.T;
+  const uint32_t* rowp = p.counts + ((size_t)v * p.rows + row) * T;
+  const uint2* rng = p.ranges + (size_t)v * T;
+  const uint32_t cap = (uint32_t)p.d.pair_capacity;
+  for (int t0 = 0; t0 < T; t0 += kTileWindow) {
+    const int t1 = min(T, t0 + kTileWindow);
+    for (int k = tid; k < t1 - t0; k += kBinThreads) cursor[k] = rng[t0 + k].x + rowp[t0 + k];
+    __syncthreads();
+    for_each_pair(p, v, row, tid, t0, t1, [&](int i, int t, float depth) {
+      const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t - t0] : atomicAdd(&cursor[t - t0], 1u);
+      if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
+        p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)i;
+    });
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: per-tile depth sort, one wavefront per tile.  Bitonic network in its all-ascending (mirror) form so
-// that a list of any length sorts with virtual +inf padding; <= kSortLds keys sort in LDS, longer lists
-// in place in global memory.  Writes the sorted Gaussian indices (the reference's point_list).
+// K5: per-tile depth sort, kSortThreads threads per tile.  Bitonic network in its all-ascending (mirror)
+// form so that a list of any length sorts with virtual +inf padding; <= kSortLds keys sort in LDS, longer
+// lists in place in global memory.  Within a substep all compare-exchanges are disjoint, so each thread
+// loads a batch of pairs before storing any (LDS latency paid once per batch, not once per pair).
+// Writes the sorted Gaussian indices (the reference's point_list).
 // ------------------------------------------------------------------------------------------------
-template <class KeyPtr>
-__device__ __forceinline__ void bitonic_wave(KeyPtr a, int n, int np, int lane) {
-  const int half = np >> 1;
-  for (int k = 2; k <= np; k <<= 1) {
-    const int hk = k >> 1;
-    for (int t = lane; t < half; t += 64) {
-      const int blk = t / hk, off = t - blk * hk;
-      const int i = blk * k + off, j = blk * k + k - 1 - off;
-      if (j < n) {
-        const unsigned long long x = a[i], y = a[j];
-        if (x > y) { a[i] = y; a[j] = x; }
-      }
+template <bool kFlip, class KeyPtr>
+__device__ __forceinline__ void bitonic_substep(KeyPtr a, int n, int half, int lg, int tid) {
+  // kFlip: pairs (blk*2^(lg+1) + off, blk*2^(lg+1) + 2^(lg+1) - 1 - off); else (i, i + 2^lg), off < 2^lg
+  constexpr int U = 4;
+  const int w = 1 << lg;
+  for (int tb = tid; tb < half; tb += kSortThreads * U) {
+    int ii[U], jj[U];
+    unsigned long long x[U], y[U];
+    bool act[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = tb + u * kSortThreads;
+      const int blk = t >> lg, off = t & (w - 1);
+      ii[u] = (blk << (lg + 1)) + off;
+      jj[u] = kFlip ? (blk << (lg + 1)) + 2 * w - 1 - off : ii[u] + w;
+      act[u] = (t < half) && (jj[u] < n);
+      x[u] = act[u] ? a[ii[u]] : 0ull;
+      y[u] = act[u] ? a[jj[u]] : 0ull;
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (act[u] && x[u] > y[u]) { a[ii[u]] = y[u]; a[jj[u]] = x[u]; }
+  }
+}
+
+template <class KeyPtr>
+__device__ __forceinline__ void bitonic_block(KeyPtr a, int n, int lgnp, int tid) {
+  const int half = 1 << (lgnp - 1);
+  for (int lk = 1; lk <= lgnp; ++lk) {
+    bitonic_substep<true>(a, n, half, lk - 1, tid);
     __syncthreads();
-    for (int jj = k >> 2; jj >= 1; jj >>= 1) {
-      for (int t = lane; t < half; t += 64) {
-        const int blk = t / jj, off = t - blk * jj;
-        const int i = blk * 2 * jj + off, j = i + jj;
-        if (j < n) {
-          const unsigned long long x = a[i], y = a[j];
-          if (x > y) { a[i] = y; a[j] = x; }
-        }
-      }
+    for (int lj = lk - 2; lj >= 0; --lj) {
+      bitonic_substep<false>(a, n, half, lj, tid);
       __syncthreads();
     }
   }
 }
 
-__global__ __launch_bounds__(64) void k_sort_tiles(const Params p) {
+constexpr int kBuckets = 1024;    // per-tile depth buckets of the bucket sort
+constexpr int kSpanMax = 48;      // longest per-thread span the insertion-sort finish accepts (else bitonic fallback)
+
+// Exclusive scan over the kSortThreads per-thread values of a workgroup (wave scan + 4 wave totals through LDS).
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot /*[4] LDS*/, int tid, uint32_t& total) {
+  const int lane = tid & 63, w = tid >> 6;
+  uint32_t s = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)s, o, 64);
+    if (lane >= o) s += t;
+  }
+  if (lane == 63) wave_tot[w] = s;
+  __syncthreads();
+  uint32_t basew = 0;
+  total = 0;
+#pragma unroll
+  for (int k = 0; k < kSortThreads / 64; ++k) {
+    const uint32_t x = wave_tot[k];
+    basew += (k < w) ? x : 0u;
+    total += x;
+  }
+  return basew + s - v;
+}
+
+// K5: per-tile depth sort, kSortThreads threads per tile; writes the sorted Gaussian indices (the reference's
+// point_list).  Lists of up to kSortLds keys: LDS bucket sort - keys stay in registers, one LDS-atomic histogram
+// over kBuckets buckets of the tile's own depth range (float bits are monotonic for positive depths), exclusive
+// scan, LDS-atomic scatter, then every thread insertion-sorts the few keys of its 4 adjacent buckets with the full
+// 64-bit (depth, index) compare.  ~40 B of LDS traffic per key instead of ~800 B for an in-LDS bitonic network.
+// Degenerate depth distributions (a span longer than kSpanMax) fall back to the bitonic network on the same LDS
+// array; lists longer than kSortLds sort in place in global memory with the same network.
+__global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   __shared__ unsigned long long sk[kSortLds];
-  const int lane = threadIdx.x;
+  __shared__ uint32_t hist[kBuckets];  // counts, then (same storage) scatter cursors
+  __shared__ uint32_t red[8];
+  uint32_t* cur = hist;
+  const int tid = threadIdx.x;
   const uint2 rg = p.ranges[blockIdx.x];
   const int n = (int)(rg.y - rg.x);
   if (n == 0) return;
   unsigned long long* keys = p.keys + rg.x;
   uint32_t* out = p.point_list + rg.x;
-  int np = 2;
-  while (np < n) np <<= 1;
-  if (n <= kSortLds) {
-    for (int k = lane; k < n; k += 64) sk[k] = keys[k];
-    __syncthreads();
-    bitonic_wave(sk, n, np, lane);
-    for (int k = lane; k < n; k += 64) out[k] = (uint32_t)sk[k];
-  } else {
-    __syncthreads();
-    bitonic_wave(keys, n, np, lane);
-    for (int k = lane; k < n; k += 64) out[k] = (uint32_t)keys[k];
+  if (n == 1) {
+    if (tid == 0) out[0] = (uint32_t)keys[0];
+    return;
   }
+  int lgnp = 1;
+  while ((1 << lgnp) < n) ++lgnp;
+  if (n > kSortLds) {
+    __syncthreads();
+    bitonic_block(keys, n, lgnp, tid);
+    for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)keys[k];
+    return;
+  }
+  constexpr int Q = kSortLds / kSortThreads;
+  unsigned long long kreg[Q];
+  uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int k = tid + q * kSortThreads;
+    kreg[q] = (k < n) ? keys[k] : ~0ull;
+    if (k < n) {
+      const uint32_t d = (uint32_t)(kreg[q] >> 32);
+      lo = d < lo ? d : lo;
+      hi = d > hi ? d : hi;
+    }
+  }
+  for (int k = tid; k < kBuckets; k += kSortThreads) hist[k] = 0;
+  // block min / max of the depth bits
+  hi = wave_max_u32(hi);
+  lo = ~wave_max_u32(~lo);
+  if ((tid & 63) == 0) { red[tid >> 6] = lo; red[4 + (tid >> 6)] = hi; }
+  __syncthreads();
+  lo = min(min(red[0], red[1]), min(red[2], red[3]));
+  hi = max(max(red[4], red[5]), max(red[6], red[7]));
+  const uint32_t range = hi - lo;
+  const int shift = range < (uint32_t)kBuckets ? 0 : (32 - __clz((int)range)) - 10;
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (tid + q * kSortThreads < n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - lo) >> shift], 1u);
+  __syncthreads();
+  // exclusive scan of the bucket counts: thread t owns buckets 4t .. 4t+3
+  const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+  const uint32_t span = c0 + c1 + c2 + c3;
+  uint32_t total;
+  const uint32_t start = block_exclusive_scan(span, red, tid, total);
+  cur[4 * tid] = start; cur[4 * tid + 1] = start + c0; cur[4 * tid + 2] = start + c0 + c1; cur[4 * tid + 3] = start + c0 + c1 + c2;
+  const bool big = __syncthreads_or(span > (uint32_t)kSpanMax) != 0;
+  // scatter into bucket order
+#pragma unroll
+  for (int q = 0; q < Q; ++q)
+    if (tid + q * kSortThreads < n) {
+      const uint32_t slot = atomicAdd(&cur[((uint32_t)(kreg[q] >> 32) - lo) >> shift], 1u);
+      sk[slot] = kreg[q];
+    }
+  __syncthreads();
+  if (!big) {
+    const int b = (int)start, e = (int)(start + span);
+    for (int i = b + 1; i < e; ++i) {
+      const unsigned long long key = sk[i];
+      int j = i;
+      while (j > b && sk[j - 1] > key) { sk[j] = sk[j - 1]; --j; }
+      sk[j] = key;
+    }
+  } else {
+    bitonic_block(sk, n, lgnp, tid);
+  }
+  __syncthreads();
+  for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: forward blend, one wavefront per 8x8 tile, lane = pixel ([EXT] forward.cu renderCUDA; oracle
-// blend_forward).  Splat records are gathered 64 at a time (lane = splat) into LDS and then broadcast.
+// Blend helpers shared by the forward and backward blend kernels (both must take the same skip decisions).
+// At staging time (lane = splat) the conic is moved to the exp2 domain: a2 = -0.5 log2e A, b2 = -log2e B,
+// c2 = -0.5 log2e C, so that per pixel  G = exp(power) = 2^(a2 dx^2 + b2 dx dy + c2 dy^2)  costs two multiplies,
+// two FMAs and one v_exp_f32.
 // ------------------------------------------------------------------------------------------------
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kLn2 = 0.6931471805599453f;
+
+__device__ __forceinline__ void to_exp2_domain(float4& q0, float4& q1) {
+  q0.z = (-0.5f * kLog2e) * q0.z;
+  q0.w = (-kLog2e) * q0.w;
+  q1.x = (-0.5f * kLog2e) * q1.x;
+}
+__device__ __forceinline__ float splat_p2(float a2, float b2, float c2, float dx, float dy) {
+  const float t = __builtin_fmaf(b2, dy, a2 * dx);
+  return __builtin_fmaf(c2 * dy, dy, t * dx);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: forward blend, one wavefront per 8x8 tile, lane = pixel ([EXT] forward.cu renderCUDA; oracle
+// blend_forward).  Splat records are gathered 64 at a time (lane = splat) into a double-buffered LDS stage
+// and then broadcast; the gather of batch b+1 and the index load of batch b+2 are in flight while batch b
+// is blended.  Lanes past the end of the list stage a null record (opacity 0 => alpha < 1/255 => skipped).
+// The per-pixel update is branch-free (selects) and unrolled by 4 so the independent alpha evaluations of
+// consecutive splats overlap the dependent transmittance chain.
+// ------------------------------------------------------------------------------------------------
+template <bool kExtra>
 __global__ __launch_bounds__(64) void k_blend_fwd(const Params p) {
-  __shared__ float4 s0[64], s1[64], s2[64];
+  __shared__ float4 sb[2][3][64];
   const Grid& g = p.g;
   const int lane = threadIdx.x;
   const int v = blockIdx.y;
@@ -581,40 +819,75 @@ __global__ __launch_bounds__(64) void k_blend_fwd(const Params p) {
   const bool inside = pxi < g.W && pyi < g.H;
   const float pxf = (float)pxi, pyf = (float)pyi;
   const uint2 rg = p.ranges[(size_t)v * g.T + t];
+  const uint32_t n = rg.y - rg.x;
+  const uint32_t* plist = p.point_list + rg.x;
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
-  const bool has_extra = p.d.has_extra != 0;
+  const float4 zero4 = make_float4(0, 0, 0, 0);
 
   float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;
-  uint32_t last = 0;
+  uint32_t last = 0, consumed = 0;
   bool done = !inside;
-  for (uint32_t base = rg.x; base < rg.y; base += 64) {
-    if (__all(done)) break;
-    const int nb = min(64u, rg.y - base);
-    if (lane < nb) {
-      const GeomRec* r = geom + p.point_list[base + lane];
-      s0[lane] = r->q0; s1[lane] = r->q1; s2[lane] = r->q2;
+  if (n > 0 && !__all(done)) {
+    // prologue: batch 0 -> LDS[0]; indices of batch 1 in flight
+    float4 r0 = zero4, r1 = zero4, r2 = zero4;
+    if ((uint32_t)lane < n) {
+      const GeomRec* r = geom + plist[lane];
+      r0 = r->q0; r1 = r->q1; r2 = r->q2;
     }
+    uint32_t id1 = (64u + lane < n) ? plist[64 + lane] : 0u;
+    to_exp2_domain(r0, r1);
+    sb[0][0][lane] = r0; sb[0][1][lane] = r1; sb[0][2][lane] = r2;
     __syncthreads();
-    for (int j = 0; j < nb; ++j) {
-      if ((j & 3) == 0 && __all(done)) break;
-      const float4 a = s0[j], b = s1[j], c = s2[j];
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float alpha = fminf(0.99f, b.y * __expf(power));
-      const float test_T = T * (1.f - alpha);
-      const bool ok = !done && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
-      const bool stop = ok && (test_T < 0.0001f);
-      const bool acc = ok && !stop;
-      done = done || stop;
-      if (acc) {
-        C0 += b.z * alpha * T; C1 += b.w * alpha * T; C2 += c.x * alpha * T;
-        if (has_extra) E += c.y * alpha * T;
-        T = test_T;
-        last = base - rg.x + j + 1;
+    for (uint32_t base = 0, b = 0; base < n; base += 64, ++b) {
+      const int cur = b & 1;
+      const uint32_t nb = min(64u, n - base);
+      const bool has_next = base + 64 < n;
+      r0 = zero4; r1 = zero4; r2 = zero4;
+      if (has_next && base + 64 + lane < n) {
+        const GeomRec* r = geom + id1;
+        r0 = r->q0; r1 = r->q1; r2 = r->q2;
       }
+      const uint32_t id2 = (base + 128 + lane < n) ? plist[base + 128 + lane] : 0u;
+      // LDS reads run one group of 4 splats ahead of the arithmetic
+      float4 na[4], nq[4], nc[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { na[u] = sb[cur][0][u]; nq[u] = sb[cur][1][u]; nc[u] = sb[cur][2][u]; }
+      for (uint32_t j = 0; j < nb; j += 4) {
+        if (__all(done)) break;
+        consumed = base + j + 4;
+        float4 a[4], bq[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = na[u]; bq[u] = nq[u]; c[u] = nc[u]; }
+        const uint32_t jn = (j + 4 < 64u) ? j + 4 : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { na[u] = sb[cur][0][jn + u]; nq[u] = sb[cur][1][jn + u]; nc[u] = sb[cur][2][jn + u]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = a[u].x - pxf, dy = a[u].y - pyf;
+          const float p2 = splat_p2(a[u].z, a[u].w, bq[u].x, dx, dy);
+          const float alpha = fminf(0.99f, bq[u].y * __builtin_amdgcn_exp2f(p2));
+          const float test_T = T * (1.f - alpha);
+          const bool ok = !done && !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
+          const bool stop = ok && (test_T < 0.0001f);
+          const bool acc = ok && !stop;
+          done = done || stop;
+          const float w = acc ? alpha * T : 0.f;
+          C0 = __builtin_fmaf(bq[u].z, w, C0);
+          C1 = __builtin_fmaf(bq[u].w, w, C1);
+          C2 = __builtin_fmaf(c[u].x, w, C2);
+          if (kExtra) E = __builtin_fmaf(c[u].y, w, E);
+          T = acc ? test_T : T;
+          last = acc ? base + j + u + 1 : last;
+        }
+      }
+      if (!has_next || __all(done)) break;
+      to_exp2_domain(r0, r1);
+      sb[cur ^ 1][0][lane] = r0; sb[cur ^ 1][1][lane] = r1; sb[cur ^ 1][2][lane] = r2;
+      __syncthreads();
+      id1 = id2;
     }
-    __syncthreads();
   }
+  if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
   if (inside) {
     const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
     const GsrView& cam = p.views[v];
@@ -624,19 +897,41 @@ __global__ __launch_bounds__(64) void k_blend_fwd(const Params p) {
     oc[pix] = C0 + T * cam.bg[0];
     oc[HW + pix] = C1 + T * cam.bg[1];
     oc[2 * HW + pix] = C2 + T * cam.bg[2];
-    if (has_extra) p.out_extra[(size_t)v * HW + pix] = E;
+    if (kExtra) p.out_extra[(size_t)v * HW + pix] = E;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // B1: backward blend, one wavefront per 8x8 tile, back-to-front replay ([EXT] backward.cu renderCUDA;
-// oracle blend_backward).  Per splat the 64 pixel gradients are reduced across the wavefront and one
-// lane per value issues the atomic into the per-(view,Gaussian) screen-space accumulator:
+// oracle blend_backward).  Per splat the 64 pixel gradients are reduced across the wavefront with DPP row
+// shifts / row broadcasts (no LDS traffic) and one lane per value issues the atomic into the per-(view,
+// Gaussian) screen-space accumulator:
 //   scratch[.. * 12 + {0,1: dmean2D  2,3,4: dconic  5: dopacity  6,7,8: dcolor  9: dextra}]
+// Record gathers are double-buffered like the forward blend.
 // ------------------------------------------------------------------------------------------------
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_add(float acc, float src) {
+  return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+}
+// Sum over the 64 lanes; the total is returned wave-uniform (read from lane 63).
+__device__ __forceinline__ float wave_sum_uniform(float v) {
+#if defined(GSR_REDUCE_SHFL)
+  return wave_sum(v);
+#else
+  float a = dpp_add<0x111, 0xf, 0xf>(v, v);  // + row_shr:1
+  a = dpp_add<0x112, 0xf, 0xf>(a, v);        // + row_shr:2
+  a = dpp_add<0x113, 0xf, 0xf>(a, v);        // + row_shr:3  -> sums of 4
+  a = dpp_add<0x114, 0xf, 0xe>(a, a);        // + row_shr:4, banks 1-3 -> sums of 8
+  a = dpp_add<0x118, 0xf, 0xc>(a, a);        // + row_shr:8, banks 2-3 -> lane 15 of each row = row sum
+  a = dpp_add<0x142, 0xa, 0xf>(a, a);        // + row_bcast:15 into rows 1,3
+  a = dpp_add<0x143, 0xc, 0xf>(a, a);        // + row_bcast:31 into rows 2,3 -> lane 63 = total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
+#endif
+}
+
 __global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
-  __shared__ float4 s0[64], s1[64], s2[64];
-  __shared__ uint32_t sid[64];
+  __shared__ float4 sb[2][3][64];
+  __shared__ uint32_t sid[2][64];
   const Grid& g = p.g;
   const int lane = threadIdx.x;
   const int v = blockIdx.y;
@@ -648,9 +943,11 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
   const uint2 rg = p.ranges[(size_t)v * g.T + t];
   const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
+  const uint32_t* plist = p.point_list + rg.x;
   float* scratch = p.scratch + (size_t)v * p.d.num_gaussians * GSR_SCREEN_GRAD_FLOATS;
   const GsrView& cam = p.views[v];
   const bool has_extra = p.d.has_extra != 0 && p.dL_dextra_img != nullptr;
+  const float4 zero4 = make_float4(0, 0, 0, 0);
 
   const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
   const uint32_t my_last = inside ? p.n_contrib[(size_t)v * HW + pix] : 0u;
@@ -667,31 +964,44 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
 
   float T = T_final, last_alpha = 0.f;
   float ar0 = 0, ar1 = 0, ar2 = 0, are = 0, lc0 = 0, lc1 = 0, lc2 = 0, lce = 0;
-  for (int base = (int)((nmax - 1) & ~63u); base >= 0; base -= 64) {
+  // batches are visited from the last (partial) one down to batch 0
+  const int top = (int)((nmax - 1) & ~63u);
+  float4 r0 = zero4, r1 = zero4, r2 = zero4;
+  uint32_t idc = 0;
+  if ((uint32_t)(top + lane) < nmax) {
+    idc = plist[top + lane];
+    const GeomRec* r = geom + idc;
+    r0 = r->q0; r1 = r->q1; r2 = r->q2;
+  }
+  uint32_t id1 = (top >= 64) ? plist[top - 64 + lane] : 0u;  // batch below is always full
+  to_exp2_domain(r0, r1);
+  sb[0][0][lane] = r0; sb[0][1][lane] = r1; sb[0][2][lane] = r2; sid[0][lane] = idc;
+  __syncthreads();
+  for (int base = top, b = 0; base >= 0; base -= 64, ++b) {
+    const int cur = b & 1;
     const int nb = min(64, (int)nmax - base);
-    if (lane < nb) {
-      const uint32_t id = p.point_list[rg.x + base + lane];
-      const GeomRec* r = geom + id;
-      s0[lane] = r->q0; s1[lane] = r->q1; s2[lane] = r->q2;
-      sid[lane] = id;
+    const bool has_next = base >= 64;
+    if (has_next) {
+      const GeomRec* r = geom + id1;
+      r0 = r->q0; r1 = r->q1; r2 = r->q2;
     }
-    __syncthreads();
+    const uint32_t id2 = (base >= 128) ? plist[base - 128 + lane] : 0u;
     for (int j = nb - 1; j >= 0; --j) {
-      const float4 a = s0[j], b = s1[j], c = s2[j];
+      const float4 a = sb[cur][0][j], bq = sb[cur][1][j], c = sb[cur][2][j];
       const uint32_t idx = (uint32_t)(base + j);
       const float dx = a.x - pxf, dy = a.y - pyf;
-      const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-      const float G = __expf(power);
-      const float alpha = fminf(0.99f, b.y * G);
-      const bool ok = (idx < my_last) && !(power > 0.f) && !(alpha < 1.0f / 255.0f);
+      const float p2 = splat_p2(a.z, a.w, bq.x, dx, dy);
+      const float G = __builtin_amdgcn_exp2f(p2);
+      const float alpha = fminf(0.99f, bq.y * G);
+      const bool ok = (idx < my_last) && !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
       if (!__any(ok)) continue;
       float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
       if (ok) {
         T = T / (1.f - alpha);
         const float dchannel_dcolor = alpha * T;
         float dL_dalpha = 0.f;
-        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = b.z; dL_dalpha += (b.z - ar0) * g0; v6 = dchannel_dcolor * g0;
-        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = b.w; dL_dalpha += (b.w - ar1) * g1; v7 = dchannel_dcolor * g1;
+        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = bq.z; dL_dalpha += (bq.z - ar0) * g0; v6 = dchannel_dcolor * g0;
+        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = bq.w; dL_dalpha += (bq.w - ar1) * g1; v7 = dchannel_dcolor * g1;
         ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.x; dL_dalpha += (c.x - ar2) * g2; v8 = dchannel_dcolor * g2;
         if (has_extra) {
           are = last_alpha * lce + (1.f - last_alpha) * are; lce = c.y; dL_dalpha += (c.y - are) * ge; v9 = dchannel_dcolor * ge;
@@ -699,10 +1009,11 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
         dL_dalpha *= T;
         last_alpha = alpha;
         dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-        const float dL_dG = b.y * dL_dalpha;
+        const float dL_dG = bq.y * dL_dalpha;
         const float gdx = G * dx, gdy = G * dy;
-        const float dG_ddelx = -gdx * a.z - gdy * a.w;
-        const float dG_ddely = -gdy * b.x - gdx * a.w;
+        // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
+        const float dG_ddelx = kLn2 * (2.f * a.z * gdx + a.w * gdy);
+        const float dG_ddely = kLn2 * (2.f * bq.x * gdy + a.w * gdx);
         v0 = dL_dG * dG_ddelx * ddelx_dx;
         v1 = dL_dG * dG_ddely * ddely_dy;
         v2 = -0.5f * gdx * dx * dL_dG;
@@ -710,18 +1021,23 @@ __global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
         v4 = -0.5f * gdy * dy * dL_dG;
         v5 = G * dL_dalpha;
       }
-      v0 = wave_sum(v0); v1 = wave_sum(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_sum(v4);
-      v5 = wave_sum(v5); v6 = wave_sum(v6); v7 = wave_sum(v7); v8 = wave_sum(v8);
-      if (has_extra) v9 = wave_sum(v9);
+      v0 = wave_sum_uniform(v0); v1 = wave_sum_uniform(v1); v2 = wave_sum_uniform(v2); v3 = wave_sum_uniform(v3);
+      v4 = wave_sum_uniform(v4); v5 = wave_sum_uniform(v5); v6 = wave_sum_uniform(v6); v7 = wave_sum_uniform(v7);
+      v8 = wave_sum_uniform(v8);
+      if (has_extra) v9 = wave_sum_uniform(v9);
       if (lane < 10) {
         float val = v0;
         val = lane == 1 ? v1 : val; val = lane == 2 ? v2 : val; val = lane == 3 ? v3 : val; val = lane == 4 ? v4 : val;
         val = lane == 5 ? v5 : val; val = lane == 6 ? v6 : val; val = lane == 7 ? v7 : val; val = lane == 8 ? v8 : val;
         val = lane == 9 ? v9 : val;
-        unsafeAtomicAdd(scratch + (size_t)sid[j] * GSR_SCREEN_GRAD_FLOATS + lane, val);
+        unsafeAtomicAdd(scratch + (size_t)sid[cur][j] * GSR_SCREEN_GRAD_FLOATS + lane, val);
       }
     }
+    if (!has_next) break;
+    to_exp2_domain(r0, r1);
+    sb[cur ^ 1][0][lane] = r0; sb[cur ^ 1][1][lane] = r1; sb[cur ^ 1][2][lane] = r2; sid[cur ^ 1][lane] = id1;
     __syncthreads();
+    id1 = id2;
   }
 }
 
@@ -910,6 +1226,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   Params p{};
   p.d = *d;
   p.g = make_grid(d->width, d->height);
+  p.rows = (d->num_gaussians + kChunk - 1) / kChunk;
   p.views = views; p.means = means; p.cov6 = cov6; p.opac = opac; p.colors = colors; p.extra = extra;
   const Layout L = make_layout(*d);
   char* b = static_cast<char*>(bin);
@@ -942,7 +1259,7 @@ extern "C" {
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 const char* gsr_build_info(void) {
-  return "gsr_hip gfx950 wave64 tile8x8 nrep64 sortlds4096 abi1";
+  return "gsr_hip gfx950 wave64 tile8x8 chunk2048 sortlds4096 abi1";
 }
 
 int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes) {
@@ -989,19 +1306,20 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   int e = 0;
 #define GSR_MARK() do { if (ev) GSR_CHECK(hipEventRecord(ev[e++], st)); } while (0)
   GSR_MARK();
-  GSR_CHECK(hipMemsetAsync(p.counts, 0, VT * kNRep * sizeof(uint32_t), st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
   hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + 63) / 64), (unsigned)V), dim3(64), shmem, st, p);
   GSR_MARK();
-  hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT * 64 + 255) / 256)), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 63) / 64)), dim3(1024), 0, st, p);
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
   GSR_MARK();
-  hipLaunchKernelGGL(k_emit, dim3((unsigned)((N + 255) / 256), (unsigned)V), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(k_emit, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   GSR_MARK();
-  hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
   GSR_MARK();
-  hipLaunchKernelGGL(k_blend_fwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
   GSR_MARK();
 #undef GSR_MARK
   GSR_CHECK(hipGetLastError());

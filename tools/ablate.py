@@ -1,0 +1,55 @@
+"""Measurement aid: per-stage HIP-event timings of the forward chain with ablation flag bits (include/gsr.h) set,
+to attribute time inside a kernel (results are wrong on purpose).  GPU box only."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pf3plat_amd import synthetic  # noqa: E402
+from pf3plat_amd.rasterizer import HipBackend, RasterConfig  # noqa: E402
+
+FLAGS = {"baseline": 0, "no_count": 0x100, "no_sh": 0x200, "no_count_no_sh": 0x300, "no_count_no_sh_no_geom": 0x1300,
+         "emit_no_store": 0x400, "emit_no_atomic": 0x800, "emit_neither": 0xC00}
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(2, n, (256, 256))
+    means, cov6, opac, shs = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
+    vb = synthetic.scene_viewbuf(sc).to(dev)
+    cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False)
+    be = HipBackend()
+    for name, fl in FLAGS.items():
+        plan = be.make_plan(cfg, dev, capacity=8 * n)
+        plan["dims"].flags = fl
+        acc = {}
+        for it in range(25):
+            ms = be.run_forward(plan, vb, means, cov6, opac, shs, profile=True)
+            if it >= 5:
+                for k, v in ms.items():
+                    acc[k] = acc.get(k, 0.0) + v / 20
+        print(f"{name:26s}", {k: round(v * 1e3, 1) for k, v in acc.items()}, "us", be.read_status(plan), flush=True)
+        if name == "baseline":
+            lay = be.workspace_layout(plan["dims"])
+            T = 4 * ((256 + 15) // 16) ** 2
+            rg = plan["bin"][lay["ranges"]: lay["ranges"] + T * 8].view(torch.int32).reshape(T, 2).cpu()
+            nc = plan["img"][lay["n_contrib"]: lay["n_contrib"] + 256 * 256 * 4].view(torch.int32).reshape(32, 8, 32, 8).cpu()
+            per_tile_max = nc.permute(0, 2, 1, 3).reshape(1024, 64).max(1).values.float()
+            per_px = nc.float().mean()
+            ln = (rg[:, 1] - rg[:, 0]).float()
+            walked = plan["bin"][lay["tile_total"]: lay["tile_total"] + T * 4].view(torch.int32).cpu().float()
+            ft = plan["img"][lay["final_T"]: lay["final_T"] + 256 * 256 * 4].view(torch.float32).reshape(32, 8, 32, 8).cpu()
+            undone = (ft.permute(0, 2, 1, 3).reshape(1024, 64) * 0 + (nc.permute(0, 2, 1, 3).reshape(1024, 64) >= 0)).sum(1)
+            full = (walked >= ln - 3).float().mean()
+            q = torch.quantile(walked, torch.tensor([0.1, 0.5, 0.9, 0.99]))
+            print("walked: mean", walked.mean().item(), "max", walked.max().item(), "quantiles 10/50/90/99", q.tolist(),
+                  "| fraction of tiles that walked their whole list", full.item(), flush=True)
+            print("lists: mean", ln.mean().item(), "max", ln.max().item(), "| per-tile max n_contrib: mean", per_tile_max.mean().item(),
+                  "max", per_tile_max.max().item(), "| per-pixel n_contrib mean", per_px.item(), flush=True)
+
+
+if __name__ == "__main__":
+    main()
