@@ -48,6 +48,7 @@ extern "C" {
 #define GSR_FLAG_ABLATE_EMIT_NO_STORE 0x400  /* emit: skip the key stores */
 #define GSR_FLAG_ABLATE_EMIT_NO_ATOMIC 0x800 /* emit: skip the slot atomics */
 #define GSR_FLAG_ABLATE_NO_GEOM_STORE 0x1000 /* preprocess: skip the projected-record store */
+#define GSR_FLAG_DEBUG_TIMING 0x2000         /* forward blend: per-tile cycle stamps into the (then unused) key buffer */
 
 /* One camera = the non-tensor fields of upstream's GaussianRasterizationSettings
  * (constructed at cuda_splatting.py:99-112), 48 floats = 192 bytes. */

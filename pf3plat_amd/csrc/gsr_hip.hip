@@ -800,18 +800,53 @@ __device__ __forceinline__ float splat_p2(float a2, float b2, float c2, float dx
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: forward blend, one wavefront per 8x8 tile, lane = pixel ([EXT] forward.cu renderCUDA; oracle
-// blend_forward).  Splat records are gathered 64 at a time (lane = splat) into a double-buffered LDS stage
-// and then broadcast; the gather of batch b+1 and the index load of batch b+2 are in flight while batch b
-// is blended.  Lanes past the end of the list stage a null record (opacity 0 => alpha < 1/255 => skipped).
-// The per-pixel update is branch-free (selects) and unrolled by 4 so the independent alpha evaluations of
-// consecutive splats overlap the dependent transmittance chain.
+// K6: forward blend ([EXT] forward.cu renderCUDA; oracle blend_forward).  One workgroup of four wavefronts per
+// 8x8 tile, lane = pixel in every wave, SPECIALISED and pipelined over batches of kFB list entries:
+//   helpers (waves 1-3), stage E : alpha(pixel, splat) for a third of a batch each -> LDS sX[batch % 3][entry][pixel]
+//                                  (0 where the reference would skip: power > 0 or alpha < 1/255); T-independent
+//   scan    (wave 0),    stage S : the only sequential part.  Free-running transmittance Tf <- Tf (1 - alpha) is the
+//                                  single loop-carried dependence (one multiply per entry); since Tf never increases,
+//                                  "the reference loop has stopped" <=> Tf (1 - alpha) < 1e-4 now.  Overwrites alpha in
+//                                  place with the blend weight w = alpha Tf (0 once stopped / when skipped).
+//   helpers,             stage A : colour (and extra-channel) accumulation sum_j c_j w_j over their third of the
+//                                  previous batch, plus the last-contributor index
+//   wave 1 also gathers the splat records two batches ahead (global gather issued before its E/A share, LDS write after).
+// Why: a lone wavefront issues one VALU instruction per ~6 cycles on MI355X (measured), and a 256x256 view only has
+// 1024 tiles for 1024 SIMDs - so the dependent chain is cut to ~8 instructions per entry on one wave and everything
+// else runs on co-resident helper waves.  Per-pixel arithmetic is that of the sequential reference loop; only the
+// colour sum is split into three partial sums (added in wave order at the end).
 // ------------------------------------------------------------------------------------------------
+// Four waves per workgroup = one per SIMD: with a fifth wave every workgroup puts two waves on the same SIMD and the
+// per-SIMD register file then admits only 3 workgroups per CU (768 of the 1024 tiles of a 256x256 view; measured).
+constexpr int kFwdHelpers = 3;
+constexpr int kFE = 11;                               // entries per helper per batch
+constexpr int kFB = kFE * kFwdHelpers;                // 33 list entries per batch
+constexpr int kFwdThreads = 64 * (1 + kFwdHelpers);   // 256
+
+__device__ __forceinline__ void stage_batch(const GeomRec* geom, const uint32_t* plist, uint32_t n, uint32_t base, int lane,
+                                            uint32_t id, float4& g, float2& g2, float4& c) {
+  // lane = splat; null record (opacity 0) past the end of the list
+  g = make_float4(0, 0, 0, 0); g2 = make_float2(0, 0); c = make_float4(0, 0, 0, 0);
+  if (base + lane < n) {
+    const GeomRec* r = geom + id;
+    float4 q0 = r->q0, q1 = r->q1;
+    const float4 q2 = r->q2;
+    to_exp2_domain(q0, q1);
+    g = q0; g2 = make_float2(q1.x, q1.y); c = make_float4(q1.z, q1.w, q2.x, q2.y);
+  }
+}
+
 template <bool kExtra>
-__global__ __launch_bounds__(64) void k_blend_fwd(const Params p) {
-  __shared__ float4 sb[2][3][64];
+__global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
+  __shared__ float sX[3][kFB][64];
+  __shared__ float4 sGeo[4][kFB];   // x, y, a2, b2
+  __shared__ float2 sGeo2[4][kFB];  // c2, opacity
+  __shared__ float4 sCol[4][kFB];   // r, g, b, extra
+  __shared__ float sPart[kFwdHelpers][4][64];
+  __shared__ uint32_t sLast[kFwdHelpers][64];
+  __shared__ int sStop;
   const Grid& g = p.g;
-  const int lane = threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v = blockIdx.y;
   const int t = xcd_remap(blockIdx.x, g.T);
   const int tx = t % g.sgx, ty = t / g.sgx;
@@ -820,225 +855,349 @@ __global__ __launch_bounds__(64) void k_blend_fwd(const Params p) {
   const float pxf = (float)pxi, pyf = (float)pyi;
   const uint2 rg = p.ranges[(size_t)v * g.T + t];
   const uint32_t n = rg.y - rg.x;
+  const uint32_t nbat = (n + kFB - 1) / kFB;
   const uint32_t* plist = p.point_list + rg.x;
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
-  const float4 zero4 = make_float4(0, 0, 0, 0);
 
-  float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;
+  float T = 1.f, Tf = inside ? 1.f : 0.f;      // scan wave: reported / free-running transmittance
+  float C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;  // helper waves: partial colour sums
   uint32_t last = 0, consumed = 0;
-  bool done = !inside;
-  if (n > 0 && !__all(done)) {
-    // prologue: batch 0 -> LDS[0]; indices of batch 1 in flight
-    float4 r0 = zero4, r1 = zero4, r2 = zero4;
-    if ((uint32_t)lane < n) {
-      const GeomRec* r = geom + plist[lane];
-      r0 = r->q0; r1 = r->q1; r2 = r->q2;
+  if (threadIdx.x == 0) sStop = 0;
+  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  unsigned long long tm0 = 0, tm1 = 0, rt0 = 0;
+  if (dbg) { tm0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+
+  auto eval = [&](uint32_t b) {  // stage E for this helper's entries of batch b
+    const int gb = b & 3, xb = b % 3, e0 = (wave - 1) * kFE;
+#pragma unroll 4
+    for (int e = e0; e < e0 + kFE; ++e) {
+      const float4 a = sGeo[gb][e];
+      const float2 a2 = sGeo2[gb][e];
+      const float dx = a.x - pxf, dy = a.y - pyf;
+      const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
+      const float alpha = fminf(0.99f, a2.y * __builtin_amdgcn_exp2f(p2));
+      const bool keep = !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
+      sX[xb][e][lane] = keep ? alpha : 0.f;
     }
-    uint32_t id1 = (64u + lane < n) ? plist[64 + lane] : 0u;
-    to_exp2_domain(r0, r1);
-    sb[0][0][lane] = r0; sb[0][1][lane] = r1; sb[0][2][lane] = r2;
+  };
+  auto accum = [&](uint32_t b) {  // stage A for this helper's entries of batch b
+    const int cb = b & 3, xb = b % 3, e0 = (wave - 1) * kFE;
+#pragma unroll 4
+    for (int e = e0; e < e0 + kFE; ++e) {
+      const float w = sX[xb][e][lane];
+      const float4 c = sCol[cb][e];
+      C0 = __builtin_fmaf(c.x, w, C0);
+      C1 = __builtin_fmaf(c.y, w, C1);
+      C2 = __builtin_fmaf(c.z, w, C2);
+      if (kExtra) E = __builtin_fmaf(c.w, w, E);
+      last = (w > 0.f) ? b * kFB + e + 1 : last;
+    }
+  };
+
+  uint32_t ib = 0;  // batch at which the loop stopped
+  if (nbat > 0) {
+    // ---- prologue: stage batches 0 (wave 1) and 1 (wave 2), evaluate batch 0
+    float4 sg = make_float4(0, 0, 0, 0), sc = sg;
+    float2 sg2 = make_float2(0, 0);
+    uint32_t id_next = 0;
+    if (lane < kFB && (wave == 1 || (wave == 2 && nbat > 1))) {
+      const uint32_t b = (uint32_t)(wave - 1);
+      const uint32_t id = (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u;
+      stage_batch(geom, plist, n, b * kFB, lane, id, sg, sg2, sc);
+      sGeo[b][lane] = sg; sGeo2[b][lane] = sg2; sCol[b][lane] = sc;
+      if (wave == 1) id_next = (2u * kFB + lane < n) ? plist[2 * kFB + lane] : 0u;
+    }
     __syncthreads();
-    for (uint32_t base = 0, b = 0; base < n; base += 64, ++b) {
-      const int cur = b & 1;
-      const uint32_t nb = min(64u, n - base);
-      const bool has_next = base + 64 < n;
-      r0 = zero4; r1 = zero4; r2 = zero4;
-      if (has_next && base + 64 + lane < n) {
-        const GeomRec* r = geom + id1;
-        r0 = r->q0; r1 = r->q1; r2 = r->q2;
-      }
-      const uint32_t id2 = (base + 128 + lane < n) ? plist[base + 128 + lane] : 0u;
-      // LDS reads run one group of 4 splats ahead of the arithmetic
-      float4 na[4], nq[4], nc[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { na[u] = sb[cur][0][u]; nq[u] = sb[cur][1][u]; nc[u] = sb[cur][2][u]; }
-      for (uint32_t j = 0; j < nb; j += 4) {
-        if (__all(done)) break;
-        consumed = base + j + 4;
-        float4 a[4], bq[4], c[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = na[u]; bq[u] = nq[u]; c[u] = nc[u]; }
-        const uint32_t jn = (j + 4 < 64u) ? j + 4 : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { na[u] = sb[cur][0][jn + u]; nq[u] = sb[cur][1][jn + u]; nc[u] = sb[cur][2][jn + u]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float dx = a[u].x - pxf, dy = a[u].y - pyf;
-          const float p2 = splat_p2(a[u].z, a[u].w, bq[u].x, dx, dy);
-          const float alpha = fminf(0.99f, bq[u].y * __builtin_amdgcn_exp2f(p2));
-          const float test_T = T * (1.f - alpha);
-          const bool ok = !done && !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
-          const bool stop = ok && (test_T < 0.0001f);
-          const bool acc = ok && !stop;
-          done = done || stop;
-          const float w = acc ? alpha * T : 0.f;
-          C0 = __builtin_fmaf(bq[u].z, w, C0);
-          C1 = __builtin_fmaf(bq[u].w, w, C1);
-          C2 = __builtin_fmaf(c[u].x, w, C2);
-          if (kExtra) E = __builtin_fmaf(c[u].y, w, E);
-          T = acc ? test_T : T;
-          last = acc ? base + j + u + 1 : last;
+    if (wave >= 1) eval(0);
+    __syncthreads();
+    if (dbg) tm1 = __builtin_readcyclecounter();
+    // ---- steady state, iteration i: S(i) | A(i-1), E(i+1), gather(i+2)
+    for (uint32_t i = 0; i < nbat; ++i) {
+      ib = i;
+      if (wave == 0) {
+        const int xb = i % 3;
+#pragma unroll 4
+        for (int e = 0; e < kFB; ++e) {
+          const float al = sX[xb][e][lane];
+          const float Tn = Tf * (1.f - al);
+          const bool alive = !(Tn < 0.0001f);
+          sX[xb][e][lane] = alive ? al * Tf : 0.f;
+          T = alive ? Tn : T;
+          Tf = Tn;
+        }
+        consumed = (i + 1) * kFB;
+        const bool all_dead = __all(Tf < 0.0001f);
+        if (lane == 0 && (all_dead || i + 1 == nbat)) sStop = (int)(i + 1);  // stamped with the iteration
+      } else {
+        const uint32_t bs = i + 2;
+        const bool do_stage = (wave == 1) && (bs < nbat) && (lane < kFB);
+        if (do_stage) {
+          stage_batch(geom, plist, n, bs * kFB, lane, id_next, sg, sg2, sc);  // global gather in flight
+          id_next = ((bs + 1) * kFB + lane < n) ? plist[(bs + 1) * kFB + lane] : 0u;
+        }
+        if (i >= 1) accum(i - 1);
+        if (i + 1 < nbat) eval(i + 1);
+        if (do_stage) {
+          const int sb = bs & 3;
+          sGeo[sb][lane] = sg; sGeo2[sb][lane] = sg2; sCol[sb][lane] = sc;
         }
       }
-      if (!has_next || __all(done)) break;
-      to_exp2_domain(r0, r1);
-      sb[cur ^ 1][0][lane] = r0; sb[cur ^ 1][1][lane] = r1; sb[cur ^ 1][2][lane] = r2;
       __syncthreads();
-      id1 = id2;
+      if (sStop == (int)(i + 1)) break;  // a later iteration's stamp can never equal this one's
+    }
+    if (wave >= 1) accum(ib);  // drain: weights of the last scanned batch
+  }
+  if (wave >= 1) {
+    sPart[wave - 1][0][lane] = C0; sPart[wave - 1][1][lane] = C1; sPart[wave - 1][2][lane] = C2;
+    if (kExtra) sPart[wave - 1][3][lane] = E;
+    sLast[wave - 1][lane] = last;
+  }
+  __syncthreads();
+  if (dbg && threadIdx.x == 0) {
+    unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
+    o[0] = tm0; o[1] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(tm1 - tm0); o[2] = __builtin_readcyclecounter();
+    o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
+  }
+  if (wave == 0) {
+    if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
+    if (inside) {
+#pragma unroll
+      for (int h = 0; h < kFwdHelpers; ++h) {
+        C0 += sPart[h][0][lane]; C1 += sPart[h][1][lane]; C2 += sPart[h][2][lane];
+        if (kExtra) E += sPart[h][3][lane];
+        last = max(last, sLast[h][lane]);
+      }
+      const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
+      const GsrView& cam = p.views[v];
+      p.final_T[(size_t)v * HW + pix] = T;
+      p.n_contrib[(size_t)v * HW + pix] = last;
+      float* oc = p.out_color + (size_t)v * 3 * HW;
+      oc[pix] = C0 + T * cam.bg[0];
+      oc[HW + pix] = C1 + T * cam.bg[1];
+      oc[2 * HW + pix] = C2 + T * cam.bg[2];
+      if (kExtra) p.out_extra[(size_t)v * HW + pix] = E;
     }
   }
-  if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
-  if (inside) {
-    const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
-    const GsrView& cam = p.views[v];
-    p.final_T[(size_t)v * HW + pix] = T;
-    p.n_contrib[(size_t)v * HW + pix] = last;
-    float* oc = p.out_color + (size_t)v * 3 * HW;
-    oc[pix] = C0 + T * cam.bg[0];
-    oc[HW + pix] = C1 + T * cam.bg[1];
-    oc[2 * HW + pix] = C2 + T * cam.bg[2];
-    if (kExtra) p.out_extra[(size_t)v * HW + pix] = E;
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// B1: backward blend, one wavefront per 8x8 tile, back-to-front replay ([EXT] backward.cu renderCUDA;
-// oracle blend_backward).  Per splat the 64 pixel gradients are reduced across the wavefront with DPP row
-// shifts / row broadcasts (no LDS traffic) and one lane per value issues the atomic into the per-(view,
-// Gaussian) screen-space accumulator:
-//   scratch[.. * 12 + {0,1: dmean2D  2,3,4: dconic  5: dopacity  6,7,8: dcolor  9: dextra}]
-// Record gathers are double-buffered like the forward blend.
+// B1: backward blend ([EXT] backward.cu renderCUDA; oracle blend_backward).  One workgroup of four wavefronts per
+// 8x8 tile, specialised and pipelined over batches of kBB list entries walked back to front:
+//   helpers (waves 1-3), stage E, lane = pixel : alpha (0 unless the forward pass blended this splat at this
+//            pixel: not skipped and index < the pixel's last contributor) and cg = colour . dL/dpixel  -> LDS
+//   chain   (wave 0),    stage C, lane = pixel : the sequential replay, in closed form so that it is 8 VALU ops:
+//              r = 1/(1-alpha);  T <- T r  (transmittance in front of the splat);  w = alpha T;
+//              dL/dalpha = T cg - r (Bg + T_final bg.g);   Bg <- Bg + w cg
+//            where Bg = sum over deeper splats of w cg.  This equals the reference's accum_rec recurrence:
+//            accum_rec_j = B_j / T_{j+1} with B_j = sum_{m>j} c_m w_m (proof in DESIGN.md).  Overwrites alpha with w
+//            and cg with dL/dalpha in place.
+//   helpers,             stage R, lane = (entry row, 4 pixels): per-splat gradients.  Each 16-lane DPP row owns one
+//            list entry, each lane accumulates 4 pixels in registers, a 4-step row_ror all-reduce finishes the sum and
+//            ONE atomic instruction (40 active lanes) adds 4 splats x 10 values into the per-(view,Gaussian)
+//            screen-space accumulator:
+//              scratch[.. * 12 + {0,1: dmean2D  2,3,4: dconic  5: dopacity  6,7,8: dcolor  9: dextra}]
+//   wave 1 also gathers the splat records two batches ahead.
+// A helper evaluates and reduces the SAME entries (groups h and h+3 of a batch), so E of the next batch may reuse the
+// LDS slot its own R has just consumed: one barrier per batch.
 // ------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK, int BANK_MASK>
-__device__ __forceinline__ float dpp_add(float acc, float src) {
-  return acc + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(src), CTRL, ROW_MASK, BANK_MASK, false));
+constexpr int kBB = 24;  // list entries per batch = 6 groups of 4; helper h owns groups h and h + 3
+constexpr int kBwdThreads = 256;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
-// Sum over the 64 lanes; the total is returned wave-uniform (read from lane 63).
-__device__ __forceinline__ float wave_sum_uniform(float v) {
-#if defined(GSR_REDUCE_SHFL)
-  return wave_sum(v);
-#else
-  float a = dpp_add<0x111, 0xf, 0xf>(v, v);  // + row_shr:1
-  a = dpp_add<0x112, 0xf, 0xf>(a, v);        // + row_shr:2
-  a = dpp_add<0x113, 0xf, 0xf>(a, v);        // + row_shr:3  -> sums of 4
-  a = dpp_add<0x114, 0xf, 0xe>(a, a);        // + row_shr:4, banks 1-3 -> sums of 8
-  a = dpp_add<0x118, 0xf, 0xc>(a, a);        // + row_shr:8, banks 2-3 -> lane 15 of each row = row sum
-  a = dpp_add<0x142, 0xa, 0xf>(a, a);        // + row_bcast:15 into rows 1,3
-  a = dpp_add<0x143, 0xc, 0xf>(a, a);        // + row_bcast:31 into rows 2,3 -> lane 63 = total
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a), 63));
-#endif
+// Sum over the 16 lanes of a DPP row, result in every lane of the row.
+__device__ __forceinline__ float row_allreduce(float v) {
+  v = dpp_row_add<0x128>(v);  // row_ror:8
+  v = dpp_row_add<0x124>(v);  // row_ror:4
+  v = dpp_row_add<0x122>(v);  // row_ror:2
+  v = dpp_row_add<0x121>(v);  // row_ror:1
+  return v;
 }
 
-__global__ __launch_bounds__(64) void k_blend_bwd(const Params p) {
-  __shared__ float4 sb[2][3][64];
-  __shared__ uint32_t sid[2][64];
+__global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
+  __shared__ __attribute__((aligned(16))) float sA[2][kBB][64];  // E: alpha -> C: weight w
+  __shared__ __attribute__((aligned(16))) float sD[2][kBB][64];  // E: cg    -> C: dL/dalpha
+  __shared__ float4 sGeo[4][kBB];   // x, y, a2, b2
+  __shared__ float4 sGeo2[4][kBB];  // c2, opacity, id bits, 0
+  __shared__ float4 sCol[4][kBB];   // r, g, b, extra
   const Grid& g = p.g;
-  const int lane = threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v = blockIdx.y;
   const int t = xcd_remap(blockIdx.x, g.T);
   const int tx = t % g.sgx, ty = t / g.sgx;
-  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
-  const bool inside = pxi < g.W && pyi < g.H;
-  const float pxf = (float)pxi, pyf = (float)pyi;
   const uint2 rg = p.ranges[(size_t)v * g.T + t];
-  const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
+  const uint32_t n = rg.y - rg.x;
+  const size_t HW = (size_t)g.H * g.W;
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
   const uint32_t* plist = p.point_list + rg.x;
   float* scratch = p.scratch + (size_t)v * p.d.num_gaussians * GSR_SCREEN_GRAD_FLOATS;
   const GsrView& cam = p.views[v];
   const bool has_extra = p.d.has_extra != 0 && p.dL_dextra_img != nullptr;
-  const float4 zero4 = make_float4(0, 0, 0, 0);
+  const float* dcol = p.dL_dcolor + (size_t)v * 3 * HW;
+  const float* dext = has_extra ? p.dL_dextra_img + (size_t)v * HW : nullptr;
 
-  const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
+  // ---- lane = pixel view (chain, stage E)
+  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
+  const bool inside = pxi < g.W && pyi < g.H;
+  const float pxf = (float)pxi, pyf = (float)pyi;
+  const size_t pix = (size_t)pyi * g.W + pxi;
   const uint32_t my_last = inside ? p.n_contrib[(size_t)v * HW + pix] : 0u;
+  const uint32_t nmax = wave_max_u32(my_last);
+  if (nmax == 0) return;  // uniform over the workgroup: every wave holds the same 64 pixels
   float g0 = 0, g1 = 0, g2 = 0, ge = 0;
   if (inside) {
-    const float* dc = p.dL_dcolor + (size_t)v * 3 * HW;
-    g0 = dc[pix]; g1 = dc[HW + pix]; g2 = dc[2 * HW + pix];
-    if (has_extra) ge = p.dL_dextra_img[(size_t)v * HW + pix];
+    g0 = dcol[pix]; g1 = dcol[HW + pix]; g2 = dcol[2 * HW + pix];
+    if (has_extra) ge = dext[pix];
   }
-  const float bg_dot = cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2;
-  const float ddelx_dx = 0.5f * (float)g.W, ddely_dy = 0.5f * (float)g.H;
-  const uint32_t nmax = wave_max_u32(my_last);
-  if (nmax == 0) return;
+  // ---- lane = (entry row, 4 pixels) view (stage R)
+  const int row = lane >> 4, li = lane & 15;
+  const int rpx0 = tx * 8 + 4 * (li & 1), rpy = ty * 8 + (li >> 1);
+  float rg0[4], rg1[4], rg2[4], rge[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = (rpx0 + k < g.W) && (rpy < g.H) && wave >= 1;
+    const size_t q = (size_t)rpy * g.W + rpx0 + k;
+    rg0[k] = in ? dcol[q] : 0.f; rg1[k] = in ? dcol[HW + q] : 0.f; rg2[k] = in ? dcol[2 * HW + q] : 0.f;
+    rge[k] = (in && has_extra) ? dext[q] : 0.f;
+  }
+  const float hW = 0.5f * (float)g.W, hH = 0.5f * (float)g.H;
 
-  float T = T_final, last_alpha = 0.f;
-  float ar0 = 0, ar1 = 0, ar2 = 0, are = 0, lc0 = 0, lc1 = 0, lc2 = 0, lce = 0;
-  // batches are visited from the last (partial) one down to batch 0
-  const int top = (int)((nmax - 1) & ~63u);
-  float4 r0 = zero4, r1 = zero4, r2 = zero4;
-  uint32_t idc = 0;
-  if ((uint32_t)(top + lane) < nmax) {
-    idc = plist[top + lane];
-    const GeomRec* r = geom + idc;
-    r0 = r->q0; r1 = r->q1; r2 = r->q2;
-  }
-  uint32_t id1 = (top >= 64) ? plist[top - 64 + lane] : 0u;  // batch below is always full
-  to_exp2_domain(r0, r1);
-  sb[0][0][lane] = r0; sb[0][1][lane] = r1; sb[0][2][lane] = r2; sid[0][lane] = idc;
-  __syncthreads();
-  for (int base = top, b = 0; base >= 0; base -= 64, ++b) {
-    const int cur = b & 1;
-    const int nb = min(64, (int)nmax - base);
-    const bool has_next = base >= 64;
-    if (has_next) {
-      const GeomRec* r = geom + id1;
-      r0 = r->q0; r1 = r->q1; r2 = r->q2;
+  const uint32_t nbat = (nmax + kBB - 1) / kBB;
+  // iteration `it` works on batch nbat-1-it; ring slots are indexed by the iteration number
+  auto batch_of = [&](uint32_t it) { return nbat - 1 - it; };
+
+  auto stage = [&](uint32_t it, float4& sg, float4& sg2, float4& sc, uint32_t id) {  // lane = entry; issues the gather
+    sg = make_float4(0, 0, 0, 0); sg2 = sg; sc = sg;
+    const uint32_t idx = batch_of(it) * kBB + lane;
+    if (lane < kBB && idx < nmax) {
+      const GeomRec* r = geom + id;
+      float4 q0 = r->q0, q1 = r->q1;
+      const float4 q2 = r->q2;
+      to_exp2_domain(q0, q1);
+      sg = q0; sg2 = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f); sc = make_float4(q1.z, q1.w, q2.x, q2.y);
     }
-    const uint32_t id2 = (base >= 128) ? plist[base - 128 + lane] : 0u;
-    for (int j = nb - 1; j >= 0; --j) {
-      const float4 a = sb[cur][0][j], bq = sb[cur][1][j], c = sb[cur][2][j];
-      const uint32_t idx = (uint32_t)(base + j);
+  };
+  auto load_ids = [&](uint32_t it) -> uint32_t {
+    if (it >= nbat) return 0u;
+    const uint32_t idx = batch_of(it) * kBB + lane;
+    return (lane < kBB && idx < nmax) ? plist[idx] : 0u;
+  };
+  auto eval = [&](uint32_t it) {  // stage E for this helper's 8 entries
+    const int ring = it & 3, slot = it & 1;
+    const uint32_t base = batch_of(it) * kBB;
+#pragma unroll 2
+    for (int q = 0; q < 8; ++q) {
+      const int e = 4 * ((wave - 1) + 3 * (q >> 2)) + (q & 3);
+      const float4 a = sGeo[ring][e], a2 = sGeo2[ring][e], c = sCol[ring][e];
       const float dx = a.x - pxf, dy = a.y - pyf;
-      const float p2 = splat_p2(a.z, a.w, bq.x, dx, dy);
-      const float G = __builtin_amdgcn_exp2f(p2);
-      const float alpha = fminf(0.99f, bq.y * G);
-      const bool ok = (idx < my_last) && !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
-      if (!__any(ok)) continue;
+      const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
+      const float alpha = fminf(0.99f, a2.y * __builtin_amdgcn_exp2f(p2));
+      const bool contrib = (base + e < my_last) && !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
+      float cg = c.x * g0;
+      cg = __builtin_fmaf(c.y, g1, cg);
+      cg = __builtin_fmaf(c.z, g2, cg);
+      cg = __builtin_fmaf(c.w, ge, cg);
+      sA[slot][e][lane] = contrib ? alpha : 0.f;
+      sD[slot][e][lane] = cg;
+    }
+  };
+  auto reduce = [&](uint32_t it) {  // stage R for this helper's 2 groups of 4 entries
+    const int ring = it & 3, slot = it & 1;
+#pragma unroll 1
+    for (int gq = 0; gq < 2; ++gq) {
+      const int e = 4 * ((wave - 1) + 3 * gq) + row;
+      const float4 w4 = *reinterpret_cast<const float4*>(&sA[slot][e][4 * li]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&sD[slot][e][4 * li]);
+      const float4 a = sGeo[ring][e], a2 = sGeo2[ring][e];
+      const float wk[4] = {w4.x, w4.y, w4.z, w4.w}, dk[4] = {d4.x, d4.y, d4.z, d4.w};
       float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
-      if (ok) {
-        T = T / (1.f - alpha);
-        const float dchannel_dcolor = alpha * T;
-        float dL_dalpha = 0.f;
-        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = bq.z; dL_dalpha += (bq.z - ar0) * g0; v6 = dchannel_dcolor * g0;
-        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = bq.w; dL_dalpha += (bq.w - ar1) * g1; v7 = dchannel_dcolor * g1;
-        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = c.x; dL_dalpha += (c.x - ar2) * g2; v8 = dchannel_dcolor * g2;
-        if (has_extra) {
-          are = last_alpha * lce + (1.f - last_alpha) * are; lce = c.y; dL_dalpha += (c.y - are) * ge; v9 = dchannel_dcolor * ge;
-        }
-        dL_dalpha *= T;
-        last_alpha = alpha;
-        dL_dalpha += (-T_final / (1.f - alpha)) * bg_dot;
-        const float dL_dG = bq.y * dL_dalpha;
+      bool any_valid = false;
+      const float dy = a.y - (float)rpy;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool valid = wk[k] > 0.f;
+        any_valid = any_valid || valid;
+        const float dx = a.x - (float)(rpx0 + k);
+        const float G = __builtin_amdgcn_exp2f(splat_p2(a.z, a.w, a2.x, dx, dy));
+        const float dl = valid ? dk[k] : 0.f;
+        const float dL_dG = a2.y * dl;
         const float gdx = G * dx, gdy = G * dy;
         // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
         const float dG_ddelx = kLn2 * (2.f * a.z * gdx + a.w * gdy);
-        const float dG_ddely = kLn2 * (2.f * bq.x * gdy + a.w * gdx);
-        v0 = dL_dG * dG_ddelx * ddelx_dx;
-        v1 = dL_dG * dG_ddely * ddely_dy;
-        v2 = -0.5f * gdx * dx * dL_dG;
-        v3 = -0.5f * gdx * dy * dL_dG;
-        v4 = -0.5f * gdy * dy * dL_dG;
-        v5 = G * dL_dalpha;
+        const float dG_ddely = kLn2 * (2.f * a2.x * gdy + a.w * gdx);
+        v0 = __builtin_fmaf(dL_dG * dG_ddelx, hW, v0);
+        v1 = __builtin_fmaf(dL_dG * dG_ddely, hH, v1);
+        const float hg = -0.5f * dL_dG;
+        v2 = __builtin_fmaf(hg * gdx, dx, v2);
+        v3 = __builtin_fmaf(hg * gdx, dy, v3);
+        v4 = __builtin_fmaf(hg * gdy, dy, v4);
+        v5 = __builtin_fmaf(G, dl, v5);
+        v6 = __builtin_fmaf(wk[k], rg0[k], v6);
+        v7 = __builtin_fmaf(wk[k], rg1[k], v7);
+        v8 = __builtin_fmaf(wk[k], rg2[k], v8);
+        v9 = __builtin_fmaf(wk[k], rge[k], v9);
       }
-      v0 = wave_sum_uniform(v0); v1 = wave_sum_uniform(v1); v2 = wave_sum_uniform(v2); v3 = wave_sum_uniform(v3);
-      v4 = wave_sum_uniform(v4); v5 = wave_sum_uniform(v5); v6 = wave_sum_uniform(v6); v7 = wave_sum_uniform(v7);
-      v8 = wave_sum_uniform(v8);
-      if (has_extra) v9 = wave_sum_uniform(v9);
-      if (lane < 10) {
+      const unsigned long long bal = __ballot(any_valid);
+      if (((bal >> (16 * row)) & 0xffffull) == 0ull) continue;  // row-uniform: nothing blended from this splat in this tile
+      v0 = row_allreduce(v0); v1 = row_allreduce(v1); v2 = row_allreduce(v2); v3 = row_allreduce(v3); v4 = row_allreduce(v4);
+      v5 = row_allreduce(v5); v6 = row_allreduce(v6); v7 = row_allreduce(v7); v8 = row_allreduce(v8);
+      if (has_extra) v9 = row_allreduce(v9);
+      if (li < 10) {
         float val = v0;
-        val = lane == 1 ? v1 : val; val = lane == 2 ? v2 : val; val = lane == 3 ? v3 : val; val = lane == 4 ? v4 : val;
-        val = lane == 5 ? v5 : val; val = lane == 6 ? v6 : val; val = lane == 7 ? v7 : val; val = lane == 8 ? v8 : val;
-        val = lane == 9 ? v9 : val;
-        unsafeAtomicAdd(scratch + (size_t)sid[cur][j] * GSR_SCREEN_GRAD_FLOATS + lane, val);
+        val = li == 1 ? v1 : val; val = li == 2 ? v2 : val; val = li == 3 ? v3 : val; val = li == 4 ? v4 : val;
+        val = li == 5 ? v5 : val; val = li == 6 ? v6 : val; val = li == 7 ? v7 : val; val = li == 8 ? v8 : val;
+        val = li == 9 ? v9 : val;
+        unsafeAtomicAdd(scratch + (size_t)__float_as_uint(a2.z) * GSR_SCREEN_GRAD_FLOATS + li, val);
       }
     }
-    if (!has_next) break;
-    to_exp2_domain(r0, r1);
-    sb[cur ^ 1][0][lane] = r0; sb[cur ^ 1][1][lane] = r1; sb[cur ^ 1][2][lane] = r2; sid[cur ^ 1][lane] = id1;
-    __syncthreads();
-    id1 = id2;
+  };
+
+  // ---- prologue: stage iterations 0 (wave 1) and 1 (wave 2), evaluate iteration 0
+  float4 sg, sg2, sc;
+  uint32_t id_next = 0;
+  if (wave == 1 || (wave == 2 && nbat > 1)) {
+    const uint32_t it0 = (uint32_t)(wave - 1);
+    stage(it0, sg, sg2, sc, load_ids(it0));
+    if (lane < kBB) { sGeo[it0][lane] = sg; sGeo2[it0][lane] = sg2; sCol[it0][lane] = sc; }
+    if (wave == 1) id_next = load_ids(2);
   }
+  __syncthreads();
+  if (wave >= 1) eval(0);
+  __syncthreads();
+  const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
+  float T = T_final;
+  float BgK = T_final * (cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2);  // Bg + T_final bg.g  (extra channel has bg 0)
+  for (uint32_t it = 0; it < nbat; ++it) {
+    if (wave == 0) {
+      const int slot = it & 1;
+#pragma unroll 4
+      for (int e = kBB - 1; e >= 0; --e) {
+        const float al = sA[slot][e][lane], cg = sD[slot][e][lane];
+        const float r = __builtin_amdgcn_rcpf(1.f - al);
+        T = T * r;
+        const float w = al * T;
+        sD[slot][e][lane] = __builtin_fmaf(T, cg, -(BgK * r));
+        sA[slot][e][lane] = w;
+        BgK = __builtin_fmaf(w, cg, BgK);
+      }
+    } else {
+      const bool do_stage = (wave == 1) && (it + 2 < nbat);
+      if (do_stage) {
+        stage(it + 2, sg, sg2, sc, id_next);  // global gather in flight
+        id_next = load_ids(it + 3);
+      }
+      if (it >= 1) reduce(it - 1);
+      if (it + 1 < nbat) eval(it + 1);
+      if (do_stage && lane < kBB) {
+        const int ring = (it + 2) & 3;
+        sGeo[ring][lane] = sg; sGeo2[ring][lane] = sg2; sCol[ring][lane] = sc;
+      }
+    }
+    __syncthreads();
+  }
+  if (wave >= 1) reduce(nbat - 1);  // drain
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1318,8 +1477,8 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   GSR_MARK();
   hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
   GSR_MARK();
-  if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
-  else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
   GSR_MARK();
 #undef GSR_MARK
   GSR_CHECK(hipGetLastError());
@@ -1380,7 +1539,7 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   int e = 0;
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipMemsetAsync(scratch, 0, V * N * GSR_SCREEN_GRAD_FLOATS * sizeof(float), st));
-  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(64), 0, st, p);
+  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)2 * 64 * ldstride * sizeof(float) : 0;

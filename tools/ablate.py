@@ -22,6 +22,31 @@ def main():
     vb = synthetic.scene_viewbuf(sc).to(dev)
     cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False)
     be = HipBackend()
+    q0 = lambda x: [round(v, 2) for v in torch.quantile(x, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)).tolist()]
+    # per-tile cycle stamps of the forward blend
+    plan = be.make_plan(cfg, dev, capacity=8 * n)
+    plan["dims"].flags = 0x2000
+    for _ in range(3):
+        be.run_forward(plan, vb, means, cov6, opac, shs)
+    torch.cuda.synchronize()
+    lay = be.workspace_layout(plan["dims"])
+    st = plan["bin"][lay["keys"]: lay["keys"] + 1024 * 32].view(torch.int64).reshape(1024, 4).cpu().double()
+    walked = plan["bin"][lay["tile_total"]: lay["tile_total"] + 1024 * 4].view(torch.int32).cpu().double()
+    raw = plan["bin"][lay["keys"]: lay["keys"] + 1024 * 32].view(torch.int64).reshape(1024, 4).cpu()
+    rs = ((raw[:, 3] >> 32) & 0xffffffff).double() * 0.01  # us
+    re = (raw[:, 3] & 0xffffffff).double() * 0.01
+    print("blend_fwd wall clock (us): start skew", q0(rs - rs.min()), "| end", q0(re - rs.min()), "| duration", q0(re - rs), flush=True)
+    bid = (raw[:, 1] >> 32) & 0xffffffff
+    late = (rs - rs.min()) > 5.0
+    print("late tiles:", int(late.sum()), "of 1024; blockIdx of late tiles: min", int(bid[late].min()) if late.any() else -1,
+          "max", int(bid[late].max()) if late.any() else -1, "| blockIdx of on-time tiles: max", int(bid[~late].max()), flush=True)
+    st[:, 1] = st[:, 0] + (raw[:, 1] & 0xffffffff).double()
+    t0 = st[:, 0] - st[:, 0].min()
+    dur = st[:, 2] - st[:, 0]
+    pro = st[:, 1] - st[:, 0]
+    q = lambda x: [round(v, 0) for v in torch.quantile(x, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)).tolist()]
+    print("blend_fwd per-tile (cycle counter ticks): start skew", q(t0), "| prologue", q(pro), "| total", q(dur),
+          "| ticks per walked entry", q((dur - pro) / walked.clamp(min=1)), "| end-start span", (st[:, 2].max() - st[:, 0].min()).item(), flush=True)
     for name, fl in FLAGS.items():
         plan = be.make_plan(cfg, dev, capacity=8 * n)
         plan["dims"].flags = fl
