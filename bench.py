@@ -188,12 +188,13 @@ def main():
                 acc[k_] = acc.get(k_, 0.0) + v_ / reps
         nv, r16 = reference_rect_stats(plan, cfg)
         ab = algorithmic_bytes(n, nv, r16, H * W, D_SH)
-        stage_bytes = {"preprocess": ab["preprocess"], "tile_scan": 0, "emit": ab["binning"] // 2, "sort": ab["binning"] // 2,
-                       "blend": ab["blend"]}
+        kc = 12 * D_SH
+        stage_bytes = {"preprocess": 12 * n + nv * 28 + nv * 28, "color": nv * kc + nv * 12, "tile_scan": 0,
+                       "emit": ab["binning"] // 2, "sort": ab["binning"] // 2, "blend": ab["blend"]}
         dom = max(acc, key=acc.get)
         chain_ms = sum(acc.values())
         ach = stage_bytes[dom] / (acc[dom] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": {"preprocess": "gsr::k_preprocess", "tile_scan": "gsr::k_tile_scan",
+        result["roofline"] = {"bound": "hbm", "kernel": {"preprocess": "gsr::k_preprocess", "color": "gsr::k_color", "tile_scan": "gsr::k_tile_scan",
                                                          "emit": "gsr::k_emit", "sort": "gsr::k_sort_tiles",
                                                          "blend": "gsr::k_blend_fwd"}[dom],
                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,

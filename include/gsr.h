@@ -16,7 +16,8 @@
  *
  * Conventions (all pointers are DEVICE pointers owned by the caller unless noted; the library
  * allocates nothing persistent, enqueues all work on `stream`, never synchronises the host, never
- * throws; every entry point returns GSR_OK or a negative error code):
+ * throws; every entry point returns GSR_OK or a negative error code.  gsr_forward forks its SH->colour kernel onto a
+ * per-thread internal side stream and joins it before the blend - a HIP-graph-capturable pattern):
  *   means     (num_sets, N, 3)   fp32 world-space centres                     (means3D)
  *   cov6      (num_sets, N, 6)   fp32 xx,xy,xz,yy,yz,zz                       (cov3D_precomp)
  *   opacities (num_sets, N)      fp32 in (0,1)
@@ -41,6 +42,11 @@ extern "C" {
 #define GSR_ERR_LAUNCH (-2)
 #define GSR_ERR_UNSUPPORTED (-3)
 #define GSR_ABI_VERSION 1
+/* GsrDims.flags input-layout bits: the arrays PF3plat's `Gaussians` record carries (src/model/types.py:7-18) can be passed
+ * as they are, with no re-layout copy (the reference wrapper makes two per call: cuda_splatting.py:75 and :115,123). */
+#define GSR_FLAG_SH_PLANAR 0x4  /* colors are (num_sets, N, 3, M) "harmonics" instead of (num_sets, N, M, 3); grads likewise */
+#define GSR_FLAG_COV_3X3 0x8    /* cov6 points at (num_sets, N, 3, 3) symmetric matrices; dL_dcov6 is (num_sets, N, 3, 3) with
+                                   the gradient on the upper triangle only (as the reference's triu gather yields) */
 /* GsrDims.flags bits >= 8 are measurement-only ablation switches (tools/ablate.py): they make results WRONG on purpose
  * to time a kernel without one of its parts.  Never set on the product path. */
 #define GSR_FLAG_ABLATE_NO_COUNT 0x100       /* preprocess: skip the per-tile pair counting atomics */
@@ -92,7 +98,7 @@ int gsr_abi_version(void);
 const char* gsr_build_info(void);
 
 /* Workspace sizes in bytes for a call with these dims (host-only arithmetic; no GPU needed).
- * geom: per-(view,Gaussian) projected records; bin: status + per-tile counters/ranges + pair
+ * geom: per-(view,Gaussian) projected records + colours; bin: status + per-tile counters/ranges + pair
  * lists (scales with pair_capacity); img: per-pixel final transmittance + contributor count.
  * Replaces upstream's geomBuffer/binningBuffer/imgBuffer resize callbacks. */
 int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes);
@@ -117,6 +123,13 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
                  void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
                  float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream);
 
+/* Camera set-up in one launch: fills views[0..num_views) from camera-to-world extrinsics (V,4,4), normalised intrinsics
+ * (V,3,3), near/far (V) and a background colour (background_stride 3: one per view; 0: one shared) - the arithmetic of the
+ * reference wrapper at cuda_splatting.py:64-71 and :80-87 (get_fov of projection.py:233-247, get_projection_matrix of
+ * cuda_splatting.py:17-44, extrinsics.inverse(), view @ proj).  scale_invariant != 0 applies the 1/near rescale. */
+int gsr_setup_views(int num_views, const float* extrinsics, const float* intrinsics, const float* near, const float* far,
+                    const float* background, int background_stride, int scale_invariant, GsrView* views, void* stream);
+
 /* Replaces upstream `_C.mark_visible` (GaussianRasterizer.markVisible): present[i] = 1 iff the
  * Gaussian passes the near-plane test of view 0 of its set (p_view.z > 0.2). */
 int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present,
@@ -124,9 +137,10 @@ int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* mea
 
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
- * Forward stages: 0 preprocess(+tile counts) 1 tile scans 2 emit 3 per-tile sort 4 blend.
+ * Forward stages: 0 preprocess (geometry + hit masks) 1 colour (SH; on the product path this one overlaps stages 0-4 on a
+ * side stream) 2 count + tile scans 3 emit 4 per-tile sort 5 blend.
  * Backward stages: 0 blend backward 1 preprocess backward. */
-#define GSR_FWD_STAGES 5
+#define GSR_FWD_STAGES 6
 #define GSR_BWD_STAGES 2
 int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
                         const float* opacities, const float* colors, const float* extra, float* out_color,

@@ -18,6 +18,8 @@ HEADER = os.path.join(REPO_ROOT, "include", "gsr.h")
 LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
 GSR_ABI_VERSION = 1
 SCREEN_GRAD_FLOATS = 12
+FLAG_SH_PLANAR = 0x4
+FLAG_COV_3X3 = 0x8
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
@@ -92,6 +94,8 @@ def load():
     lib.gsr_backward.argtypes = [dp] + [vp] * 19
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
+    lib.gsr_setup_views.restype = ctypes.c_int
+    lib.gsr_setup_views.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
     fp = ctypes.POINTER(ctypes.c_float)
     lib.gsr_forward_profile.restype = ctypes.c_int
     lib.gsr_forward_profile.argtypes = [dp] + [vp] * 13 + [fp]
@@ -105,7 +109,7 @@ def load():
 
 EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
-    "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile",
+    "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
 )
-FWD_STAGES = ("preprocess", "tile_scan", "emit", "sort", "blend")
+FWD_STAGES = ("preprocess", "color", "tile_scan", "emit", "sort", "blend")
 BWD_STAGES = ("blend_bwd", "preprocess_bwd")

@@ -37,10 +37,12 @@ constexpr float kNear = 0.2f;     // [EXT] auxiliary.h in_frustum: p_view.z <= 0
 
 struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one record = half a cache line
   float4 q0;  // x, y, conic a, conic b
-  float4 q1;  // conic c, opacity, r, g
-  float4 q2;  // b, extra, depth, bits(radius | clamped << 28)
+  float4 q1;  // conic c, opacity, -, -
+  float4 q2;  // -, extra, depth, bits(radius)
   float4 q3;  // bits: hit mask lo, hit mask hi, window origin (sx0 | sy0 << 12 | big << 31), depth
 };
+// The view-dependent colour lives in its own array (float4 per (view, Gaussian): r, g, b, bits(clamp mask)) because it is
+// produced by a separate kernel (k_color) that runs on a second stream concurrently with the geometry/binning chain.
 // q3: the 8x8 tiles this splat must be listed in, as a 64-bit mask over the 8x8-tile window whose top-left tile is
 // (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); computed once in preprocess, consumed by count and emit.
 // Footprints wider than 8 tiles set `big` and are re-derived from q0/q1 by the binning kernels.
@@ -61,6 +63,7 @@ __host__ __device__ inline Grid make_grid(int W, int H) {
 
 struct Layout {
   size_t geom_bytes, bin_bytes, img_bytes;
+  size_t o_rgbc;  // in geom
   size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list;  // in bin
   size_t o_finalT, o_ncontrib;                                   // in img
 };
@@ -72,7 +75,8 @@ static Layout make_layout(const GsrDims& d) {
   const Grid g = make_grid(d.width, d.height);
   const size_t V = d.num_views, N = d.num_gaussians, VT = V * (size_t)g.T;
   const size_t cap = d.pair_capacity > 0 ? (size_t)d.pair_capacity : 0;
-  L.geom_bytes = align_up(V * N * sizeof(GeomRec), 256);
+  L.o_rgbc = align_up(V * N * sizeof(GeomRec), 256);
+  L.geom_bytes = L.o_rgbc + align_up(V * N * sizeof(float4), 256);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
   const size_t rows = (N + kChunk - 1) / kChunk;
@@ -99,6 +103,7 @@ struct Params {
   float* out_extra;
   int32_t* radii;
   GeomRec* geom;
+  float4* rgbc;
   GsrStatus* status;
   uint32_t* counts;
   uint32_t* tile_total;
@@ -192,6 +197,21 @@ __device__ __forceinline__ void sh_visit(int deg, float x, float y, float z, F&&
   }
 }
 
+// Input layouts (GsrDims.flags): covariances as 6 floats xx,xy,xz,yy,yz,zz (the rasterizer's cov3D_precomp) or, with
+// GSR_FLAG_COV_3X3, as the full symmetric 3x3 PF3plat carries (only its upper triangle is read, and only the upper
+// triangle receives gradient - exactly what the reference's fancy-index gather does, cuda_splatting.py:115,123);
+// SH as (N, M, 3) (the rasterizer's shs) or, with GSR_FLAG_SH_PLANAR, as PF3plat's harmonics (N, 3, M).
+__device__ __forceinline__ void load_cov6(const float* cov, size_t gi, bool c9, float* o) {
+  if (c9) {
+    const float* c = cov + 9 * gi;
+    o[0] = c[0]; o[1] = c[1]; o[2] = c[2]; o[3] = c[4]; o[4] = c[5]; o[5] = c[8];
+  } else {
+    const float* c = cov + 6 * gi;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = c[k];
+  }
+}
+
 // EWA projection pieces shared by forward and backward ([EXT] forward.cu computeCov2D);
 // same expression trees as oracle cov2d_parts.
 struct Cov2D {
@@ -242,6 +262,7 @@ __device__ __forceinline__ void cov2d_parts(const float mx, const float my, cons
 // outside it alpha = o exp(-q/2) < 1/255 and the blend would skip the pixel anyway.
 struct Foot {
   float cx, cy, A, B, C, tau, nBiC, nBiA;  // nBiC = -B/C, nBiA = -B/A
+  float detc, hx, hy;                          // conic determinant, half extents of the ellipse {q <= tau}
   bool convex;
   int sx0, sx1, sy0, sy1;
 };
@@ -267,10 +288,13 @@ __device__ __forceinline__ Foot make_foot(float x, float y, float A, float B, fl
   f.tau = tau + 1e-4f * fabsf(tau) + 0.02f;  // margin >> fp32 error of the blend's own power evaluation
   const float detc = A * C - B * B;
   f.convex = (A > 0.f) && (C > 0.f) && (detc > 0.f) && (detc < 3.0e38f);
+  f.detc = detc; f.hx = 0.f; f.hy = 0.f;
   if (!(f.tau >= 0.f)) {  // opacity < 1/255 (or NaN): alpha < 1/255 everywhere
     f.sx1 = f.sx0; f.sy1 = f.sy0;
   } else if (f.convex) {
-    const float hx = sqrtf(f.tau * C / detc) + 0.5f, hy = sqrtf(f.tau * A / detc) + 0.5f;
+    f.detc = detc;
+    f.hx = sqrtf(f.tau * C / detc); f.hy = sqrtf(f.tau * A / detc);
+    const float hx = f.hx + 0.5f, hy = f.hy + 0.5f;
     f.sx0 = max(f.sx0, f2i_clamped(floorf((x - hx) * 0.125f)));
     f.sx1 = min(f.sx1, f2i_clamped(floorf((x + hx) * 0.125f)) + 1);
     f.sy0 = max(f.sy0, f2i_clamped(floorf((y - hy) * 0.125f)));
@@ -296,6 +320,29 @@ __device__ __forceinline__ bool subtile_hit(const Foot& f, int sx, int sy, const
   };
   const float qmin = fminf(fminf(qx(dx0), qx(dx1)), fminf(qy(dy0), qy(dy1)));
   return qmin <= f.tau;
+}
+
+// All hit tiles of one row of 8x8 tiles at once: the ellipse {q <= tau} cut by the row's band of pixel centres is convex,
+// so its x-projection is an interval [xl, xr]; xr(y) = (-B y + sqrt(A tau - det y^2)) / A is concave with its maximum at the
+// ellipse's rightmost point y_r = -B hx / C, hence the band maximum sits at y_r clamped into the band (xl symmetrically).
+// Returns the bits (relative to f.sx0) of the tiles whose pixel-centre span meets that interval - the same set the
+// per-tile box minimum (subtile_hit) accepts, at the cost of two square roots per row instead of ~50 ops per tile.
+__device__ __forceinline__ uint32_t row_hit_bits(const Foot& f, int sy, const Grid& g) {
+  const int w = f.sx1 - f.sx0;
+  const uint32_t all = w >= 32 ? 0xffffffffu : ((1u << w) - 1u);
+  if (!f.convex) return all;
+  const float ya = fmaxf((float)(8 * sy) - f.cy, -f.hy), yb = fminf((float)min(8 * sy + 7, g.H - 1) - f.cy, f.hy);
+  if (ya > yb) return 0u;
+  const float yrt = f.nBiC * f.hx;  // y of the rightmost point; the leftmost is at -yrt
+  const float yr = fminf(fmaxf(yrt, ya), yb), yl = fminf(fmaxf(-yrt, ya), yb);
+  const float inva = 1.f / f.A, at = f.A * f.tau;
+  const float xr = (-f.B * yr + sqrtf(fmaxf(0.f, at - f.detc * yr * yr))) * inva + 1e-3f;
+  const float xl = (-f.B * yl - sqrtf(fmaxf(0.f, at - f.detc * yl * yl))) * inva - 1e-3f;
+  const int lo = max(f.sx0, f2i_clamped(ceilf((xl + f.cx - 7.f) * 0.125f)));
+  const int hi = min(f.sx1 - 1, f2i_clamped(floorf((xr + f.cx) * 0.125f)));
+  if (hi < lo) return 0u;
+  const int n = hi - lo + 1;
+  return (n >= 32 ? 0xffffffffu : ((1u << n) - 1u)) << (lo - f.sx0);
 }
 
 // Wave-cooperative copy of `cnt` rows of `rowf` floats from global to LDS (row stride ldstride floats).
@@ -335,53 +382,37 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: preprocess — projection, EWA covariance, conic, radius, SH -> RGB ([EXT] forward.cu preprocessCUDA;
-// oracle preprocess()).  One wavefront per 64 Gaussians of a view.  The wave's 64 x 3M SH floats (19 200 B at
-// M = 25) are requested first, as 16-byte coalesced loads into registers, so that HBM latency overlaps the
-// projection math; they are then transposed through LDS (row stride 3M floats, odd => conflict-free).
+// K1: preprocess ([EXT] forward.cu preprocessCUDA; oracle preprocess()), split in two kernels that run CONCURRENTLY on
+// two streams because they have nothing in common but the means:
+//   k_preprocess (this stream, feeds the binning chain): projection, EWA covariance, conic, radius, reference rect and the
+//       64-bit 8x8-tile hit mask - 40 B in, 64 B out per (view, Gaussian), VALU-bound on the hit tests;
+//   k_color (side stream, joined before the blend): SH -> RGB (+0.5, clamp mask) for every view of a set - 300 of the 352
+//       input bytes per Gaussian, HBM-bound.  The wave's 64 x 3M SH floats (19 200 B at M = 25) are requested first, as
+//       16-byte coalesced loads into registers, then transposed through LDS (row stride 3M floats, odd => conflict-free)
+//       and evaluated once per view of the set (the SH of a set is read ONCE however many views it has).
 // ------------------------------------------------------------------------------------------------
-constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's SH rows (64 * 75 / 4 / 64 = 18.75)
+constexpr int kPreThreads = 256;
 
-__global__ __launch_bounds__(64) void k_preprocess(const Params p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int lane = threadIdx.x, v = blockIdx.y;
+__global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
+  const int v = blockIdx.y;
   const int N = p.d.num_gaussians;
-  const int g0 = blockIdx.x * 64;
-  const int i = g0 + lane;
+  const int i = blockIdx.x * kPreThreads + threadIdx.x;
+  if (i >= N) return;
   const int set = v / p.d.views_per_set;
   const GsrView& cam = p.views[v];
   const Grid& g = p.g;
-  const bool in_range = i < N;
-  const size_t gi = (size_t)set * N + (in_range ? i : 0), oi = (size_t)v * N + (in_range ? i : 0);
+  const size_t gi = (size_t)set * N + i, oi = (size_t)v * N + i;
 
-  // ---- SH prefetch (fast path: rows contiguous in LDS, 16-byte aligned source)
-  const int M = (p.d.flags & GSR_FLAG_ABLATE_NO_SH) ? 0 : p.d.sh_coeffs;
-  const int rowf = 3 * M, ldstride = rowf | 1;
-  const int cnt = min(64, N - g0);
-  const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
-  const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
-  const bool sh_fast = (M > 0) && (ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0);
-  float4 pre[kShPre];
-  if (sh_fast) {
+  const float mx = p.means[3 * gi + 0] * cam.scale, my = p.means[3 * gi + 1] * cam.scale, mz = p.means[3 * gi + 2] * cam.scale;
+  float cov6[6];
+  load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, cov6);
 #pragma unroll
-    for (int q = 0; q < kShPre; ++q) {
-      const int k = lane + 64 * q;
-      pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
-    }
-  }
-
-  bool vis = in_range;
-  float mx = 0, my = 0, mz = 0, cov6[6] = {0, 0, 0, 0, 0, 0}, op = 0;
-  if (in_range) {
-    mx = p.means[3 * gi + 0] * cam.scale; my = p.means[3 * gi + 1] * cam.scale; mz = p.means[3 * gi + 2] * cam.scale;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov6[k] = p.cov6[6 * gi + k] * cam.scale2;
-    op = p.opac[gi];
-  }
+  for (int k = 0; k < 6; ++k) cov6[k] *= cam.scale2;
+  const float op = p.opac[gi];
   const float* vm = cam.viewmatrix;
   const float* pm = cam.projmatrix;
   const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
-  vis = vis && !(pvz <= kNear);
+  bool vis = !(pvz <= kNear);
   const float ph0 = pm[0] * mx + pm[4] * my + pm[8] * mz + pm[12];
   const float ph1 = pm[1] * mx + pm[5] * my + pm[9] * mz + pm[13];
   const float ph3 = pm[3] * mx + pm[7] * my + pm[11] * mz + pm[15];
@@ -405,67 +436,91 @@ __global__ __launch_bounds__(64) void k_preprocess(const Params p) {
     ref_rect16(px, py, my_radius, g, rx0, ry0, rx1, ry1);
     vis = (rx1 - rx0) * (ry1 - ry0) != 0;
   }
-
-  // ---- colour
-  float cr = 0, cg = 0, cb = 0;
-  uint32_t clampbits = 0;
-  if (M > 0) {
-    if (__any(vis)) {
-      if (sh_fast) {
-#pragma unroll
-        for (int q = 0; q < kShPre; ++q) {
-          const int k = lane + 64 * q;
-          if (k < sh_n4) reinterpret_cast<float4*>(lds)[k] = pre[q];
-        }
-        for (int k = (sh_n4 << 2) + lane; k < sh_total; k += 64) lds[k] = sh_src[k];
+  const int radius = vis ? (int)my_radius : 0;
+  p.radii[oi] = radius;
+  GeomRec rec;
+  const float ex = (vis && p.d.has_extra) ? p.extra[oi] : 0.f;
+  rec.q0 = vis ? make_float4(px, py, conA, conB) : make_float4(0, 0, 0, 0);
+  rec.q1 = vis ? make_float4(conC, op, 0.f, 0.f) : make_float4(0, 0, 0, 0);
+  rec.q2 = make_float4(0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius));
+  unsigned long long mask = 0ull;
+  uint32_t origin = 0u;
+  if (vis && !(p.d.flags & GSR_FLAG_ABLATE_NO_COUNT)) {
+    const Foot f = make_foot(px, py, conA, conB, conC, op, my_radius, g);
+    if (f.sx1 > f.sx0 && f.sy1 > f.sy0) {
+      origin = (uint32_t)f.sx0 | ((uint32_t)f.sy0 << 12);
+      if (f.sx1 - f.sx0 <= 8 && f.sy1 - f.sy0 <= 8) {
+        for (int sy = f.sy0; sy < f.sy1; ++sy) mask |= (unsigned long long)row_hit_bits(f, sy, g) << ((sy - f.sy0) * 8);
       } else {
-        stage_rows(lds, sh_src, cnt, rowf, ldstride, lane);
-      }
-      __syncthreads();
-      if (vis) {
-        const float* sh = lds + lane * ldstride;
-        float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
-        const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-        dx = dx / len; dy = dy / len; dz = dz / len;
-        const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
-        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
-          if (k < M) { cr += bk * sh[3 * k + 0]; cg += bk * sh[3 * k + 1]; cb += bk * sh[3 * k + 2]; }
-        });
-        cr += 0.5f; cg += 0.5f; cb += 0.5f;
-        clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
-        cr = fmaxf(cr, 0.f); cg = fmaxf(cg, 0.f); cb = fmaxf(cb, 0.f);
+        origin |= 0x80000000u;
       }
     }
-  } else if (vis && p.d.sh_coeffs == 0) {
-    cr = p.colors[3 * gi + 0]; cg = p.colors[3 * gi + 1]; cb = p.colors[3 * gi + 2];
   }
+  rec.q3 = make_float4(__uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)), __uint_as_float(origin),
+                       vis ? pvz : 0.f);
+  if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE)) p.geom[oi] = rec;
+}
 
-  if (in_range) {
-    const int radius = vis ? (int)my_radius : 0;
-    p.radii[oi] = radius;
-    GeomRec rec;
-    const float ex = (vis && p.d.has_extra) ? p.extra[oi] : 0.f;
-    rec.q0 = vis ? make_float4(px, py, conA, conB) : make_float4(0, 0, 0, 0);
-    rec.q1 = vis ? make_float4(conC, op, cr, cg) : make_float4(0, 0, 0, 0);
-    rec.q2 = make_float4(vis ? cb : 0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius | (clampbits << 28)));
-    unsigned long long mask = 0ull;
-    uint32_t origin = 0u;
-    if (vis && !(p.d.flags & GSR_FLAG_ABLATE_NO_COUNT)) {
-      const Foot f = make_foot(px, py, conA, conB, conC, op, my_radius, g);
-      if (f.sx1 > f.sx0 && f.sy1 > f.sy0) {
-        origin = (uint32_t)f.sx0 | ((uint32_t)f.sy0 << 12);
-        if (f.sx1 - f.sx0 <= 8 && f.sy1 - f.sy0 <= 8) {
-          for (int sy = f.sy0; sy < f.sy1; ++sy)
-            for (int sx = f.sx0; sx < f.sx1; ++sx)
-              if (subtile_hit(f, sx, sy, g)) mask |= 1ull << ((sy - f.sy0) * 8 + (sx - f.sx0));
-        } else {
-          origin |= 0x80000000u;
-        }
-      }
+constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's SH rows (64 * 75 / 4 / 64 = 18.75)
+
+__global__ __launch_bounds__(64) void k_color(const Params p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x, set = blockIdx.y;
+  const int N = p.d.num_gaussians, Vs = p.d.views_per_set;
+  const int g0 = blockIdx.x * 64;
+  const int i = g0 + lane;
+  const bool in_range = i < N;
+  const size_t gi = (size_t)set * N + (in_range ? i : 0);
+  const int M = p.d.sh_coeffs;
+  if (M == 0) {  // precomputed colours: copy through (no clamp)
+    if (in_range)
+      for (int vv = 0; vv < Vs; ++vv)
+        p.rgbc[(size_t)(set * Vs + vv) * N + i] = make_float4(p.colors[3 * gi], p.colors[3 * gi + 1], p.colors[3 * gi + 2], 0.f);
+    return;
+  }
+  const int rowf = 3 * M, ldstride = rowf | 1;
+  const int cnt = min(64, N - g0);
+  const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
+  const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
+  const bool sh_fast = (ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0);
+  if (sh_fast) {
+    float4 pre[kShPre];
+#pragma unroll
+    for (int q = 0; q < kShPre; ++q) {
+      const int k = lane + 64 * q;
+      pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
     }
-    rec.q3 = make_float4(__uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)), __uint_as_float(origin),
-                         vis ? pvz : 0.f);
-    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE)) p.geom[oi] = rec;
+#pragma unroll
+    for (int q = 0; q < kShPre; ++q) {
+      const int k = lane + 64 * q;
+      if (k < sh_n4) reinterpret_cast<float4*>(lds)[k] = pre[q];
+    }
+    for (int k = (sh_n4 << 2) + lane; k < sh_total; k += 64) lds[k] = sh_src[k];
+  } else {
+    stage_rows(lds, sh_src, cnt, rowf, ldstride, lane);
+  }
+  float rmx = 0, rmy = 0, rmz = 0;
+  if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
+  __syncthreads();
+  if (!in_range) return;
+  const float* sh = lds + lane * ldstride;
+  const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
+  const int ks = planar ? 1 : 3, cs = planar ? M : 1;  // coefficient k of channel c sits at k * ks + c * cs
+  const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+  for (int vv = 0; vv < Vs; ++vv) {
+    const int v = set * Vs + vv;
+    const GsrView& cam = p.views[v];
+    const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
+    float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+    dx = dx / len; dy = dy / len; dz = dz / len;
+    float cr = 0, cg = 0, cb = 0;
+    sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
+      if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
+    });
+    cr += 0.5f; cg += 0.5f; cb += 0.5f;
+    const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
+    p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
   }
 }
 
@@ -823,16 +878,17 @@ constexpr int kFE = 11;                               // entries per helper per 
 constexpr int kFB = kFE * kFwdHelpers;                // 33 list entries per batch
 constexpr int kFwdThreads = 64 * (1 + kFwdHelpers);   // 256
 
-__device__ __forceinline__ void stage_batch(const GeomRec* geom, const uint32_t* plist, uint32_t n, uint32_t base, int lane,
-                                            uint32_t id, float4& g, float2& g2, float4& c) {
+__device__ __forceinline__ void stage_batch(const GeomRec* geom, const float4* rgbc, uint32_t n, uint32_t base, int lane,
+                                            uint32_t id, bool want_extra, float4& g, float2& g2, float4& c) {
   // lane = splat; null record (opacity 0) past the end of the list
   g = make_float4(0, 0, 0, 0); g2 = make_float2(0, 0); c = make_float4(0, 0, 0, 0);
   if (base + lane < n) {
     const GeomRec* r = geom + id;
     float4 q0 = r->q0, q1 = r->q1;
-    const float4 q2 = r->q2;
+    const float4 col = rgbc[id];
+    const float ex = want_extra ? r->q2.y : 0.f;
     to_exp2_domain(q0, q1);
-    g = q0; g2 = make_float2(q1.x, q1.y); c = make_float4(q1.z, q1.w, q2.x, q2.y);
+    g = q0; g2 = make_float2(q1.x, q1.y); c = make_float4(col.x, col.y, col.z, ex);
   }
 }
 
@@ -858,6 +914,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
   const uint32_t nbat = (n + kFB - 1) / kFB;
   const uint32_t* plist = p.point_list + rg.x;
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
+  const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
 
   float T = 1.f, Tf = inside ? 1.f : 0.f;      // scan wave: reported / free-running transmittance
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;  // helper waves: partial colour sums
@@ -903,7 +960,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
     if (lane < kFB && (wave == 1 || (wave == 2 && nbat > 1))) {
       const uint32_t b = (uint32_t)(wave - 1);
       const uint32_t id = (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u;
-      stage_batch(geom, plist, n, b * kFB, lane, id, sg, sg2, sc);
+      stage_batch(geom, rgbc, n, b * kFB, lane, id, kExtra, sg, sg2, sc);
       sGeo[b][lane] = sg; sGeo2[b][lane] = sg2; sCol[b][lane] = sc;
       if (wave == 1) id_next = (2u * kFB + lane < n) ? plist[2 * kFB + lane] : 0u;
     }
@@ -932,7 +989,7 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
         const uint32_t bs = i + 2;
         const bool do_stage = (wave == 1) && (bs < nbat) && (lane < kFB);
         if (do_stage) {
-          stage_batch(geom, plist, n, bs * kFB, lane, id_next, sg, sg2, sc);  // global gather in flight
+          stage_batch(geom, rgbc, n, bs * kFB, lane, id_next, kExtra, sg, sg2, sc);  // global gather in flight
           id_next = ((bs + 1) * kFB + lane < n) ? plist[(bs + 1) * kFB + lane] : 0u;
         }
         if (i >= 1) accum(i - 1);
@@ -1031,6 +1088,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
   const uint32_t n = rg.y - rg.x;
   const size_t HW = (size_t)g.H * g.W;
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
+  const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
   const uint32_t* plist = p.point_list + rg.x;
   float* scratch = p.scratch + (size_t)v * p.d.num_gaussians * GSR_SCREEN_GRAD_FLOATS;
   const GsrView& cam = p.views[v];
@@ -1074,9 +1132,10 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
     if (lane < kBB && idx < nmax) {
       const GeomRec* r = geom + id;
       float4 q0 = r->q0, q1 = r->q1;
-      const float4 q2 = r->q2;
+      const float4 col = rgbc[id];
+      const float ex = has_extra ? r->q2.y : 0.f;
       to_exp2_domain(q0, q1);
-      sg = q0; sg2 = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f); sc = make_float4(q1.z, q1.w, q2.x, q2.y);
+      sg = q0; sg2 = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f); sc = make_float4(col.x, col.y, col.z, ex);
     }
   };
   auto load_ids = [&](uint32_t it) -> uint32_t {
@@ -1227,8 +1286,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   float rmx = 0, rmy = 0, rmz = 0, rcov[6] = {0, 0, 0, 0, 0, 0};
   if (in_range) {
     rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) rcov[k] = p.cov6[6 * gi + k];
+    load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, rcov);
   }
   float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0};
   for (int vv = 0; vv < Vs; ++vv) {
@@ -1238,6 +1296,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     uint32_t bits = 0;
     if (in_range) bits = __float_as_uint(p.geom[oi].q2.w);
     const bool vis = in_range && (bits & 0x0fffffffu) != 0;
+    if (vis && M > 0) bits |= __float_as_uint(p.rgbc[oi].w) << 28;
     float sg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     if (vis) {
       const float* s = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
@@ -1316,12 +1375,14 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const float d0 = (cl & 1u) ? 0.f : sg[6], d1 = (cl & 2u) ? 0.f : sg[7], d2 = (cl & 4u) ? 0.f : sg[8];
       const float* sh = sh_in + lane * ldstride;
       float* dsh = sh_out + lane * ldstride;
+      const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
+      const int ks = planar ? 1 : 3, cs = planar ? M : 1;
       float ddx = 0, ddy = 0, ddz = 0;
       const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
       sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
         if (k < M) {
-          dsh[3 * k + 0] += bk * d0; dsh[3 * k + 1] += bk * d1; dsh[3 * k + 2] += bk * d2;
-          const float sd = sh[3 * k + 0] * d0 + sh[3 * k + 1] * d1 + sh[3 * k + 2] * d2;
+          dsh[k * ks + 0 * cs] += bk * d0; dsh[k * ks + 1 * cs] += bk * d1; dsh[k * ks + 2 * cs] += bk * d2;
+          const float sd = sh[k * ks + 0 * cs] * d0 + sh[k * ks + 1 * cs] * d1 + sh[k * ks + 2 * cs] * d2;
           ddx += bx * sd; ddy += by * sd; ddz += bz * sd;
         }
       });
@@ -1341,8 +1402,13 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   if (in_range) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) p.dL_dmeans[3 * gi + j] = dmean[j];
+    if (p.d.flags & GSR_FLAG_COV_3X3) {
+      float* o = p.dL_dcov6 + 9 * gi;
+      o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = 0.f; o[4] = dcov[3]; o[5] = dcov[4]; o[6] = 0.f; o[7] = 0.f; o[8] = dcov[5];
+    } else {
 #pragma unroll
-    for (int k = 0; k < 6; ++k) p.dL_dcov6[6 * gi + k] = dcov[k];
+      for (int k = 0; k < 6; ++k) p.dL_dcov6[6 * gi + k] = dcov[k];
+    }
     p.dL_dopac[gi] = dop;
     if (M == 0) { p.dL_dcolors[3 * gi + 0] = dcol[0]; p.dL_dcolors[3 * gi + 1] = dcol[1]; p.dL_dcolors[3 * gi + 2] = dcol[2]; }
   }
@@ -1350,6 +1416,94 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     __syncthreads();
     unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_out, cnt, rowf, ldstride, lane);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Camera set-up: what the reference wrapper does with ~40 tiny torch launches per call (cuda_splatting.py:64-71, 80-87:
+// scale-invariant rescale, get_fov, get_projection_matrix, extrinsics.inverse(), view @ proj) in ONE launch, one
+// thread per view, straight into the GsrView records the raster kernels read.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool inv3(const float* m, float* o) {
+  const float c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+  const float det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+  const float id = 1.f / det;
+  o[0] = c00 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+  o[3] = c01 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  o[6] = c02 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+  return det != 0.f;
+}
+__device__ __forceinline__ void inv4(const float* m, float* inv) {  // general 4x4 inverse by cofactors
+  inv[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
+  inv[4] = -m[4] * m[10] * m[15] + m[4] * m[11] * m[14] + m[8] * m[6] * m[15] - m[8] * m[7] * m[14] - m[12] * m[6] * m[11] + m[12] * m[7] * m[10];
+  inv[8] = m[4] * m[9] * m[15] - m[4] * m[11] * m[13] - m[8] * m[5] * m[15] + m[8] * m[7] * m[13] + m[12] * m[5] * m[11] - m[12] * m[7] * m[9];
+  inv[12] = -m[4] * m[9] * m[14] + m[4] * m[10] * m[13] + m[8] * m[5] * m[14] - m[8] * m[6] * m[13] - m[12] * m[5] * m[10] + m[12] * m[6] * m[9];
+  inv[1] = -m[1] * m[10] * m[15] + m[1] * m[11] * m[14] + m[9] * m[2] * m[15] - m[9] * m[3] * m[14] - m[13] * m[2] * m[11] + m[13] * m[3] * m[10];
+  inv[5] = m[0] * m[10] * m[15] - m[0] * m[11] * m[14] - m[8] * m[2] * m[15] + m[8] * m[3] * m[14] + m[12] * m[2] * m[11] - m[12] * m[3] * m[10];
+  inv[9] = -m[0] * m[9] * m[15] + m[0] * m[11] * m[13] + m[8] * m[1] * m[15] - m[8] * m[3] * m[13] - m[12] * m[1] * m[11] + m[12] * m[3] * m[9];
+  inv[13] = m[0] * m[9] * m[14] - m[0] * m[10] * m[13] - m[8] * m[1] * m[14] + m[8] * m[2] * m[13] + m[12] * m[1] * m[10] - m[12] * m[2] * m[9];
+  inv[2] = m[1] * m[6] * m[15] - m[1] * m[7] * m[14] - m[5] * m[2] * m[15] + m[5] * m[3] * m[14] + m[13] * m[2] * m[7] - m[13] * m[3] * m[6];
+  inv[6] = -m[0] * m[6] * m[15] + m[0] * m[7] * m[14] + m[4] * m[2] * m[15] - m[4] * m[3] * m[14] - m[12] * m[2] * m[7] + m[12] * m[3] * m[6];
+  inv[10] = m[0] * m[5] * m[15] - m[0] * m[7] * m[13] - m[4] * m[1] * m[15] + m[4] * m[3] * m[13] + m[12] * m[1] * m[7] - m[12] * m[3] * m[5];
+  inv[14] = -m[0] * m[5] * m[14] + m[0] * m[6] * m[13] + m[4] * m[1] * m[14] - m[4] * m[2] * m[13] - m[12] * m[1] * m[6] + m[12] * m[2] * m[5];
+  inv[3] = -m[1] * m[6] * m[11] + m[1] * m[7] * m[10] + m[5] * m[2] * m[11] - m[5] * m[3] * m[10] - m[9] * m[2] * m[7] + m[9] * m[3] * m[6];
+  inv[7] = m[0] * m[6] * m[11] - m[0] * m[7] * m[10] - m[4] * m[2] * m[11] + m[4] * m[3] * m[10] + m[8] * m[2] * m[7] - m[8] * m[3] * m[6];
+  inv[11] = -m[0] * m[5] * m[11] + m[0] * m[7] * m[9] + m[4] * m[1] * m[11] - m[4] * m[3] * m[9] - m[8] * m[1] * m[7] + m[8] * m[3] * m[5];
+  inv[15] = m[0] * m[5] * m[10] - m[0] * m[6] * m[9] - m[4] * m[1] * m[10] + m[4] * m[2] * m[9] + m[8] * m[1] * m[6] - m[8] * m[2] * m[5];
+  const float det = m[0] * inv[0] + m[1] * inv[4] + m[2] * inv[8] + m[3] * inv[12];
+  const float id = 1.f / det;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) inv[i] *= id;
+}
+
+__global__ void k_setup_views(int V, const float* ext, const float* intr, const float* near_, const float* far_, const float* bg,
+                              int bg_stride, int scale_invariant, GsrView* out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  float E[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) E[i] = ext[16 * v + i];
+  float nr = near_[v], fr = far_[v];
+  const float s = scale_invariant ? 1.f / nr : 1.f;
+  if (scale_invariant) { E[3] *= s; E[7] *= s; E[11] *= s; nr = nr * s; fr = fr * s; }
+  // get_fov (projection.py:233-247): angle between the un-projected edge-midpoint rays
+  float Ki[9];
+  inv3(intr + 9 * v, Ki);
+  auto ray = [&](float x, float y, float* o) {
+    o[0] = Ki[0] * x + Ki[1] * y + Ki[2]; o[1] = Ki[3] * x + Ki[4] * y + Ki[5]; o[2] = Ki[6] * x + Ki[7] * y + Ki[8];
+    const float n = sqrtf(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    o[0] /= n; o[1] /= n; o[2] /= n;
+  };
+  float l[3], r[3], t[3], b[3];
+  ray(0.f, 0.5f, l); ray(1.f, 0.5f, r); ray(0.5f, 0.f, t); ray(0.5f, 1.f, b);
+  const float fov_x = acosf(l[0] * r[0] + l[1] * r[1] + l[2] * r[2]);
+  const float fov_y = acosf(t[0] * b[0] + t[1] * b[1] + t[2] * b[2]);
+  const float tx = tanf(0.5f * fov_x), ty = tanf(0.5f * fov_y);
+  // get_projection_matrix (cuda_splatting.py:17-44)
+  const float top = ty * nr, right = tx * nr;
+  float P[16] = {0};
+  P[0] = 2.f * nr / (right + right); P[5] = 2.f * nr / (top + top); P[14] = 1.f;
+  P[10] = fr / (fr - nr); P[11] = -(fr * nr) / (fr - nr);
+  float Ei[16];
+  inv4(E, Ei);
+  GsrView o;
+  // viewmatrix = (E^-1)^T, projmatrix = (E^-1)^T P^T, both stored row-major (cuda_splatting.py:85-87)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o.viewmatrix[4 * i + j] = Ei[4 * j + i];
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += Ei[4 * k + i] * P[4 * j + k];
+      o.projmatrix[4 * i + j] = a;
+    }
+  o.campos[0] = E[3]; o.campos[1] = E[7]; o.campos[2] = E[11];
+  o.tanfovx = tx; o.tanfovy = ty;
+  o.bg[0] = bg[bg_stride * v + 0]; o.bg[1] = bg[bg_stride * v + 1]; o.bg[2] = bg[bg_stride * v + 2];
+  o.scale = s; o.scale2 = s * s; o.scale_modifier = 1.f;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) o.reserved[i] = 0.f;
+  out[v] = o;
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(const Params p, uint8_t* present) {
@@ -1390,6 +1544,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   const Layout L = make_layout(*d);
   char* b = static_cast<char*>(bin);
   p.geom = static_cast<GeomRec*>(geom);
+  p.rgbc = geom ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rgbc) : nullptr;
   p.status = reinterpret_cast<GsrStatus*>(b + L.o_status);
   p.counts = reinterpret_cast<uint32_t*>(b + L.o_counts);
   p.tile_total = reinterpret_cast<uint32_t*>(b + L.o_total);
@@ -1412,6 +1567,30 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
 using namespace gsr;
 
 static hipEvent_t* g_bwd_events = nullptr;
+
+// Per host thread: one non-blocking side stream and a fork/join event pair (created on first use, kept for the life of
+// the thread - the only persistent state the library holds).  Event records are ordered by the calling stream, so the
+// pair can be reused call after call, and the fork/join pattern is capturable into a HIP graph.
+struct SideStream {
+  hipStream_t stream = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+static SideStream* side_stream() {
+  static thread_local SideStream s;
+  static thread_local int dev = -1;
+  int cur = 0;
+  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+  if (!s.ok || dev != cur) {
+    if (s.ok) { (void)hipStreamDestroy(s.stream); (void)hipEventDestroy(s.fork); (void)hipEventDestroy(s.join); s.ok = false; }
+    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
+    s.ok = true;
+    dev = cur;
+  }
+  return &s;
+}
 
 extern "C" {
 
@@ -1464,15 +1643,30 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const size_t VT = V * (size_t)p.g.T;
   int e = 0;
 #define GSR_MARK() do { if (ev) GSR_CHECK(hipEventRecord(ev[e++], st)); } while (0)
-  GSR_MARK();
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
-  hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + 63) / 64), (unsigned)V), dim3(64), shmem, st, p);
+  const bool do_color = !(d.flags & GSR_FLAG_ABLATE_NO_SH);
+  const dim3 cgrid((unsigned)((N + 63) / 64), (unsigned)d.num_sets);
+  // Fork: the colour kernel (HBM-bound, 85 % of the input bytes) runs on a side stream while this stream goes through
+  // geometry -> binning -> sort; joined before the blend.  In profile mode (ev != null) everything stays on one
+  // stream so each stage is timed alone.
+  SideStream* ss = ev ? nullptr : side_stream();
+  GSR_MARK();
+  if (do_color && ss) {
+    GSR_CHECK(hipEventRecord(ss->fork, st));
+    GSR_CHECK(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+    hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, ss->stream, p);
+    GSR_CHECK(hipEventRecord(ss->join, ss->stream));
+  }
+  hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
+  GSR_MARK();
+  if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
   GSR_MARK();
   hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 63) / 64)), dim3(1024), 0, st, p);
   hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
   GSR_MARK();
+  if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));  // long signalled by now: colour ends before the scans do
   hipLaunchKernelGGL(k_emit, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   GSR_MARK();
   hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
@@ -1572,6 +1766,17 @@ int gsr_backward_profile(const GsrDims* dims, const GsrView* views, const float*
   }
   for (int i = 0; i <= GSR_BWD_STAGES; ++i) (void)hipEventDestroy(ev[i]);
   return rc;
+}
+
+int gsr_setup_views(int num_views, const float* extrinsics, const float* intrinsics, const float* near_, const float* far_,
+                    const float* background, int background_stride, int scale_invariant, GsrView* views, void* stream_) {
+  if (num_views < 0 || (background_stride != 0 && background_stride != 3)) return GSR_ERR_INVALID_ARGUMENT;
+  if (num_views == 0) return GSR_OK;
+  if (!extrinsics || !intrinsics || !near_ || !far_ || !background || !views) return GSR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_setup_views, dim3((unsigned)((num_views + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     num_views, extrinsics, intrinsics, near_, far_, background, background_stride, scale_invariant, views);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
 }
 
 int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present, void* stream_) {

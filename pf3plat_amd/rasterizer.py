@@ -51,6 +51,7 @@ class RasterConfig:
     sh_coeffs: int  # M; 0 => precomputed colours
     max_sh_eval: int = 4
     has_extra: bool = False
+    flags: int = 0  # _lib.FLAG_SH_PLANAR | _lib.FLAG_COV_3X3 (input layouts)
 
 
 def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx: Tensor, tanfovy: Tensor,
@@ -100,7 +101,7 @@ class HipBackend:
     def _dims(cfg: RasterConfig, capacity: int) -> _lib.GsrDims:
         return _lib.GsrDims(_lib.GSR_ABI_VERSION, cfg.num_views, cfg.num_sets, cfg.views_per_set, cfg.num_gaussians,
                             cfg.height, cfg.width, cfg.sh_degree, cfg.sh_coeffs, cfg.max_sh_eval,
-                            int(cfg.has_extra), 0, int(capacity))
+                            int(cfg.has_extra), int(cfg.flags), int(capacity))
 
     def workspace_sizes(self, dims: _lib.GsrDims):
         g, b, i = ctypes.c_size_t(), ctypes.c_size_t(), ctypes.c_size_t()
@@ -146,11 +147,14 @@ class HipBackend:
         )
         if backward:
             if colors_shape is None:
-                colors_shape = (s, n, cfg.sh_coeffs, 3) if cfg.sh_coeffs > 0 else (s, n, 3)
+                if cfg.sh_coeffs > 0:
+                    colors_shape = (s, n, 3, cfg.sh_coeffs) if cfg.flags & _lib.FLAG_SH_PLANAR else (s, n, cfg.sh_coeffs, 3)
+                else:
+                    colors_shape = (s, n, 3)
             plan.update(
                 scratch=torch.empty(max(1, v * n * _lib.SCREEN_GRAD_FLOATS), dtype=f32, device=device),
                 d_means=torch.empty((s, n, 3), dtype=f32, device=device),
-                d_cov6=torch.empty((s, n, 6), dtype=f32, device=device),
+                d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=device),
                 d_opac=torch.empty((s, n), dtype=f32, device=device),
                 d_colors=torch.empty(colors_shape, dtype=f32, device=device),
                 d_extra=torch.empty((v, n), dtype=f32, device=device) if cfg.has_extra else None,
@@ -241,7 +245,8 @@ class HipBackend:
         f32 = torch.float32
         plan = dict(cfg=cfg, dims=dims, device=dev, geom=geom, bin=binb, img=img,
                     scratch=torch.empty(max(1, v * n * _lib.SCREEN_GRAD_FLOATS), dtype=f32, device=dev),
-                    d_means=torch.empty((s, n, 3), dtype=f32, device=dev), d_cov6=torch.empty((s, n, 6), dtype=f32, device=dev),
+                    d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
+                    d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=dev),
                     d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
                     d_extra=torch.empty((v, n), dtype=f32, device=dev) if cfg.has_extra else None,
                     d_means2d=torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None)
@@ -252,6 +257,21 @@ class HipBackend:
                                else g_extra_img.contiguous().to(f32))
             self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d)
         return plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
+
+    def setup_views(self, extrinsics, intrinsics, near, far, background, scale_invariant: bool = True) -> Tensor:
+        """(V,4,4) c2w, (V,3,3), (V,), (V,), (3,) or (V,3) -> (V,48) camera records, one kernel launch (gsr_setup_views)."""
+        self._check_device(extrinsics, intrinsics, near, far, background)
+        v = extrinsics.shape[0]
+        f32 = torch.float32
+        ext, intr = extrinsics.to(f32).contiguous(), intrinsics.to(f32).contiguous()
+        nr, fr, bg = near.to(f32).contiguous(), far.to(f32).contiguous(), background.to(f32).contiguous()
+        out = torch.empty((v, VIEW_FLOATS), dtype=f32, device=ext.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(ext.device).cuda_stream)
+        rc = self.lib.gsr_setup_views(v, _ptr(ext), _ptr(intr), _ptr(nr), _ptr(fr), _ptr(bg), 3 if bg.dim() == 2 else 0,
+                                      int(bool(scale_invariant)), _ptr(out), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_setup_views failed with code {rc}")
+        return out
 
     def mark_visible(self, cfg: RasterConfig, viewbuf, means):
         self._check_device(viewbuf, means)
@@ -322,13 +342,14 @@ class _RasterizeViews(torch.autograd.Function):
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
                     image_shape, sh_degree: int, use_sh: bool, views_per_set: int, extra: Optional[Tensor] = None,
-                    means2d: Optional[Tensor] = None, max_sh_eval: int = 4):
+                    means2d: Optional[Tensor] = None, max_sh_eval: int = 4, sh_planar: bool = False, cov_3x3: bool = False):
     """Render V = num_sets * views_per_set views in one launch chain.
 
-    means (S,N,3), cov6 (S,N,6), opacities (S,N), colors (S,N,M,3) if use_sh else (S,N,3),
-    viewbuf (V,48) from `pack_views` (set-major), extra (V,N) optional 4th blended channel.
-    Returns (color (V,3,H,W), extra_img (V,H,W) | None, radii (V,N) int32).  Differentiable w.r.t. means,
-    cov6, opacities, colors, extra (and means2d receives the screen-space gradient); cameras get none,
+    means (S,N,3); cov6 (S,N,6) or, with cov_3x3, the full symmetric (S,N,3,3); opacities (S,N); colors (S,N,M,3) or, with
+    sh_planar, PF3plat's harmonics layout (S,N,3,M) if use_sh else (S,N,3); viewbuf (V,48) from `pack_views` / the backend's
+    `setup_views` (set-major); extra (V,N) optional 4th blended channel.
+    Returns (color (V,3,H,W), extra_img (V,H,W) | None, radii (V,N) int32).  Differentiable w.r.t. means, cov6, opacities,
+    colors, extra (gradients come back in the layouts given; means2d receives the screen-space gradient); cameras get none,
     like the reference operator.
     """
     s, n = means.shape[0], means.shape[1]
@@ -343,10 +364,13 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     colors = colors.to(f32).contiguous()
     if extra is not None:
         extra = extra.to(f32).contiguous()
-    m = colors.shape[2] if use_sh else 0
     if use_sh and colors.dim() != 4:
-        raise ValueError("shs must be (sets, N, M, 3)")
-    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), extra is not None)
+        raise ValueError("shs must be (sets, N, M, 3) or (sets, N, 3, M)")
+    if cov6.shape[2:] != ((3, 3) if cov_3x3 else (6,)):
+        raise ValueError(f"covariances have shape {tuple(cov6.shape)}; expected (sets, N, {'3, 3' if cov_3x3 else '6'})")
+    m = (colors.shape[3] if sh_planar else colors.shape[2]) if use_sh else 0
+    flags = (_lib.FLAG_SH_PLANAR if (sh_planar and use_sh) else 0) | (_lib.FLAG_COV_3X3 if cov_3x3 else 0)
+    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), extra is not None, flags)
     color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg)
     return color, (extra_img if extra is not None else None), radii
 

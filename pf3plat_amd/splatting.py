@@ -21,7 +21,7 @@ import torch
 from torch import Tensor
 
 from .geometry import depth_to_relative_disparity, get_fov, get_projection_matrix, homogenize_points
-from .rasterizer import pack_views, rasterize_views
+from .rasterizer import get_backend, pack_views, rasterize_views
 from .types import DepthRenderingMode
 
 _TRIU = ((0, 0, 0, 1, 1, 2), (0, 1, 2, 1, 2, 2))  # torch.triu_indices(3, 3)
@@ -53,6 +53,18 @@ def _cameras(extrinsics, intrinsics, near, far, scale_invariant: bool):
     return view_matrix, full_projection, extrinsics[:, :3, 3], tan_fov_x, tan_fov_y, scale
 
 
+def _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invariant: bool) -> Tensor:
+    """Camera records for `rasterize_views`: one `gsr_setup_views` launch when the backend has it (the HIP library), else the
+    batched torch ops above (the arithmetic of the reference wrapper; used by the CPU tests)."""
+    with torch.no_grad():
+        backend = get_backend()
+        if hasattr(backend, "setup_views"):
+            return backend.setup_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+        view_matrix, full_projection, campos, tan_x, tan_y, scale = _cameras(extrinsics, intrinsics, near, far, scale_invariant)
+        bg = background_color if background_color.dim() == 2 else background_color.reshape(1, 3).expand(extrinsics.shape[0], 3)
+        return pack_views(view_matrix, full_projection, campos, tan_x, tan_y, bg, scale)
+
+
 def render_cuda(
     extrinsics: Tensor,  # (batch, 4, 4) camera-to-world
     intrinsics: Tensor,  # (batch, 3, 3) normalised
@@ -68,17 +80,15 @@ def render_cuda(
     use_sh: bool = True,
 ) -> Tensor:  # (batch, 3, height, width)
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
-    with torch.no_grad():
-        view_matrix, full_projection, campos, tan_x, tan_y, scale = _cameras(
-            extrinsics, intrinsics, near, far, scale_invariant)
-        viewbuf = pack_views(view_matrix, full_projection, campos, tan_x, tan_y, background_color, scale)
+    viewbuf = _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invariant)
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
-    shs = gaussian_sh_coefficients.permute(0, 1, 3, 2)  # "b g xyz n -> b g n xyz"
-    colors = shs if use_sh else shs[:, :, 0, :]
+    # harmonics (b, g, 3, d_sh) and covariances (b, g, 3, 3) go to the operator as they are (no re-layout copies;
+    # the reference permutes + gathers here, cuda_splatting.py:75,115,123)
+    colors = gaussian_sh_coefficients if use_sh else gaussian_sh_coefficients[:, :, :, 0]
     color, _, _ = rasterize_views(
-        gaussian_means, _cov6(gaussian_covariances), gaussian_opacities, colors, viewbuf,
-        image_shape=image_shape, sh_degree=degree, use_sh=use_sh, views_per_set=1)
+        gaussian_means, gaussian_covariances, gaussian_opacities, colors, viewbuf,
+        image_shape=image_shape, sh_degree=degree, use_sh=use_sh, views_per_set=1, sh_planar=True, cov_3x3=True)
     return color
 
 
@@ -166,15 +176,12 @@ def render_depth_cuda(
     is blended here once, as the extra channel of a colour-less pass."""
     fake_color = depth_fake_color(extrinsics, gaussian_means, near, far, mode)
     b, g = fake_color.shape
-    with torch.no_grad():
-        view_matrix, full_projection, campos, tan_x, tan_y, scale = _cameras(
-            extrinsics, intrinsics, near, far, scale_invariant)
-        bg = torch.zeros((b, 3), dtype=torch.float32, device=fake_color.device)
-        viewbuf = pack_views(view_matrix, full_projection, campos, tan_x, tan_y, bg, scale)
-        zero_rgb = torch.zeros((b, g, 3), dtype=torch.float32, device=fake_color.device)
+    bg = torch.zeros((b, 3), dtype=torch.float32, device=fake_color.device)
+    viewbuf = _viewbuf(extrinsics, intrinsics, near, far, bg, scale_invariant)
+    zero_rgb = torch.zeros((b, g, 3), dtype=torch.float32, device=fake_color.device)
     _, depth, _ = rasterize_views(
-        gaussian_means, _cov6(gaussian_covariances), gaussian_opacities, zero_rgb, viewbuf,
-        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=1, extra=fake_color)
+        gaussian_means, gaussian_covariances, gaussian_opacities, zero_rgb, viewbuf,
+        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=1, extra=fake_color, cov_3x3=True)
     return depth
 
 
@@ -201,19 +208,15 @@ def render_views(
     nr, fr = near.reshape(s * v), far.reshape(s * v)
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
-    with torch.no_grad():
-        view_matrix, full_projection, campos, tan_x, tan_y, scale = _cameras(ext, intr, nr, fr, scale_invariant)
-        viewbuf = pack_views(view_matrix, full_projection, campos, tan_x, tan_y,
-                             background_color.reshape(1, 3).expand(s * v, 3), scale)
+    viewbuf = _viewbuf(ext, intr, nr, fr, background_color.reshape(3), scale_invariant)
     extra = None
     if depth_mode is not None:
         g = gaussian_means.shape[1]
         means_rep = gaussian_means[:, None].expand(s, v, g, 3).reshape(s * v, g, 3)
         extra = depth_fake_color(ext, means_rep, nr, fr, depth_mode)
-    shs = gaussian_sh_coefficients.permute(0, 1, 3, 2)
     color, depth, _ = rasterize_views(
-        gaussian_means, _cov6(gaussian_covariances), gaussian_opacities, shs, viewbuf,
-        image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra=extra)
+        gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, viewbuf,
+        image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra=extra, sh_planar=True, cov_3x3=True)
     h, w = image_shape
     color = color.reshape(s, v, 3, h, w)
     if depth is not None:

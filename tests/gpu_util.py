@@ -32,6 +32,9 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
     T = sgx * sgy
     g = geom[: V * N * 64].view(torch.float32).reshape(V, N, 16).cpu().numpy()
     bits = geom[: V * N * 64].view(torch.int32).reshape(V, N, 16)[:, :, 11].cpu().numpy()
+    o_rgbc = (V * N * 64 + 255) // 256 * 256
+    rgbc = geom[o_rgbc: o_rgbc + V * N * 16].view(torch.float32).reshape(V, N, 4).cpu().numpy()
+    cbits = geom[o_rgbc: o_rgbc + V * N * 16].view(torch.int32).reshape(V, N, 4)[:, :, 3].cpu().numpy()
     b = binb.cpu()
     st = b[:16]
     num_pairs = int(st[:8].view(torch.int64).item())
@@ -42,7 +45,7 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
     im = img.cpu()
     final_T = im[lay["final_T"]: lay["final_T"] + V * H * W * 4].view(torch.float32).reshape(V, H, W).numpy()
     n_contrib = im[lay["n_contrib"]: lay["n_contrib"] + V * H * W * 4].view(torch.int32).reshape(V, H, W).numpy()
-    return dict(geom=g, radius=bits & 0x0FFFFFFF, clamped=(bits >> 28) & 7, ranges=ranges, point_list=plist, keys=keys,
+    return dict(geom=g, rgb=rgbc[:, :, :3], radius=bits & 0x0FFFFFFF, clamped=cbits & 7, ranges=ranges, point_list=plist, keys=keys,
                 final_T=final_T, n_contrib=n_contrib, num_pairs=num_pairs, overflow=int(st[8:12].view(torch.int32).item()),
                 max_list=int(st[12:16].view(torch.int32).item()), sgx=sgx, sgy=sgy, T=T)
 

@@ -31,7 +31,17 @@ class OracleBackend:
         return dict(viewmatrix=vb[0:16], projmatrix=vb[16:32], campos=vb[32:35], tanfovx=vb[35], tanfovy=vb[36],
                     bg=vb[37:40], scale=vb[40], scale2=vb[41], scale_modifier=vb[42])
 
+    @staticmethod
+    def _canon(cfg, cov6, colors):
+        """Inputs in the layouts flagged by cfg.flags -> the per-view rasterizer's (N,6) / (N,M,3) layouts."""
+        if cfg.flags & 0x8:
+            cov6 = torch.stack((cov6[..., 0, 0], cov6[..., 0, 1], cov6[..., 0, 2], cov6[..., 1, 1], cov6[..., 1, 2], cov6[..., 2, 2]), -1)
+        if cfg.flags & 0x4 and cfg.sh_coeffs > 0:
+            colors = colors.permute(0, 1, 3, 2)
+        return cov6, colors
+
     def forward(self, cfg, viewbuf, means, cov6, opac, colors, extra, capacity=None):
+        cov6, colors = self._canon(cfg, cov6, colors)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
         color = torch.zeros((V, 3, H, W), dtype=tdt)
@@ -73,6 +83,8 @@ class OracleBackend:
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         V, N, S = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         d_means = torch.zeros((S, N, 3), dtype=tdt)
+        colors_in_shape = tuple(colors.shape)
+        cov6, colors = self._canon(cfg, cov6, colors)
         d_cov6 = torch.zeros((S, N, 6), dtype=tdt)
         d_opac = torch.zeros((S, N), dtype=tdt)
         d_colors = torch.zeros(tuple(colors.shape), dtype=tdt)
@@ -91,6 +103,14 @@ class OracleBackend:
                 d_extra[v] = torch.from_numpy(g["extra"])
             if want_means2d:
                 d_m2d[v] = torch.from_numpy(g["means2D"])
+        if cfg.flags & 0x4 and cfg.sh_coeffs > 0:
+            d_colors = d_colors.permute(0, 1, 3, 2).contiguous()
+        if cfg.flags & 0x8:
+            d9 = torch.zeros((S, N, 3, 3), dtype=tdt)
+            for k, (i, j) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+                d9[..., i, j] = d_cov6[..., k]
+            d_cov6 = d9
+        assert tuple(d_colors.shape) == colors_in_shape
         return d_means, d_cov6, d_opac, d_colors, d_extra, d_m2d
 
     def mark_visible(self, cfg, viewbuf, means):

@@ -27,7 +27,7 @@ def check_preprocess(res, cfg, v=0):
             "xy": (hx[:, 0:2], geo["xy"][vis]),
             "conic": (np.stack([hx[:, 2], hx[:, 3], hx[:, 4]], -1), geo["conic_opacity"][vis][:, :3]),
             "opacity": (hx[:, 5], geo["conic_opacity"][vis][:, 3]),
-            "rgb": (np.stack([hx[:, 6], hx[:, 7], hx[:, 8]], -1), geo["rgb"][vis]),
+            "rgb": (ws["rgb"][v][vis], geo["rgb"][vis]),
             "depth": (hx[:, 10], geo["depth"][vis]),
         }
         for k, (a, b) in pairs.items():

@@ -170,3 +170,31 @@ def test_per_view_rasterizer_upstream_signature():
         assert rel_l2(g[i], o[i]) < 1e-4, i
     assert np.array_equal(g[5], o[5]) and g[5].all()
     assert rel_l2(g[6], g[0]) < 1e-4  # scale/rotation path reproduces the precomputed covariance image
+
+
+def test_setup_views_kernel_matches_reference_camera_arithmetic():
+    """gsr_setup_views (one launch) == the wrapper's batched torch ops (which tests/test_wrapper_fixtures.py pins to the
+    reference's cuda_splatting.py:64-87), for rotated/translated cameras, off-centre principal points and both scale modes."""
+    from pf3plat_amd.rasterizer import pack_views
+    from pf3plat_amd.splatting import _cameras
+    from tests.util import look_at_c2w
+
+    v = 5
+    gen = torch.Generator().manual_seed(3)
+    ext = torch.stack([torch.tensor(look_at_c2w((0.3 * i - 0.5, 0.2 * i, -0.4 * i))) for i in range(v)])
+    intr = torch.eye(3).repeat(v, 1, 1)
+    intr[:, 0, 0] = 0.6 + 0.5 * torch.rand(v, generator=gen)
+    intr[:, 1, 1] = 0.6 + 0.5 * torch.rand(v, generator=gen)
+    intr[:, 0, 2] = 0.45 + 0.1 * torch.rand(v, generator=gen)
+    intr[:, 1, 2] = 0.5
+    near = 0.5 + 2 * torch.rand(v, generator=gen)
+    far = 50 + 50 * torch.rand(v, generator=gen)
+    bg = torch.rand(v, 3, generator=gen)
+    be = rasterizer.get_backend()
+    for si in (True, False):
+        got = be.setup_views(ext.to(DEV), intr.to(DEV), near.to(DEV), far.to(DEV), bg.to(DEV), si).cpu()
+        vm, fp, cp, tx, ty, sc = _cameras(ext, intr, near, far, si)
+        want = pack_views(vm, fp, cp, tx, ty, bg, sc)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+    one_bg = be.setup_views(ext.to(DEV), intr.to(DEV), near.to(DEV), far.to(DEV), bg[0].to(DEV), True).cpu()
+    assert torch.allclose(one_bg[:, 37:40], bg[0].expand(v, 3))
