@@ -47,6 +47,15 @@ extern "C" {
 #define GSR_FLAG_SH_PLANAR 0x4  /* colors are (num_sets, N, 3, M) "harmonics" instead of (num_sets, N, M, 3); grads likewise */
 #define GSR_FLAG_COV_3X3 0x8    /* cov6 points at (num_sets, N, 3, 3) symmetric matrices; dL_dcov6 is (num_sets, N, 3, 3) with
                                    the gradient on the upper triangle only (as the reference's triu gather yields) */
+/* GsrDims.flags bits 4-6: built-in extra channel.  0 = blend the caller's `extra` array; otherwise `extra` may be NULL and
+ * the kernels blend f(z) of the camera-space depth in un-normalised units, i.e. the image the reference's
+ * render_depth_cuda produces in each DepthRenderingMode (cuda_splatting.py:238-251) - in the same pass as the colour.
+ * The backward then adds dL/dextra * f'(z) * dz/dmean to dL_dmeans itself (dL_dextra is not written). */
+#define GSR_EXTRA_DEPTH 1
+#define GSR_EXTRA_DISPARITY 2
+#define GSR_EXTRA_RELATIVE_DISPARITY 3
+#define GSR_EXTRA_LOG 4
+#define GSR_FLAG_EXTRA_MODE(m) ((m) << 4)
 /* GsrDims.flags bits >= 8 are measurement-only ablation switches (tools/ablate.py): they make results WRONG on purpose
  * to time a kernel without one of its parts.  Never set on the product path. */
 #define GSR_FLAG_ABLATE_NO_COUNT 0x100       /* preprocess: skip the per-tile pair counting atomics */
@@ -67,7 +76,7 @@ typedef struct GsrView {
   float scale;           /* scale-invariant factor s applied on load: mean*s (cuda_splatting.py:70) */
   float scale2;          /* s*s computed by the caller in fp32: cov*s2 (cuda_splatting.py:69) */
   float scale_modifier;  /* upstream scale_modifier (only with scales/rotations; 1.0) */
-  float reserved[5];
+  float reserved[5];     /* [0], [1]: un-normalised near / far of the view (used by GSR_EXTRA_RELATIVE_DISPARITY / _LOG) */
 } GsrView;
 
 typedef struct GsrDims {

@@ -212,6 +212,23 @@ __device__ __forceinline__ void load_cov6(const float* cov, size_t gi, bool c9, 
   }
 }
 
+// Built-in extra channel (GsrDims.flags bits 4-6, GSR_EXTRA_*): the scalar the reference's depth render blends
+// (cuda_splatting.py:238-251) - camera-space z in UN-normalised units (z_scaled / scale), mapped by the mode - and its
+// derivative w.r.t. z for the backward chain.  near/far are the caller's un-normalised values (GsrView.near/far).
+__device__ __forceinline__ float extra_from_depth(int mode, float z, float nr, float fr, float& dfdz) {
+  const float eps = 1e-10f;
+  if (mode == GSR_EXTRA_DEPTH) { dfdz = 1.f; return z; }
+  if (mode == GSR_EXTRA_DISPARITY) { const float r = 1.f / z; dfdz = -r * r; return r; }
+  if (mode == GSR_EXTRA_RELATIVE_DISPARITY) {  // depth_to_relative_disparity, conversions.py:17-27
+    const float dn = 1.f / (nr + eps), df = 1.f / (fr + eps), d = 1.f / (z + eps);
+    const float k = 1.f / (dn - df + eps);
+    dfdz = d * d * k;
+    return 1.f - (d - df) * k;
+  }
+  dfdz = 0.f;  // GSR_EXTRA_LOG: the reference's min(near).max(far).log() is the constant log(far) (cuda_splatting.py:251)
+  return logf(fmaxf(fminf(z, nr), fr));
+}
+
 // EWA projection pieces shared by forward and backward ([EXT] forward.cu computeCov2D);
 // same expression trees as oracle cov2d_parts.
 struct Cov2D {
@@ -439,7 +456,12 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   const int radius = vis ? (int)my_radius : 0;
   p.radii[oi] = radius;
   GeomRec rec;
-  const float ex = (vis && p.d.has_extra) ? p.extra[oi] : 0.f;
+  const int emode = (p.d.flags >> 4) & 7;
+  float ex = 0.f;
+  if (vis && p.d.has_extra) {
+    float dfdz;
+    ex = emode == 0 ? p.extra[oi] : extra_from_depth(emode, pvz / cam.scale, cam.reserved[0], cam.reserved[1], dfdz);
+  }
   rec.q0 = vis ? make_float4(px, py, conA, conB) : make_float4(0, 0, 0, 0);
   rec.q1 = vis ? make_float4(conC, op, 0.f, 0.f) : make_float4(0, 0, 0, 0);
   rec.q2 = make_float4(0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius));
@@ -1396,6 +1418,14 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) dmean[j] += dm[j] * cam.scale;
+    const int emode = (p.d.flags >> 4) & 7;
+    if (emode != 0 && p.d.has_extra) {  // built-in extra channel: dL/dextra flows to the mean through z (un-normalised units)
+      const float z = (vw[2] * mx + vw[6] * my + vw[10] * mz + vw[14]) / cam.scale;
+      float dfdz;
+      (void)extra_from_depth(emode, z, cam.reserved[0], cam.reserved[1], dfdz);
+      const float gz = sg[9] * dfdz;
+      dmean[0] += gz * vw[2]; dmean[1] += gz * vw[6]; dmean[2] += gz * vw[10];
+    }
 #pragma unroll
     for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
   }
@@ -1501,8 +1531,9 @@ __global__ void k_setup_views(int V, const float* ext, const float* intr, const 
   o.tanfovx = tx; o.tanfovy = ty;
   o.bg[0] = bg[bg_stride * v + 0]; o.bg[1] = bg[bg_stride * v + 1]; o.bg[2] = bg[bg_stride * v + 2];
   o.scale = s; o.scale2 = s * s; o.scale_modifier = 1.f;
+  o.reserved[0] = near_[v]; o.reserved[1] = far_[v];  // un-normalised near / far (built-in relative-disparity / log extra channel)
 #pragma unroll
-  for (int i = 0; i < 5; ++i) o.reserved[i] = 0.f;
+  for (int i = 2; i < 5; ++i) o.reserved[i] = 0.f;
   out[v] = o;
 }
 
@@ -1628,7 +1659,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const size_t V = d.num_views, N = d.num_gaussians, HW = (size_t)d.height * d.width;
   if (V == 0) return GSR_OK;
   if (!views || !out_color || !bin || !img) return GSR_ERR_INVALID_ARGUMENT;
-  if (d.has_extra && (!extra || !out_extra)) return GSR_ERR_INVALID_ARGUMENT;
+  if (d.has_extra && ((!extra && ((d.flags >> 4) & 7) == 0) || !out_extra)) return GSR_ERR_INVALID_ARGUMENT;
   Params p = base_params(dims, views, means, cov6, opacities, colors, extra, geom, bin, img);
   p.out_color = out_color; p.out_extra = out_extra; p.radii = radii;
   const Layout L = make_layout(d);

@@ -22,6 +22,7 @@ from torch import Tensor, nn
 from . import _lib
 
 VIEW_FLOATS = 48  # sizeof(GsrView) / 4
+EXTRA_MODES = {"depth": 1, "disparity": 2, "relative_disparity": 3, "log": 4}  # GSR_EXTRA_* (include/gsr.h)
 
 
 class GaussianRasterizationSettings(NamedTuple):
@@ -55,11 +56,13 @@ class RasterConfig:
 
 
 def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx: Tensor, tanfovy: Tensor,
-               bg: Tensor, scale: Optional[Tensor] = None, scale_modifier: float = 1.0) -> Tensor:
+               bg: Tensor, scale: Optional[Tensor] = None, scale_modifier: float = 1.0, near: Optional[Tensor] = None,
+               far: Optional[Tensor] = None) -> Tensor:
     """Pack V cameras into the (V, 48) fp32 `GsrView` array (include/gsr.h) on the inputs' device.
 
     viewmatrix/projmatrix are the transposed matrices exactly as the reference passes them
-    (cuda_splatting.py:85-87, 106-107); `scale` is the scale-invariant factor of :64-71 (None = 1).
+    (cuda_splatting.py:85-87, 106-107); `scale` is the scale-invariant factor of :64-71 (None = 1); `near`/`far` are the
+    un-normalised clip distances (only read by the built-in relative-disparity / log extra channel).
     """
     v = viewmatrix.shape[0]
     dev = viewmatrix.device
@@ -71,7 +74,9 @@ def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx: 
         viewmatrix.to(f32).reshape(v, 16), projmatrix.to(f32).reshape(v, 16), campos.to(f32).reshape(v, 3),
         tanfovx.to(f32).reshape(v, 1), tanfovy.to(f32).reshape(v, 1), bg.to(f32).reshape(v, 3),
         scale, scale * scale, torch.full((v, 1), float(scale_modifier), dtype=f32, device=dev),
-        torch.zeros((v, 5), dtype=f32, device=dev),
+        (near.to(f32).reshape(v, 1) if near is not None else torch.zeros((v, 1), dtype=f32, device=dev)),
+        (far.to(f32).reshape(v, 1) if far is not None else torch.zeros((v, 1), dtype=f32, device=dev)),
+        torch.zeros((v, 3), dtype=f32, device=dev),
     ]
     out = torch.cat(parts, dim=1).contiguous()
     assert out.shape == (v, VIEW_FLOATS)
@@ -248,7 +253,7 @@ class HipBackend:
                     d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
                     d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=dev),
                     d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
-                    d_extra=torch.empty((v, n), dtype=f32, device=dev) if cfg.has_extra else None,
+                    d_extra=torch.empty((v, n), dtype=f32, device=dev) if (cfg.has_extra and not (cfg.flags >> 4) & 7) else None,
                     d_means2d=torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None)
         if n > 0 and v > 0:
             g_color = g_color.contiguous().to(f32)
@@ -332,6 +337,8 @@ class _RasterizeViews(torch.autograd.Function):
         cfg = ctx.cfg
         if not cfg.has_extra:
             extra, g_extra_img = None, None
+        elif (cfg.flags >> 4) & 7:
+            extra = None  # built-in mode: no extra array; its gradient is folded into d_means by the backward kernel
         if g_color is None:
             g_color = torch.zeros((cfg.num_views, 3, cfg.height, cfg.width), dtype=torch.float32, device=means.device)
         d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
@@ -342,12 +349,14 @@ class _RasterizeViews(torch.autograd.Function):
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
                     image_shape, sh_degree: int, use_sh: bool, views_per_set: int, extra: Optional[Tensor] = None,
-                    means2d: Optional[Tensor] = None, max_sh_eval: int = 4, sh_planar: bool = False, cov_3x3: bool = False):
+                    means2d: Optional[Tensor] = None, max_sh_eval: int = 4, sh_planar: bool = False, cov_3x3: bool = False,
+                    extra_mode: Optional[str] = None):
     """Render V = num_sets * views_per_set views in one launch chain.
 
     means (S,N,3); cov6 (S,N,6) or, with cov_3x3, the full symmetric (S,N,3,3); opacities (S,N); colors (S,N,M,3) or, with
     sh_planar, PF3plat's harmonics layout (S,N,3,M) if use_sh else (S,N,3); viewbuf (V,48) from `pack_views` / the backend's
-    `setup_views` (set-major); extra (V,N) optional 4th blended channel.
+    `setup_views` (set-major); extra (V,N) optional 4th blended channel, or extra_mode in {"depth", "disparity",
+    "relative_disparity", "log"} to blend the reference's depth-render scalar f(z) computed inside the kernels.
     Returns (color (V,3,H,W), extra_img (V,H,W) | None, radii (V,N) int32).  Differentiable w.r.t. means, cov6, opacities,
     colors, extra (gradients come back in the layouts given; means2d receives the screen-space gradient); cameras get none,
     like the reference operator.
@@ -370,9 +379,14 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
         raise ValueError(f"covariances have shape {tuple(cov6.shape)}; expected (sets, N, {'3, 3' if cov_3x3 else '6'})")
     m = (colors.shape[3] if sh_planar else colors.shape[2]) if use_sh else 0
     flags = (_lib.FLAG_SH_PLANAR if (sh_planar and use_sh) else 0) | (_lib.FLAG_COV_3X3 if cov_3x3 else 0)
-    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), extra is not None, flags)
+    if extra_mode is not None:
+        if extra is not None:
+            raise ValueError("give either `extra` or `extra_mode`")
+        flags |= EXTRA_MODES[extra_mode] << 4
+    has_extra = extra is not None or extra_mode is not None
+    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags)
     color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg)
-    return color, (extra_img if extra is not None else None), radii
+    return color, (extra_img if has_extra else None), radii
 
 
 def _cov3d_from_scale_rotation(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:

@@ -62,7 +62,7 @@ def _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invarian
             return backend.setup_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
         view_matrix, full_projection, campos, tan_x, tan_y, scale = _cameras(extrinsics, intrinsics, near, far, scale_invariant)
         bg = background_color if background_color.dim() == 2 else background_color.reshape(1, 3).expand(extrinsics.shape[0], 3)
-        return pack_views(view_matrix, full_projection, campos, tan_x, tan_y, bg, scale)
+        return pack_views(view_matrix, full_projection, campos, tan_x, tan_y, bg, scale, near=near, far=far)
 
 
 def render_cuda(
@@ -173,15 +173,18 @@ def render_depth_cuda(
 ) -> Tensor:  # (batch, height, width)
     """Depth image = sum_i f(z_i) alpha_i T_i (reference :226-269).  The reference renders f(z) as a
     3-channel precomputed colour and averages the channels; the three channels are identical, so it
-    is blended here once, as the extra channel of a colour-less pass."""
-    fake_color = depth_fake_color(extrinsics, gaussian_means, near, far, mode)
-    b, g = fake_color.shape
-    bg = torch.zeros((b, 3), dtype=torch.float32, device=fake_color.device)
+    is blended here once, as the extra channel of a colour-less pass, with f(z) (`depth_fake_color`
+    below states it in torch) evaluated inside the kernels.  Gaussians receive the same gradients as in
+    the reference; the (unused) gradient the reference's torch graph sends to `extrinsics` through
+    `extrinsics.inverse()` is not produced."""
+    b, g = gaussian_opacities.shape
+    dev = gaussian_means.device
+    bg = torch.zeros((b, 3), dtype=torch.float32, device=dev)
     viewbuf = _viewbuf(extrinsics, intrinsics, near, far, bg, scale_invariant)
-    zero_rgb = torch.zeros((b, g, 3), dtype=torch.float32, device=fake_color.device)
+    zero_rgb = torch.zeros((b, g, 3), dtype=torch.float32, device=dev)
     _, depth, _ = rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, zero_rgb, viewbuf,
-        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=1, extra=fake_color, cov_3x3=True)
+        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=1, extra_mode=mode, cov_3x3=True)
     return depth
 
 
@@ -209,14 +212,10 @@ def render_views(
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
     viewbuf = _viewbuf(ext, intr, nr, fr, background_color.reshape(3), scale_invariant)
-    extra = None
-    if depth_mode is not None:
-        g = gaussian_means.shape[1]
-        means_rep = gaussian_means[:, None].expand(s, v, g, 3).reshape(s * v, g, 3)
-        extra = depth_fake_color(ext, means_rep, nr, fr, depth_mode)
     color, depth, _ = rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, viewbuf,
-        image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra=extra, sh_planar=True, cov_3x3=True)
+        image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra_mode=depth_mode, sh_planar=True,
+        cov_3x3=True)
     h, w = image_shape
     color = color.reshape(s, v, 3, h, w)
     if depth is not None:

@@ -29,7 +29,23 @@ class OracleBackend:
     def _view_fields(self, viewbuf, v):
         vb = viewbuf[v].detach().cpu().numpy().astype(np.float32)
         return dict(viewmatrix=vb[0:16], projmatrix=vb[16:32], campos=vb[32:35], tanfovx=vb[35], tanfovy=vb[36],
-                    bg=vb[37:40], scale=vb[40], scale2=vb[41], scale_modifier=vb[42])
+                    bg=vb[37:40], scale=vb[40], scale2=vb[41], scale_modifier=vb[42], near=vb[43], far=vb[44])
+
+    @staticmethod
+    def _extra_from_depth(mode, f, m_scaled):
+        """Built-in extra channel (GSR_EXTRA_*): f(z) of the camera-space depth in un-normalised units, and f'(z)."""
+        vm = f["viewmatrix"]
+        z = ((vm[2] * m_scaled[:, 0] + vm[6] * m_scaled[:, 1] + vm[10] * m_scaled[:, 2] + vm[14]) / np.float32(f["scale"])).astype(np.float32)
+        eps = np.float32(1e-10)
+        if mode == 1:
+            return z, np.ones_like(z)
+        if mode == 2:
+            return 1 / z, -1 / (z * z)
+        if mode == 3:
+            dn, df, d = 1 / (f["near"] + eps), 1 / (f["far"] + eps), 1 / (z + eps)
+            k = 1 / (dn - df + eps)
+            return (1 - (d - df) * k).astype(np.float32), (d * d * k).astype(np.float32)
+        return np.log(np.maximum(np.minimum(z, f["near"]), f["far"])).astype(np.float32), np.zeros_like(z)
 
     @staticmethod
     def _canon(cfg, cov6, colors):
@@ -55,10 +71,16 @@ class OracleBackend:
             m = (means[s].detach().cpu().numpy().astype(np.float32) * np.float32(f["scale"]))
             c = (cov6[s].detach().cpu().numpy().astype(np.float32) * np.float32(f["scale2"]))
             col = colors[s].detach().cpu().numpy()
+            emode = (cfg.flags >> 4) & 7
+            if emode:
+                ex_v, dfdz = self._extra_from_depth(emode, f, m)
+                f["dfdz"] = dfdz
+            else:
+                ex_v = None if extra is None else extra[v].detach().cpu().numpy()
             kw = dict(height=H, width=W, tanfovx=float(f["tanfovx"]), tanfovy=float(f["tanfovy"]), bg=f["bg"],
                       viewmatrix=f["viewmatrix"], projmatrix=f["projmatrix"], campos=f["campos"],
                       sh_degree=cfg.sh_degree, means3D=m, opacities=opac[s].detach().cpu().numpy(), cov3D_precomp=c,
-                      extra=None if extra is None else extra[v].detach().cpu().numpy())
+                      extra=ex_v)
             if cfg.sh_coeffs > 0:
                 kw["shs"] = col
             else:
@@ -88,7 +110,8 @@ class OracleBackend:
         d_cov6 = torch.zeros((S, N, 6), dtype=tdt)
         d_opac = torch.zeros((S, N), dtype=tdt)
         d_colors = torch.zeros(tuple(colors.shape), dtype=tdt)
-        d_extra = torch.zeros((V, N), dtype=tdt) if cfg.has_extra else None
+        emode = (cfg.flags >> 4) & 7
+        d_extra = torch.zeros((V, N), dtype=tdt) if (cfg.has_extra and not emode) else None
         d_m2d = torch.zeros((V, N, 3), dtype=tdt) if want_means2d else None
         for v in range(V):
             s = v // cfg.views_per_set
@@ -99,7 +122,11 @@ class OracleBackend:
             d_cov6[s] += torch.from_numpy(g["cov3D_precomp"]) * float(f["scale2"])
             d_opac[s] += torch.from_numpy(g["opacities"])
             d_colors[s] += torch.from_numpy(g["colors"])
-            if cfg.has_extra:
+            if cfg.has_extra and emode:
+                vm = f["viewmatrix"]
+                gz = torch.from_numpy(np.asarray(g["extra"] * f["dfdz"]))
+                d_means[s] += gz[:, None] * torch.tensor([vm[2], vm[6], vm[10]], dtype=tdt)[None, :]
+            elif cfg.has_extra:
                 d_extra[v] = torch.from_numpy(g["extra"])
             if want_means2d:
                 d_m2d[v] = torch.from_numpy(g["means2D"])

@@ -109,3 +109,29 @@ def test_mark_visible_and_empty_scene(oracle_backend):
     img, radii = r(means3D=torch.zeros(0, 3), means2D=torch.zeros(0, 3), opacities=torch.zeros(0, 1), colors_precomp=torch.zeros(0, 3),
                    cov3D_precomp=torch.zeros(0, 6))
     assert img.shape == (3, 8, 8) and radii.shape == (0,) and torch.all(img == 0)
+
+
+@pytest.mark.parametrize("mode", ["depth", "disparity", "relative_disparity", "log"])
+def test_builtin_depth_channel_equals_explicit_fake_colour(oracle_backend, mode):
+    """extra_mode (f(z) evaluated by the operator, gradient folded into d_means) == the reference's formulation: f(z) as an
+    explicit torch tensor (depth_fake_color, cuda_splatting.py:238-251) blended as an extra array, autograd doing the chain."""
+    from pf3plat_amd.rasterizer import rasterize_views
+    from pf3plat_amd.splatting import _viewbuf, depth_fake_color
+
+    sc = synthetic.make_scene(6, 200, (16, 20), num_views=2, near=1.7)
+    ext, intr, nr, fr = sc.extrinsics[0], sc.intrinsics[0], sc.near[0], sc.far[0]
+    w = torch.rand((2, 16, 20), generator=torch.Generator().manual_seed(2))
+    outs = []
+    for builtin in (True, False):
+        m, c, h, o = _leaves(sc, 2)
+        vb = _viewbuf(ext, intr, nr, fr, torch.zeros(3), True)
+        kw = dict(image_shape=(16, 20), sh_degree=0, use_sh=False, views_per_set=1, cov_3x3=True)
+        zero = torch.zeros((2, 200, 3))
+        if builtin:
+            _, d, _ = rasterize_views(m, c, o, zero, vb, extra_mode=mode, **kw)
+        else:
+            _, d, _ = rasterize_views(m, c, o, zero, vb, extra=depth_fake_color(ext, m, nr, fr, mode), **kw)
+        (d * w).sum().backward()
+        outs.append((d.detach().numpy(), m.grad.numpy(), c.grad.numpy(), o.grad.numpy()))
+    for a, b, name in zip(outs[0], outs[1], ("depth", "d_means", "d_cov", "d_opac")):
+        assert rel_l2(a, b) < 5e-5, (mode, name, rel_l2(a, b))
