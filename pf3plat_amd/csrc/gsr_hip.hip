@@ -938,6 +938,18 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
   const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
 
+  if (p.status->overflow) {  // pair workspace too small: nothing was binned.  Poison the outputs so the condition cannot go
+    if (wave == 0 && inside) {  // unnoticed even when the caller defers reading the status block.
+      const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
+      const float qnan = __uint_as_float(0x7fc00000u);
+      float* oc = p.out_color + (size_t)v * 3 * HW;
+      oc[pix] = qnan; oc[HW + pix] = qnan; oc[2 * HW + pix] = qnan;
+      if (kExtra) p.out_extra[(size_t)v * HW + pix] = qnan;
+      p.final_T[(size_t)v * HW + pix] = 1.f;
+      p.n_contrib[(size_t)v * HW + pix] = 0u;
+    }
+    return;
+  }
   float T = 1.f, Tf = inside ? 1.f : 0.f;      // scan wave: reported / free-running transmittance
   float C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;  // helper waves: partial colour sums
   uint32_t last = 0, consumed = 0;

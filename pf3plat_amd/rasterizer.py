@@ -98,8 +98,9 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self.capacity_hint = {}  # (V, N, H, W) -> pairs needed last time
-        self.defer_status = False  # True: never read the status block back (caller checks later)
-        self.pending = []  # status tensors not yet checked (deferred mode)
+        self.sync_policy = "lazy"  # or "sync": see forward()
+        self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
+        self.pending = []  # (pinned status copy, event, shape key) of lazy forwards not yet verified
         self.last_status = None
 
     @staticmethod
@@ -211,36 +212,60 @@ class HipBackend:
 
     # ---- autograd-facing calls: fresh outputs/workspaces per call, kept alive for backward
     def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None):
+        """Pair-count policy (`self.sync_policy`):
+        "sync"  - read the 16-byte status block back after every call (one host sync, as the reference extension does) and
+                  retry with the exact size on overflow;
+        "lazy"  - (default) do that only the first time a (views, N, H, W) shape is seen; afterwards size the workspace at
+                  1.25x the last known pair count, copy the status block asynchronously and verify it at the next call
+                  (or `check_pending()`).  A workspace that turns out too small poisons that call's image with NaN
+                  (k_blend_fwd) and raises at verification - it cannot pass silently."""
         self._check_device(viewbuf, means, cov6, opac, colors, extra)
+        self.check_pending()
         dev = viewbuf.device
         v, h, w, n = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians
+        key = (v, n, h, w)
+        lazy = (self.sync_policy == "lazy" and capacity is None and key in self.capacity_hint) or self.defer_status
         cap = self._default_capacity(cfg) if capacity is None else int(capacity)
         for attempt in range(3):
             plan = self.make_plan(cfg, dev, cap)
             self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra)
             saved = (plan["dims"], plan["geom"], plan["bin"], plan["img"])
             out = (plan["color"], plan["extra_img"], plan["radii"], saved)
-            if self.defer_status or n == 0 or v == 0:
-                if n > 0 and v > 0:
-                    self.pending.append(plan["bin"][:16])
+            if n == 0 or v == 0:
                 return out
-            # one small D2H read (the reference extension also reads its pair count back to the host)
+            if lazy:
+                host = torch.empty(16, dtype=torch.uint8, pin_memory=True)
+                host.copy_(plan["bin"][:16], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                self.pending.append((host, ev, key))
+                return out
             self.last_status = st = self.read_status(plan)
-            self.capacity_hint[(v, n, h, w)] = st["num_pairs"]
+            self.capacity_hint[key] = st["num_pairs"]
             if not st["overflow"]:
                 return out
             cap = int(st["num_pairs"] * 1.05) + 4096
         raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
 
-    def check_pending(self):
-        """Deferred mode: verify that no forward since the last check overflowed its pair workspace."""
-        bad = 0
-        for s in self.pending:
-            st = s.cpu()
-            bad += int(st[8:12].view(torch.int32).item())
-        self.pending = []
-        if bad:
-            raise RuntimeError(f"{bad} deferred gsr_forward call(s) overflowed the pair workspace; results invalid")
+    def check_pending(self, wait: bool = False):
+        """Verify the status blocks of earlier lazy/deferred forwards (those whose async copy has landed; all if `wait`)."""
+        keep = []
+        for host, ev, key in self.pending:
+            if wait:
+                ev.synchronize()
+            elif not ev.query():
+                keep.append((host, ev, key))
+                continue
+            num_pairs = int(host[:8].view(torch.int64).item())
+            overflow = int(host[8:12].view(torch.int32).item())
+            self.last_status = {"num_pairs": num_pairs, "overflow": overflow, "max_list": int(host[12:16].view(torch.int32).item())}
+            self.capacity_hint[key] = max(num_pairs, 1)
+            if overflow:
+                self.pending = [p for p in self.pending if p[0] is not host]
+                raise RuntimeError(
+                    f"an earlier gsr_forward needed {num_pairs} pairs but its workspace was smaller; that call's image was "
+                    "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync').")
+        self.pending = keep
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
                  want_means2d: bool):

@@ -194,7 +194,7 @@ def test_setup_views_kernel_matches_reference_camera_arithmetic():
     for si in (True, False):
         got = be.setup_views(ext.to(DEV), intr.to(DEV), near.to(DEV), far.to(DEV), bg.to(DEV), si).cpu()
         vm, fp, cp, tx, ty, sc = _cameras(ext, intr, near, far, si)
-        want = pack_views(vm, fp, cp, tx, ty, bg, sc)
+        want = pack_views(vm, fp, cp, tx, ty, bg, sc, near=near, far=far)
         np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
     one_bg = be.setup_views(ext.to(DEV), intr.to(DEV), near.to(DEV), far.to(DEV), bg[0].to(DEV), True).cpu()
     assert torch.allclose(one_bg[:, 37:40], bg[0].expand(v, 3))

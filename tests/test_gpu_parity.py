@@ -219,3 +219,29 @@ def test_forward_is_deterministic_and_backward_nearly():
     for k in ("means", "cov6", "opac", "colors"):
         d = np.abs(a["hip"]["grads"][k] - b["hip"]["grads"][k]).max()
         assert d <= 1e-5 * np.abs(a["hip"]["grads"][k]).max(), k  # fp32 atomics: order-dependent rounding only
+
+
+def test_lazy_status_policy_poisons_and_raises_on_late_overflow():
+    """Default policy: status read synchronously only the first time a shape is seen, verified asynchronously afterwards.
+    If the pair count then outgrows the 1.25x workspace, that call's image is NaN and the next check raises (never silent)."""
+    from pf3plat_amd import rasterizer
+    from pf3plat_amd.synthetic import scene_operator_inputs, scene_viewbuf
+
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(14, 4000, (64, 64))
+    means, cov6, opac, colors = (t.to(dev) for t in scene_operator_inputs(sc))
+    vb = scene_viewbuf(sc).to(dev)
+    cfg = RasterConfig(1, 1, 1, 4000, 64, 64, 4, 25, 4, False)
+    be = rasterizer.HipBackend()
+    c1, _, _, _ = be.forward(cfg, vb, means, cov6, opac, colors, None)  # first call of this shape: synchronous status
+    n1 = be.last_status["num_pairs"]
+    c2, _, _, _ = be.forward(cfg, vb, means, cov6, opac, colors, None)  # lazy
+    be.check_pending(wait=True)
+    assert torch.equal(c1, c2) and torch.isfinite(c2).all()
+    c3, _, _, _ = be.forward(cfg, vb, means, cov6 * 400.0, opac, colors, None)  # 20x larger footprints: lists no longer fit
+    with pytest.raises(RuntimeError, match="poisoned with NaN"):
+        be.check_pending(wait=True)
+    assert torch.isnan(c3).all()
+    c4, _, _, _ = be.forward(cfg, vb, means, cov6 * 400.0, opac, colors, None)  # hint raised: fits now
+    be.check_pending(wait=True)
+    assert torch.isfinite(c4).all() and be.last_status["num_pairs"] > 1.25 * n1 and not be.last_status["overflow"]
