@@ -81,11 +81,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")  # "gloo": functional test of the N > 1 path on a 1-GPU box
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from pf3plat_amd import synthetic
     from pf3plat_amd.distributed import gather_views
@@ -111,6 +117,7 @@ def main():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -137,28 +144,37 @@ def main():
             graph = None
             torch.cuda.synchronize()
 
-    def timed(fn, k):
+    # N > 1: every rank keeps the K views it renders and ONE fused RCCL all-gather exchanges them at the end of the
+    # timed region (north_star: "all-gather of rendered tiles ... only at the end").  Eager launches (the per-step
+    # destination slot is not capturable in a static graph).
+    views = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def timed(fn, k, keep_views):
         barrier()
         t0 = time.perf_counter()
-        for _ in range(k):
+        for i in range(k):
             fn()
-        if world > 1:
-            keep.append(gather_views(plan["color"]))  # the one exchange step: fused all-gather at the end
+            if keep_views:
+                views[i].copy_(plan["color"][0], non_blocking=True)
+        if keep_views:
+            gathered.append(gather_views(views))  # (world * K, 3, H, W) on every rank
         barrier()
         return time.perf_counter() - t0
 
-    keep = []
+    gathered = []
+    if world > 1:
+        graph = None
     run = (graph.replay if graph is not None else step)
     for _ in range(Wm):
         run()
-    dt = timed(run, K)
+    dt = timed(run, K, world > 1)
     eager_dt = None
     if graph is not None:
         for _ in range(min(Wm, 5)):
             step()
-        eager_dt = timed(step, K)
+        eager_dt = timed(step, K, False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     status = be.read_status(plan)
@@ -172,7 +188,7 @@ def main():
         "config": {"workload": f"configs[1]: {n} Gaussians (SH degree 4, 25 coeffs), 1 view {H}x{W}, fwd-only raster, "
                                "one scene per GPU (seed 2+rank), inputs resident in HBM",
                    "launch": "hip_graph_replay" if graph is not None else "eager",
-                   "parallelism": f"views sharded 1 scene/GPU x{world}" + (", one fused RCCL all-gather of rendered views at the end" if world > 1 else ""),
+                   "parallelism": f"views sharded 1 scene/GPU x{world}" + (f", one fused RCCL all-gather of the {K} x {world} rendered views at the end" if world > 1 else ""),
                    "num_pairs_8x8": status["num_pairs"], "max_tile_list": status["max_list"]},
     }
     if eager_dt is not None:
@@ -266,6 +282,46 @@ def main():
             on = oc.numpy()
             result["parity"] = {"color_rel_l2_vs_oracle": float(np.linalg.norm(hc - on) / np.linalg.norm(on)),
                                 "max_abs": float(np.abs(hc - on).max())}
+        if world == 1:
+            # ---- extras (not the headline): 8 jittered views of the same scene in one launch chain (SURVEY §8d config 2
+            # "batched variant"), and the decoder-level call of BASELINE configs[3] (B=1, G=131072, V=3, colour + depth)
+            try:
+                import pf3plat_amd
+                from pf3plat_amd.types import Gaussians
+
+                offs = torch.randn(8, generator=torch.Generator().manual_seed(8)).mul(0.05).tolist()
+                sc8 = synthetic.make_scene(2, n, (H, W), d_sh=D_SH, num_views=8, view_offsets=offs)
+                vb8 = synthetic.scene_viewbuf(sc8).to(dev)
+                cfg8 = RasterConfig(8, 1, 8, n, H, W, 4, D_SH, 4, False)
+                plan8 = be.make_plan(cfg8, dev, capacity=8 * int(status["num_pairs"] * 1.2))
+                for _ in range(5):
+                    be.run_forward(plan8, vb8, means, cov6, opac, shs)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(40):
+                    be.run_forward(plan8, vb8, means, cov6, opac, shs)
+                torch.cuda.synchronize()
+                t8 = (time.perf_counter() - t0) / 40
+                assert not be.read_status(plan8)["overflow"]
+                result["batched_8_views"] = {"views_per_s": 8 / t8, "ms_per_launch_chain": 1e3 * t8}
+                sc4 = synthetic.make_scene(50, 131072, (H, W), d_sh=D_SH, num_views=3).to(dev)
+                dec = pf3plat_amd.DecoderSplattingCUDA().to(dev)
+                g4 = sc4.gaussians
+                a4 = (sc4.extrinsics, sc4.intrinsics, sc4.near, sc4.far, (H, W))
+                with torch.no_grad():
+                    for _ in range(5):
+                        dec.forward(g4, *a4, depth_mode="depth")
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    for _ in range(40):
+                        dec.forward(g4, *a4, depth_mode="depth")
+                    torch.cuda.synchronize()
+                    t4 = (time.perf_counter() - t0) / 40
+                pf3plat_amd.get_backend().check_pending(wait=True)
+                result["decoder_config4"] = {"workload": "DecoderSplattingCUDA.forward, B=1, G=131072, K=25, V=3, colour+depth",
+                                             "ms_per_call": 1e3 * t4, "views_per_s": 3 / t4}
+            except Exception as e:  # extras must never take the headline line down
+                result["extras_error"] = f"{type(e).__name__}: {e}"
         print(json.dumps(result))
     if world > 1:
         dist.barrier()

@@ -37,6 +37,8 @@ def gather_views(local: Tensor, num_total: int | None = None, group=None) -> Ten
     never gather per view).  Ragged shards (ranks holding different n_local) are padded to the largest shard."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
+    if dist.get_backend(group) == "gloo" and local.is_cuda:  # functional testing of the N > 1 path without RCCL
+        return gather_views(local.cpu(), num_total, group).to(local.device)
     world = dist.get_world_size(group)
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = [torch.zeros_like(n_local) for _ in range(world)]
