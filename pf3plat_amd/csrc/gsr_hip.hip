@@ -679,14 +679,81 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
   }
 }
 
+// With kScan the workgroup computes the list ranges itself (exclusive scan of all V*T tile totals, <= kEmitScanMax of
+// them) instead of reading them from a separate k_tile_scan launch: ~2 us of redundant work per workgroup buys one kernel
+// boundary (~6.5 us at 1024 tiles).  Block (0,0) publishes ranges + status for the kernels that follow.
+constexpr int kEmitScanMax = 8192;
+
+template <bool kScan>
 __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
   __shared__ uint32_t cursor[kTileWindow];
-  if (p.status->overflow) return;
+  __shared__ unsigned long long wtot[kBinThreads / 64];
+  __shared__ uint32_t smax;
   const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T;
   const uint32_t* rowp = p.counts + ((size_t)v * p.rows + row) * T;
-  const uint2* rng = p.ranges + (size_t)v * T;
   const uint32_t cap = (uint32_t)p.d.pair_capacity;
+  if (kScan) {
+    const int VT = p.d.num_views * T;
+    const int per = (VT + kBinThreads - 1) / kBinThreads;  // <= 8
+    const int b = tid * per, e = min(VT, b + per);
+    uint32_t tot[kEmitScanMax / kBinThreads];
+    unsigned long long sum = 0;
+    uint32_t mx = 0;
+#pragma unroll
+    for (int q = 0; q < kEmitScanMax / kBinThreads; ++q) {
+      tot[q] = (q < per && b + q < e) ? p.tile_total[b + q] : 0u;
+      sum += tot[q];
+      mx = max(mx, tot[q]);
+    }
+    // block exclusive scan of the 64-bit per-thread sums: wave scan (shuffles) + 16 wave totals through LDS
+    const int lane = tid & 63, w = tid >> 6;
+    unsigned long long incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, 64);
+      if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    if (tid == 0) smax = 0;
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    unsigned long long basew = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kBinThreads / 64; ++k) {
+      const unsigned long long x = wtot[k];
+      basew += (k < w) ? x : 0ull;
+      total += x;
+    }
+    atomicMax(&smax, mx);
+    const bool overflow = total > (unsigned long long)cap;
+    unsigned long long run = basew + incl - sum;
+    const bool publish = (row == 0 && v == 0);
+    const int lo_t = v * T, hi_t = lo_t + min(T, kTileWindow);  // kScan implies T <= kEmitScanMax <= kTileWindow: one window
+#pragma unroll
+    for (int q = 0; q < kEmitScanMax / kBinThreads; ++q) {
+      const int k = b + q;
+      if (q < per && k < e) {
+        if (publish) p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + tot[q]));
+        if (k >= lo_t && k < hi_t) cursor[k - lo_t] = (uint32_t)run + rowp[k - lo_t];
+        run += tot[q];
+      }
+    }
+    __syncthreads();
+    if (publish && tid == 0) {
+      p.status->num_pairs = total;
+      p.status->overflow = overflow ? 1u : 0u;
+      p.status->max_list = smax;
+    }
+    if (overflow) return;
+    for_each_pair(p, v, row, tid, 0, T, [&](int i, int t, float depth) {
+      const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
+      if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
+        p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)i;
+    });
+    return;
+  }
+  if (p.status->overflow) return;
+  const uint2* rng = p.ranges + (size_t)v * T;
   for (int t0 = 0; t0 < T; t0 += kTileWindow) {
     const int t1 = min(T, t0 + kTileWindow);
     for (int k = tid; k < t1 - t0; k += kBinThreads) cursor[k] = rng[t0 + k].x + rowp[t0 + k];
@@ -1640,7 +1707,7 @@ extern "C" {
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 const char* gsr_build_info(void) {
-  return "gsr_hip gfx950 wave64 tile8x8 chunk2048 sortlds4096 abi1";
+  return "gsr_hip gfx950 wave64 tile8x8 chunk1024 sortlds4096 abi1";
 }
 
 int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes) {
@@ -1707,10 +1774,12 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   GSR_MARK();
   hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 63) / 64)), dim3(1024), 0, st, p);
-  hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
+  const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
+  if (!scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
   GSR_MARK();
   if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));  // long signalled by now: colour ends before the scans do
-  hipLaunchKernelGGL(k_emit, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  if (scan_in_emit) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   GSR_MARK();
   hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
   GSR_MARK();
