@@ -963,8 +963,8 @@ __device__ __forceinline__ float splat_p2(float a2, float b2, float c2, float dx
 // Four waves per workgroup = one per SIMD: with a fifth wave every workgroup puts two waves on the same SIMD and the
 // per-SIMD register file then admits only 3 workgroups per CU (768 of the 1024 tiles of a 256x256 view; measured).
 constexpr int kFwdHelpers = 3;
-constexpr int kFE = 11;                               // entries per helper per batch
-constexpr int kFB = kFE * kFwdHelpers;                // 33 list entries per batch
+constexpr int kFE = 12;                               // entries per helper per batch (3 groups of 4)
+constexpr int kFB = kFE * kFwdHelpers;                // 36 list entries per batch
 constexpr int kFwdThreads = 64 * (1 + kFwdHelpers);   // 256
 
 __device__ __forceinline__ void stage_batch(const GeomRec* geom, const float4* rgbc, uint32_t n, uint32_t base, int lane,
@@ -1074,14 +1074,29 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
       ib = i;
       if (wave == 0) {
         const int xb = i % 3;
-#pragma unroll 4
-        for (int e = 0; e < kFB; ++e) {
-          const float al = sX[xb][e][lane];
-          const float Tn = Tf * (1.f - al);
-          const bool alive = !(Tn < 0.0001f);
-          sX[xb][e][lane] = alive ? al * Tf : 0.f;
-          T = alive ? Tn : T;
-          Tf = Tn;
+        // groups of 4 entries; the LDS reads of the next group are issued before the dependent chain of this one
+        float an[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) an[u] = sX[xb][u][lane];
+#pragma unroll 1
+        for (int e0 = 0; e0 < kFB; e0 += 4) {
+          float al[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) al[u] = an[u];
+          const int en = (e0 + 4 < kFB) ? e0 + 4 : 0;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) an[u] = sX[xb][en + u][lane];
+          float wv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float Tn = Tf * (1.f - al[u]);
+            const bool alive = !(Tn < 0.0001f);
+            wv[u] = alive ? al[u] * Tf : 0.f;
+            T = alive ? Tn : T;
+            Tf = Tn;
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) sX[xb][e0 + u][lane] = wv[u];
         }
         consumed = (i + 1) * kFB;
         const bool all_dead = __all(Tf < 0.0001f);
