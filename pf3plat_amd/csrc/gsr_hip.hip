@@ -1287,7 +1287,9 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
       const float4 d4 = *reinterpret_cast<const float4*>(&sD[slot][e][4 * li]);
       const float4 a = sGeo[ring][e], a2 = sGeo2[ring][e];
       const float wk[4] = {w4.x, w4.y, w4.z, w4.w}, dk[4] = {d4.x, d4.y, d4.z, d4.w};
-      float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
+      // Per pixel only the moments of s = dL/dG * G are accumulated (s, s dx, s dy, s dx^2, s dx dy, s dy^2); the conic enters
+      // after the reduction because dG/ddelx = ln2 (2 a2 gdx + b2 gdy) and dG/ddely = ln2 (2 c2 gdy + b2 gdx) are linear in them.
+      float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
       bool any_valid = false;
       const float dy = a.y - (float)rpy;
 #pragma unroll
@@ -1296,19 +1298,14 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
         any_valid = any_valid || valid;
         const float dx = a.x - (float)(rpx0 + k);
         const float G = __builtin_amdgcn_exp2f(splat_p2(a.z, a.w, a2.x, dx, dy));
-        const float dl = valid ? dk[k] : 0.f;
-        const float dL_dG = a2.y * dl;
-        const float gdx = G * dx, gdy = G * dy;
-        // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
-        const float dG_ddelx = kLn2 * (2.f * a.z * gdx + a.w * gdy);
-        const float dG_ddely = kLn2 * (2.f * a2.x * gdy + a.w * gdx);
-        v0 = __builtin_fmaf(dL_dG * dG_ddelx, hW, v0);
-        v1 = __builtin_fmaf(dL_dG * dG_ddely, hH, v1);
-        const float hg = -0.5f * dL_dG;
-        v2 = __builtin_fmaf(hg * gdx, dx, v2);
-        v3 = __builtin_fmaf(hg * gdx, dy, v3);
-        v4 = __builtin_fmaf(hg * gdy, dy, v4);
-        v5 = __builtin_fmaf(G, dl, v5);
+        const float q = G * (valid ? dk[k] : 0.f);  // G dL/dalpha
+        const float sq = a2.y * q;                  // dL/dG * G
+        const float tx = sq * dx, ty = sq * dy;
+        v5 += q;
+        Sx += tx; Sy += ty;
+        Sxx = __builtin_fmaf(tx, dx, Sxx);
+        Sxy = __builtin_fmaf(tx, dy, Sxy);
+        Syy = __builtin_fmaf(ty, dy, Syy);
         v6 = __builtin_fmaf(wk[k], rg0[k], v6);
         v7 = __builtin_fmaf(wk[k], rg1[k], v7);
         v8 = __builtin_fmaf(wk[k], rg2[k], v8);
@@ -1316,9 +1313,13 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
       }
       const unsigned long long bal = __ballot(any_valid);
       if (((bal >> (16 * row)) & 0xffffull) == 0ull) continue;  // row-uniform: nothing blended from this splat in this tile
-      v0 = row_allreduce(v0); v1 = row_allreduce(v1); v2 = row_allreduce(v2); v3 = row_allreduce(v3); v4 = row_allreduce(v4);
+      Sx = row_allreduce(Sx); Sy = row_allreduce(Sy); Sxx = row_allreduce(Sxx); Sxy = row_allreduce(Sxy); Syy = row_allreduce(Syy);
       v5 = row_allreduce(v5); v6 = row_allreduce(v6); v7 = row_allreduce(v7); v8 = row_allreduce(v8);
       if (has_extra) v9 = row_allreduce(v9);
+      // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
+      const float v0 = hW * kLn2 * (2.f * a.z * Sx + a.w * Sy);
+      const float v1 = hH * kLn2 * (2.f * a2.x * Sy + a.w * Sx);
+      const float v2 = -0.5f * Sxx, v3 = -0.5f * Sxy, v4 = -0.5f * Syy;
       if (li < 10) {
         float val = v0;
         val = li == 1 ? v1 : val; val = li == 2 ? v2 : val; val = li == 3 ? v3 : val; val = li == 4 ? v4 : val;
@@ -1347,15 +1348,28 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
   for (uint32_t it = 0; it < nbat; ++it) {
     if (wave == 0) {
       const int slot = it & 1;
-#pragma unroll 4
-      for (int e = kBB - 1; e >= 0; --e) {
-        const float al = sA[slot][e][lane], cg = sD[slot][e][lane];
-        const float r = __builtin_amdgcn_rcpf(1.f - al);
-        T = T * r;
-        const float w = al * T;
-        sD[slot][e][lane] = __builtin_fmaf(T, cg, -(BgK * r));
-        sA[slot][e][lane] = w;
-        BgK = __builtin_fmaf(w, cg, BgK);
+      // groups of 4 entries, back to front; the LDS reads of the next group are issued before this group's dependent chain
+      float an[4], cn[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { an[u] = sA[slot][kBB - 1 - u][lane]; cn[u] = sD[slot][kBB - 1 - u][lane]; }
+#pragma unroll 1
+      for (int e0 = kBB - 1; e0 >= 0; e0 -= 4) {
+        float al[4], cg[4], wv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { al[u] = an[u]; cg[u] = cn[u]; }
+        const int en = (e0 - 4 >= 0) ? e0 - 4 : kBB - 1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { an[u] = sA[slot][en - u][lane]; cn[u] = sD[slot][en - u][lane]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float r = __builtin_amdgcn_rcpf(1.f - al[u]);
+          T = T * r;
+          wv[u] = al[u] * T;
+          dv[u] = __builtin_fmaf(T, cg[u], -(BgK * r));
+          BgK = __builtin_fmaf(wv[u], cg[u], BgK);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sA[slot][e0 - u][lane] = wv[u]; sD[slot][e0 - u][lane] = dv[u]; }
       }
     } else {
       const bool do_stage = (wave == 1) && (it + 2 < nbat);
@@ -1392,11 +1406,13 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   const int M = p.d.sh_coeffs;
   const int rowf = 3 * M, ldstride = rowf | 1;
   const int cnt = min(64, N - g0);
+  // One LDS buffer of 64 SH rows: it holds the coefficients while the views are walked (the mean gradient needs them),
+  // then each lane zeroes its own row and a second, cheap walk over the views accumulates dL/dsh into it (rows are
+  // private to their lane, so no barrier is needed in between) before the cooperative store.  Half the LDS of an
+  // in + out pair => twice the resident waves for this latency-bound kernel.
   float* sh_in = lds;
-  float* sh_out = lds + 64 * ldstride;
   if (M > 0) {
     stage_rows(sh_in, p.colors + ((size_t)set * N + g0) * rowf, cnt, rowf, ldstride, lane);
-    for (int k = 0; k < rowf; ++k) sh_out[lane * ldstride + k] = 0.f;
     __syncthreads();
   }
   float rmx = 0, rmy = 0, rmz = 0, rcov[6] = {0, 0, 0, 0, 0, 0};
@@ -1490,14 +1506,12 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const uint32_t cl = bits >> 28;
       const float d0 = (cl & 1u) ? 0.f : sg[6], d1 = (cl & 2u) ? 0.f : sg[7], d2 = (cl & 4u) ? 0.f : sg[8];
       const float* sh = sh_in + lane * ldstride;
-      float* dsh = sh_out + lane * ldstride;
       const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
       const int ks = planar ? 1 : 3, cs = planar ? M : 1;
       float ddx = 0, ddy = 0, ddz = 0;
       const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
-      sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
+      sh_visit(deg, x, y, z, [&](int k, float, float bx, float by, float bz) {
         if (k < M) {
-          dsh[k * ks + 0 * cs] += bk * d0; dsh[k * ks + 1 * cs] += bk * d1; dsh[k * ks + 2 * cs] += bk * d2;
           const float sd = sh[k * ks + 0 * cs] * d0 + sh[k * ks + 1 * cs] * d1 + sh[k * ks + 2 * cs] * d2;
           ddx += bx * sd; ddy += by * sd; ddz += bz * sd;
         }
@@ -1537,8 +1551,27 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     if (M == 0) { p.dL_dcolors[3 * gi + 0] = dcol[0]; p.dL_dcolors[3 * gi + 1] = dcol[1]; p.dL_dcolors[3 * gi + 2] = dcol[2]; }
   }
   if (M > 0) {
+    float* dsh = sh_in + lane * ldstride;  // this lane's row: the coefficients are no longer needed
+    for (int k = 0; k < rowf; ++k) dsh[k] = 0.f;
+    const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
+    const int ks = planar ? 1 : 3, cs = planar ? M : 1;
+    const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+    for (int vv = 0; vv < Vs && in_range; ++vv) {
+      const int v = set * Vs + vv;
+      const GsrView& cam = p.views[v];
+      const size_t oi = (size_t)v * N + i;
+      if ((__float_as_uint(p.geom[oi].q2.w) & 0x0fffffffu) == 0) continue;
+      const uint32_t cl = __float_as_uint(p.rgbc[oi].w);
+      const float* sgp = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
+      const float d0 = (cl & 1u) ? 0.f : sgp[6], d1 = (cl & 2u) ? 0.f : sgp[7], d2 = (cl & 4u) ? 0.f : sgp[8];
+      const float ox = rmx * cam.scale - cam.campos[0], oy = rmy * cam.scale - cam.campos[1], oz = rmz * cam.scale - cam.campos[2];
+      const float len = sqrtf(ox * ox + oy * oy + oz * oz);
+      sh_visit(deg, ox / len, oy / len, oz / len, [&](int k, float bk, float, float, float) {
+        if (k < M) { dsh[k * ks + 0 * cs] += bk * d0; dsh[k * ks + 1 * cs] += bk * d1; dsh[k * ks + 2 * cs] += bk * d2; }
+      });
+    }
     __syncthreads();
-    unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_out, cnt, rowf, ldstride, lane);
+    unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_in, cnt, rowf, ldstride, lane);
   }
 }
 
@@ -1863,7 +1896,7 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
-  const size_t shmem = d.sh_coeffs > 0 ? (size_t)2 * 64 * ldstride * sizeof(float) : 0;
+  const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
   hipLaunchKernelGGL(k_preprocess_bwd, dim3((unsigned)((N + 63) / 64), (unsigned)d.num_sets), dim3(64), shmem, st, p);
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipGetLastError());
