@@ -410,11 +410,10 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
 // ------------------------------------------------------------------------------------------------
 constexpr int kPreThreads = 256;
 
-__global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
-  const int v = blockIdx.y;
+// Everything preprocess does for Gaussian i of view v; `hit(tile)` is called once per (8x8 tile, splat) pair it lists.
+template <class F>
+__device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&& hit) {
   const int N = p.d.num_gaussians;
-  const int i = blockIdx.x * kPreThreads + threadIdx.x;
-  if (i >= N) return;
   const int set = v / p.d.views_per_set;
   const GsrView& cam = p.views[v];
   const Grid& g = p.g;
@@ -472,15 +471,48 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
     if (f.sx1 > f.sx0 && f.sy1 > f.sy0) {
       origin = (uint32_t)f.sx0 | ((uint32_t)f.sy0 << 12);
       if (f.sx1 - f.sx0 <= 8 && f.sy1 - f.sy0 <= 8) {
-        for (int sy = f.sy0; sy < f.sy1; ++sy) mask |= (unsigned long long)row_hit_bits(f, sy, g) << ((sy - f.sy0) * 8);
+        for (int sy = f.sy0; sy < f.sy1; ++sy) {
+          uint32_t bits = row_hit_bits(f, sy, g);
+          mask |= (unsigned long long)bits << ((sy - f.sy0) * 8);
+          while (bits) {
+            const int bpos = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            hit(sy * g.sgx + f.sx0 + bpos);
+          }
+        }
       } else {
         origin |= 0x80000000u;
+        for (int sy = f.sy0; sy < f.sy1; ++sy)
+          for (int sx = f.sx0; sx < f.sx1; ++sx)
+            if (subtile_hit(f, sx, sy, g)) hit(sy * g.sgx + sx);
       }
     }
   }
   rec.q3 = make_float4(__uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)), __uint_as_float(origin),
                        vis ? pvz : 0.f);
   if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE)) p.geom[oi] = rec;
+}
+
+__global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
+  const int i = blockIdx.x * kPreThreads + threadIdx.x;
+  if (i >= p.d.num_gaussians) return;
+  preprocess_one(p, blockIdx.y, i, [](int) {});
+}
+
+// Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the kChunk Gaussians of
+// one row of the count matrix, histograms their pairs in LDS while it projects them and stores the row at the end -
+// k_count's result without a second pass over the records and without its launch.
+__global__ __launch_bounds__(kBinThreads) void k_preprocess_count(const Params p) {
+  __shared__ uint32_t hist[kTileWindow];
+  const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
+  const int T = p.g.T, N = p.d.num_gaussians;
+  for (int k = tid; k < T; k += kBinThreads) hist[k] = 0;
+  __syncthreads();
+  const int end = min(N, (row + 1) * kChunk);
+  for (int i = row * kChunk + tid; i < end; i += kBinThreads) preprocess_one(p, v, i, [&](int t) { atomicAdd(&hist[t], 1u); });
+  __syncthreads();
+  uint32_t* out = p.counts + ((size_t)v * p.rows + row) * T;
+  for (int k = tid; k < T; k += kBinThreads) out[k] = hist[k];
 }
 
 constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's SH rows (64 * 75 / 4 / 64 = 18.75)
@@ -1816,11 +1848,13 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, ss->stream, p);
     GSR_CHECK(hipEventRecord(ss->join, ss->stream));
   }
-  hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
+  const bool fused_count = p.g.T <= kTileWindow && !(d.flags & GSR_FLAG_ABLATE_NO_COUNT);
+  if (fused_count) hipLaunchKernelGGL(k_preprocess_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   GSR_MARK();
   if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
   GSR_MARK();
-  hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  if (!fused_count) hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 63) / 64)), dim3(1024), 0, st, p);
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
   if (!scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
