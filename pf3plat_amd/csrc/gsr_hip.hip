@@ -882,6 +882,10 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   __shared__ uint32_t red[8];
   uint32_t* cur = hist;
   const int tid = threadIdx.x;
+  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(p.counts) + (size_t)blockIdx.x * 8;
+#define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  GSR_STAMP(0);
   const uint2 rg = p.ranges[blockIdx.x];
   const int n = (int)(rg.y - rg.x);
   if (n == 0) return;
@@ -912,6 +916,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       hi = d > hi ? d : hi;
     }
   }
+  GSR_STAMP(1);
   for (int k = tid; k < kBuckets; k += kSortThreads) hist[k] = 0;
   // block min / max of the depth bits
   hi = wave_max_u32(hi);
@@ -926,13 +931,15 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   for (int q = 0; q < Q; ++q)
     if (tid + q * kSortThreads < n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - lo) >> shift], 1u);
   __syncthreads();
+  GSR_STAMP(2);
   // exclusive scan of the bucket counts: thread t owns buckets 4t .. 4t+3
   const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
   const uint32_t span = c0 + c1 + c2 + c3;
   uint32_t total;
   const uint32_t start = block_exclusive_scan(span, red, tid, total);
   cur[4 * tid] = start; cur[4 * tid + 1] = start + c0; cur[4 * tid + 2] = start + c0 + c1; cur[4 * tid + 3] = start + c0 + c1 + c2;
-  const bool big = __syncthreads_or(span > (uint32_t)kSpanMax) != 0;
+  const bool big = __syncthreads_or(max(max(c0, c1), max(c2, c3)) > (uint32_t)kSpanMax) != 0;
+  GSR_STAMP(3);
   // scatter into bucket order
 #pragma unroll
   for (int q = 0; q < Q; ++q)
@@ -941,19 +948,29 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       sk[slot] = kreg[q];
     }
   __syncthreads();
+  GSR_STAMP(4);
   if (!big) {
-    const int b = (int)start, e = (int)(start + span);
-    for (int i = b + 1; i < e; ++i) {
-      const unsigned long long key = sk[i];
-      int j = i;
-      while (j > b && sk[j - 1] > key) { sk[j] = sk[j - 1]; --j; }
-      sk[j] = key;
+    // finish by ranking: every entry counts the smaller keys of its own bucket (keys are unique: they carry the
+    // Gaussian index) and goes straight to its final slot in the global list.  The loads are independent, unlike
+    // the dependent chain of an insertion sort.  After the scatter cur[b] is the END of bucket b.
+    for (int k = tid; k < n; k += kSortThreads) {
+      const unsigned long long key = sk[k];
+      const uint32_t b = ((uint32_t)(key >> 32) - lo) >> shift;
+      const int bs = b ? (int)cur[b - 1] : 0, be = (int)cur[b];
+      int rank = bs;
+      for (int j = bs; j < be; ++j) rank += sk[j] < key ? 1 : 0;
+      out[rank] = (uint32_t)key;
     }
-  } else {
-    bitonic_block(sk, n, lgnp, tid);
+    GSR_STAMP(5);
+    GSR_STAMP(6);
+    return;
   }
+  bitonic_block(sk, n, lgnp, tid);
   __syncthreads();
+  GSR_STAMP(5);
   for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
+  GSR_STAMP(6);
+#undef GSR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -47,6 +47,12 @@ def main():
     q = lambda x: [round(v, 0) for v in torch.quantile(x, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)).tolist()]
     print("blend_fwd per-tile (cycle counter ticks): start skew", q(t0), "| prologue", q(pro), "| total", q(dur),
           "| ticks per walked entry", q((dur - pro) / walked.clamp(min=1)), "| end-start span", (st[:, 2].max() - st[:, 0].min()).item(), flush=True)
+    sst = plan["bin"][lay["counts"]: lay["counts"] + 1024 * 64].view(torch.int64).reshape(1024, 8).cpu().double() * 0.01
+    names = ["ranges+keys+minmax", "hist", "scan", "scatter", "finish", "store"]
+    base = sst[:, 0].min()
+    print("sort_tiles phases (us, median over tiles; start skew median %.2f): " % torch.median(sst[:, 0] - base).item() +
+          ", ".join(f"{names[k]} {torch.median(sst[:, k + 1] - sst[:, k]).item():.2f}" for k in range(6)) +
+          f" | total median {torch.median(sst[:, 6] - sst[:, 0]).item():.2f} max {(sst[:, 6] - sst[:, 0]).max().item():.2f} | kernel span {(sst[:, 6].max() - base).item():.2f}", flush=True)
     for name, fl in FLAGS.items():
         plan = be.make_plan(cfg, dev, capacity=8 * n)
         plan["dims"].flags = fl
