@@ -588,32 +588,36 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
 //   K4 emit  : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
 // Count and emit walk the same footprints with the same code, so slots match counts exactly.
 // ------------------------------------------------------------------------------------------------
+// Walks the (tile) pairs of one Gaussian from its record's q3 word (hit mask, origin, depth).
+template <class F>
+__device__ __forceinline__ void walk_pairs(const Params& p, const GeomRec* rec, const float4 q3, int i, int t0, int t1, F&& f) {
+  const Grid& g = p.g;
+  const uint32_t origin = __float_as_uint(q3.z);
+  unsigned long long m = ((unsigned long long)__float_as_uint(q3.y) << 32) | __float_as_uint(q3.x);
+  const int sx0 = (int)(origin & 0xfffu), sy0 = (int)((origin >> 12) & 0xfffu);
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int t = (sy0 + (b >> 3)) * g.sgx + sx0 + (b & 7);
+    if (t >= t0 && t < t1) f(i, t, q3.w);
+  }
+  if (origin & 0x80000000u) {  // footprint wider than the 8x8-tile mask window: walk it
+    const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
+    const Foot ft = make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
+    for (int sy = ft.sy0; sy < ft.sy1; ++sy)
+      for (int sx = ft.sx0; sx < ft.sx1; ++sx) {
+        const int t = sy * g.sgx + sx;
+        if (t >= t0 && t < t1 && subtile_hit(ft, sx, sy, g)) f(i, t, q3.w);
+      }
+  }
+}
 template <class F>
 __device__ __forceinline__ void for_each_pair(const Params& p, int v, int row, int tid, int t0, int t1, F&& f) {
   const int N = p.d.num_gaussians;
-  const Grid& g = p.g;
   const int end = min(N, (row + 1) * kChunk);
   for (int i = row * kChunk + tid; i < end; i += kBinThreads) {
     const GeomRec* rec = p.geom + (size_t)v * N + i;
-    const float4 q3 = rec->q3;
-    const uint32_t origin = __float_as_uint(q3.z);
-    unsigned long long m = ((unsigned long long)__float_as_uint(q3.y) << 32) | __float_as_uint(q3.x);
-    const int sx0 = (int)(origin & 0xfffu), sy0 = (int)((origin >> 12) & 0xfffu);
-    while (m) {
-      const int b = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int t = (sy0 + (b >> 3)) * g.sgx + sx0 + (b & 7);
-      if (t >= t0 && t < t1) f(i, t, q3.w);
-    }
-    if (origin & 0x80000000u) {  // footprint wider than the 8x8-tile mask window: walk it
-      const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
-      const Foot ft = make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
-      for (int sy = ft.sy0; sy < ft.sy1; ++sy)
-        for (int sx = ft.sx0; sx < ft.sx1; ++sx) {
-          const int t = sy * g.sgx + sx;
-          if (t >= t0 && t < t1 && subtile_hit(ft, sx, sy, g)) f(i, t, q3.w);
-        }
-    }
+    walk_pairs(p, rec, rec->q3, i, t0, t1, f);
   }
 }
 
@@ -725,19 +729,39 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
   const int T = p.g.T;
   const uint32_t* rowp = p.counts + ((size_t)v * p.rows + row) * T;
   const uint32_t cap = (uint32_t)p.d.pair_capacity;
+  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  unsigned long long* stamp = p.keys + (size_t)cap - (size_t)(blockIdx.x + 1) * 8;
+#define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  GSR_STAMP(0);
   if (kScan) {
     const int VT = p.d.num_views * T;
     const int per = (VT + kBinThreads - 1) / kBinThreads;  // <= 8
     const int b = tid * per, e = min(VT, b + per);
-    uint32_t tot[kEmitScanMax / kBinThreads];
+    const int lo_t = v * T, hi_t = lo_t + min(T, kTileWindow);  // kScan implies T <= kEmitScanMax <= kTileWindow: one window
+    const int N = p.d.num_gaussians, gend = min(N, (row + 1) * kChunk);
+    // every global read of this workgroup is issued up front (tile totals, this row's prefixes, the records of the
+    // Gaussians it will walk) so that one memory latency covers them all
+    uint32_t tot[kEmitScanMax / kBinThreads], rowv[kEmitScanMax / kBinThreads];
+    float4 q3r[kChunk / kBinThreads];
+#pragma unroll
+    for (int q = 0; q < kEmitScanMax / kBinThreads; ++q) {
+      const bool on = q < per && b + q < e;
+      tot[q] = on ? p.tile_total[b + q] : 0u;
+      rowv[q] = (on && b + q >= lo_t && b + q < hi_t) ? rowp[b + q - lo_t] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk / kBinThreads; ++u) {
+      const int i = row * kChunk + tid + u * kBinThreads;
+      q3r[u] = i < gend ? p.geom[(size_t)v * N + i].q3 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     unsigned long long sum = 0;
     uint32_t mx = 0;
 #pragma unroll
     for (int q = 0; q < kEmitScanMax / kBinThreads; ++q) {
-      tot[q] = (q < per && b + q < e) ? p.tile_total[b + q] : 0u;
       sum += tot[q];
       mx = max(mx, tot[q]);
     }
+    GSR_STAMP(1);
     // block exclusive scan of the 64-bit per-thread sums: wave scan (shuffles) + 16 wave totals through LDS
     const int lane = tid & 63, w = tid >> 6;
     unsigned long long incl = sum;
@@ -756,17 +780,20 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
       basew += (k < w) ? x : 0ull;
       total += x;
     }
-    atomicMax(&smax, mx);
+    GSR_STAMP(2);
+    const bool publish = (row == 0 && v == 0);
+    if (publish) {
+      mx = wave_max_u32(mx);
+      if (lane == 0) atomicMax(&smax, mx);
+    }
     const bool overflow = total > (unsigned long long)cap;
     unsigned long long run = basew + incl - sum;
-    const bool publish = (row == 0 && v == 0);
-    const int lo_t = v * T, hi_t = lo_t + min(T, kTileWindow);  // kScan implies T <= kEmitScanMax <= kTileWindow: one window
 #pragma unroll
     for (int q = 0; q < kEmitScanMax / kBinThreads; ++q) {
       const int k = b + q;
       if (q < per && k < e) {
         if (publish) p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + tot[q]));
-        if (k >= lo_t && k < hi_t) cursor[k - lo_t] = (uint32_t)run + rowp[k - lo_t];
+        if (k >= lo_t && k < hi_t) cursor[k - lo_t] = (uint32_t)run + rowv[q];
         run += tot[q];
       }
     }
@@ -777,11 +804,18 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
       p.status->max_list = smax;
     }
     if (overflow) return;
-    for_each_pair(p, v, row, tid, 0, T, [&](int i, int t, float depth) {
-      const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
-      if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
-        p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)i;
-    });
+    GSR_STAMP(3);
+#pragma unroll
+    for (int u = 0; u < kChunk / kBinThreads; ++u) {
+      const int i = row * kChunk + tid + u * kBinThreads;
+      if (i < gend)
+        walk_pairs(p, p.geom + (size_t)v * N + i, q3r[u], i, 0, T, [&](int gi, int t, float depth) {
+          const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
+          if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
+            p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
+        });
+    }
+    GSR_STAMP(4);
     return;
   }
   if (p.status->overflow) return;
@@ -797,6 +831,7 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
     });
     __syncthreads();
   }
+#undef GSR_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------

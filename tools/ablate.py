@@ -53,6 +53,14 @@ def main():
     print("sort_tiles phases (us, median over tiles; start skew median %.2f): " % torch.median(sst[:, 0] - base).item() +
           ", ".join(f"{names[k]} {torch.median(sst[:, k + 1] - sst[:, k]).item():.2f}" for k in range(6)) +
           f" | total median {torch.median(sst[:, 6] - sst[:, 0]).item():.2f} max {(sst[:, 6] - sst[:, 0]).max().item():.2f} | kernel span {(sst[:, 6].max() - base).item():.2f}", flush=True)
+    rows = (n + 2047) // 2048
+    kb = plan["bin"][lay["keys"]: lay["keys"] + (8 * n) * 8].view(torch.int64)
+    est = kb[(8 * n) - rows * 8:].reshape(rows, 8).flip(0).cpu().double() * 0.01
+    names = ["tile totals loaded", "scan", "cursors+ranges", "pair walk"]
+    base = est[:, 0].min()
+    print("emit phases (us, median over row blocks; start skew max %.2f): " % (est[:, 0] - base).max().item() +
+          ", ".join(f"{names[k]} {torch.median(est[:, k + 1] - est[:, k]).item():.2f}" for k in range(4)) +
+          f" | total median {torch.median(est[:, 4] - est[:, 0]).item():.2f} max {(est[:, 4] - est[:, 0]).max().item():.2f} | kernel span {(est[:, 4].max() - base).item():.2f}", flush=True)
     for name, fl in FLAGS.items():
         plan = be.make_plan(cfg, dev, capacity=8 * n)
         plan["dims"].flags = fl
