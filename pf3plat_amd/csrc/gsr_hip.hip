@@ -28,7 +28,9 @@
 
 namespace gsr {
 
-constexpr int kChunk = 2048;      // Gaussians per binning workgroup = one row of the per-view count matrix
+constexpr int kChunkMax = 2048;   // most Gaussians per binning workgroup (= one row of the per-view count matrix)
+constexpr int kChunkMin = 1024;
+constexpr int kCUs = 256;
 constexpr int kBinThreads = 1024; // threads of a binning workgroup (count / emit)
 constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup (32 KiB)
 constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
@@ -70,6 +72,20 @@ struct Layout {
 
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Gaussians per binning workgroup.  The binning kernels are latency/VALU bound per workgroup, so the chip is fullest
+// when one round of workgroups covers all CUs: the chunk (a multiple of 64 in [kChunkMin, kChunkMax]) that minimises
+// rounds x chunk, the larger one on ties (fewer rows in the count matrix).
+static int choose_chunk(const GsrDims& d) {
+  const long long V = d.num_views > 0 ? d.num_views : 1, N = d.num_gaussians > 0 ? d.num_gaussians : 1;
+  long long best_cost = -1;
+  int best = kChunkMax;
+  for (int c = kChunkMax; c >= kChunkMin; c -= 64) {
+    const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + kCUs - 1) / kCUs) * c;
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
+  }
+  return best;
+}
+
 static Layout make_layout(const GsrDims& d) {
   Layout L;
   const Grid g = make_grid(d.width, d.height);
@@ -79,7 +95,7 @@ static Layout make_layout(const GsrDims& d) {
   L.geom_bytes = L.o_rgbc + align_up(V * N * sizeof(float4), 256);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
-  const size_t rows = (N + kChunk - 1) / kChunk;
+  const size_t rows = (N + choose_chunk(d) - 1) / choose_chunk(d);
   L.o_counts = o; o = align_up(o + VT * (rows > 0 ? rows : 1) * 4, 256);
   L.o_total = o; o = align_up(o + VT * 4, 256);
   L.o_ranges = o; o = align_up(o + VT * 8, 256);
@@ -96,7 +112,8 @@ static Layout make_layout(const GsrDims& d) {
 struct Params {
   GsrDims d;
   Grid g;
-  int rows;  // binning chunks per view = ceil(N / kChunk)
+  int rows;   // binning chunks per view = ceil(N / chunk)
+  int chunk;  // Gaussians per binning workgroup (choose_chunk)
   const GsrView* views;
   const float *means, *cov6, *opac, *colors, *extra;
   float* out_color;
@@ -362,6 +379,23 @@ __device__ __forceinline__ uint32_t row_hit_bits(const Foot& f, int sy, const Gr
   return (n >= 32 ? 0xffffffffu : ((1u << n) - 1u)) << (lo - f.sx0);
 }
 
+// Walks of a footprint wider than the mask window: by one lane, or by all 64 lanes of a wave (wave-uniform foot).
+template <class F>
+__device__ __forceinline__ void big_walk_lane(const Foot& ft, const Grid& g, F&& f) {
+  for (int sy = ft.sy0; sy < ft.sy1; ++sy)
+    for (int sx = ft.sx0; sx < ft.sx1; ++sx)
+      if (subtile_hit(ft, sx, sy, g)) f(sy * g.sgx + sx);
+}
+template <class F>
+__device__ __forceinline__ void big_walk_wave(const Foot& ft, const Grid& g, int lane, F&& f) {
+  const int w = ft.sx1 - ft.sx0, cnt = w * (ft.sy1 - ft.sy0);
+  for (int c = lane; c < cnt; c += 64) {
+    const int dy = c / w, sx = ft.sx0 + (c - dy * w), sy = ft.sy0 + dy;
+    if (subtile_hit(ft, sx, sy, g)) f(sy * g.sgx + sx);
+  }
+}
+constexpr int kBigList = 256;  // deferred wide footprints per binning workgroup (more are walked in line)
+
 // Wave-cooperative copy of `cnt` rows of `rowf` floats from global to LDS (row stride ldstride floats).
 __device__ __forceinline__ void stage_rows(float* lds, const float* src, int cnt, int rowf, int ldstride, int lane) {
   const int total = cnt * rowf;
@@ -411,8 +445,9 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
 constexpr int kPreThreads = 256;
 
 // Everything preprocess does for Gaussian i of view v; `hit(tile)` is called once per (8x8 tile, splat) pair it lists.
-template <class F>
-__device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&& hit) {
+// Footprints wider than the 8x8-tile mask window are handed to `big(i, foot)` (the caller walks them).
+template <class F, class B>
+__device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&& hit, B&& big) {
   const int N = p.d.num_gaussians;
   const int set = v / p.d.views_per_set;
   const GsrView& cam = p.views[v];
@@ -471,20 +506,16 @@ __device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&
     if (f.sx1 > f.sx0 && f.sy1 > f.sy0) {
       origin = (uint32_t)f.sx0 | ((uint32_t)f.sy0 << 12);
       if (f.sx1 - f.sx0 <= 8 && f.sy1 - f.sy0 <= 8) {
-        for (int sy = f.sy0; sy < f.sy1; ++sy) {
-          uint32_t bits = row_hit_bits(f, sy, g);
-          mask |= (unsigned long long)bits << ((sy - f.sy0) * 8);
-          while (bits) {
-            const int bpos = __ffs((int)bits) - 1;
-            bits &= bits - 1;
-            hit(sy * g.sgx + f.sx0 + bpos);
-          }
+        for (int sy = f.sy0; sy < f.sy1; ++sy) mask |= (unsigned long long)row_hit_bits(f, sy, g) << ((sy - f.sy0) * 8);
+        unsigned long long m = mask;
+        while (m) {
+          const int b = __ffsll((long long)m) - 1;
+          m &= m - 1;
+          hit((f.sy0 + (b >> 3)) * g.sgx + f.sx0 + (b & 7));
         }
       } else {
         origin |= 0x80000000u;
-        for (int sy = f.sy0; sy < f.sy1; ++sy)
-          for (int sx = f.sx0; sx < f.sx1; ++sx)
-            if (subtile_hit(f, sx, sy, g)) hit(sy * g.sgx + sx);
+        big(i, f);
       }
     }
   }
@@ -496,23 +527,64 @@ __device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   const int i = blockIdx.x * kPreThreads + threadIdx.x;
   if (i >= p.d.num_gaussians) return;
-  preprocess_one(p, blockIdx.y, i, [](int) {});
+  preprocess_one(p, blockIdx.y, i, [](int) {}, [](int, const Foot&) {});
 }
 
-// Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the kChunk Gaussians of
+// Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the `chunk` Gaussians of
 // one row of the count matrix, histograms their pairs in LDS while it projects them and stores the row at the end -
 // k_count's result without a second pass over the records and without its launch.
 __global__ __launch_bounds__(kBinThreads) void k_preprocess_count(const Params p) {
   __shared__ uint32_t hist[kTileWindow];
+  __shared__ float bigs[kBigList][8];
+  __shared__ uint32_t nbig;
   const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T, N = p.d.num_gaussians;
+  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  unsigned long long* stamp = p.keys + (size_t)p.d.pair_capacity - 8192 - (size_t)(blockIdx.x + 1) * 8;
+#define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  GSR_STAMP(0);
   for (int k = tid; k < T; k += kBinThreads) hist[k] = 0;
+  if (tid == 0) nbig = 0;
   __syncthreads();
-  const int end = min(N, (row + 1) * kChunk);
-  for (int i = row * kChunk + tid; i < end; i += kBinThreads) preprocess_one(p, v, i, [&](int t) { atomicAdd(&hist[t], 1u); });
+  GSR_STAMP(1);
+  const int end = min(N, (row + 1) * p.chunk);
+  int it = 2;
+  for (int i = row * p.chunk + tid; i < end; i += kBinThreads) {
+    preprocess_one(p, v, i, [&](int t) { atomicAdd(&hist[t], 1u); },
+                   [&](int, const Foot& f) {
+                     const uint32_t slot = atomicAdd(&nbig, 1u);
+                     if (slot < (uint32_t)kBigList) {
+                       float* b = bigs[slot];
+                       b[0] = f.cx; b[1] = f.cy; b[2] = f.A; b[3] = f.B; b[4] = f.C; b[5] = f.tau;
+                       b[6] = __int_as_float(f.sx0 | (f.sx1 << 16)); b[7] = __int_as_float(f.sy0 | (f.sy1 << 16));
+                     } else {
+                       big_walk_lane(f, p.g, [&](int t) { atomicAdd(&hist[t], 1u); });
+                     }
+                   });
+    GSR_STAMP(it);
+    ++it;
+  }
   __syncthreads();
+  {  // wide footprints: one wave each, 64 candidate tiles per step
+    const int nb = (int)min(nbig, (uint32_t)kBigList), lane = tid & 63;
+    for (int e = tid >> 6; e < nb; e += kBinThreads / 64) {
+      const float* b = bigs[e];
+      Foot f;
+      f.cx = b[0]; f.cy = b[1]; f.A = b[2]; f.B = b[3]; f.C = b[4]; f.tau = b[5];
+      f.nBiC = -f.B / f.C; f.nBiA = -f.B / f.A;
+      const int xs = __float_as_int(b[6]), ys = __float_as_int(b[7]);
+      f.sx0 = xs & 0xffff; f.sx1 = xs >> 16; f.sy0 = ys & 0xffff; f.sy1 = ys >> 16;
+      const float detc = f.A * f.C - f.B * f.B;
+      f.convex = (f.A > 0.f) && (f.C > 0.f) && (detc > 0.f) && (detc < 3.0e38f);
+      big_walk_wave(f, p.g, lane, [&](int t) { atomicAdd(&hist[t], 1u); });
+    }
+  }
+  __syncthreads();
+  GSR_STAMP(4);
   uint32_t* out = p.counts + ((size_t)v * p.rows + row) * T;
   for (int k = tid; k < T; k += kBinThreads) out[k] = hist[k];
+  GSR_STAMP(5);
+#undef GSR_STAMP
 }
 
 constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's SH rows (64 * 75 / 4 / 64 = 18.75)
@@ -580,7 +652,7 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
 
 // ------------------------------------------------------------------------------------------------
 // Binning = counting sort of (8x8 tile, splat) pairs by tile WITHOUT global atomics (device-scope atomics
-// measured ~25 G/s on MI355X: 50 us per pass at 1.25 M pairs).  A workgroup owns a chunk of kChunk Gaussians
+// measured ~25 G/s on MI355X: 50 us per pass at 1.25 M pairs).  A workgroup owns a chunk of `chunk` Gaussians
 // of one view and histograms its pairs per tile in LDS:
 //   K2 count : counts[v][chunk][tile] = pairs of this chunk in this tile        (LDS atomics, coalesced row store)
 //   K3a      : per (v, tile) exclusive scan down the chunk rows, tile totals     (column scan)
@@ -588,9 +660,13 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
 //   K4 emit  : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
 // Count and emit walk the same footprints with the same code, so slots match counts exactly.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Foot foot_of_record(const GeomRec* rec, const Grid& g) {
+  const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
+  return make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
+}
 // Walks the (tile) pairs of one Gaussian from its record's q3 word (hit mask, origin, depth).
-template <class F>
-__device__ __forceinline__ void walk_pairs(const Params& p, const GeomRec* rec, const float4 q3, int i, int t0, int t1, F&& f) {
+template <class F, class B>
+__device__ __forceinline__ void walk_pairs(const Params& p, const float4 q3, int i, int t0, int t1, F&& f, B&& big) {
   const Grid& g = p.g;
   const uint32_t origin = __float_as_uint(q3.z);
   unsigned long long m = ((unsigned long long)__float_as_uint(q3.y) << 32) | __float_as_uint(q3.x);
@@ -601,23 +677,19 @@ __device__ __forceinline__ void walk_pairs(const Params& p, const GeomRec* rec, 
     const int t = (sy0 + (b >> 3)) * g.sgx + sx0 + (b & 7);
     if (t >= t0 && t < t1) f(i, t, q3.w);
   }
-  if (origin & 0x80000000u) {  // footprint wider than the 8x8-tile mask window: walk it
-    const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
-    const Foot ft = make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
-    for (int sy = ft.sy0; sy < ft.sy1; ++sy)
-      for (int sx = ft.sx0; sx < ft.sx1; ++sx) {
-        const int t = sy * g.sgx + sx;
-        if (t >= t0 && t < t1 && subtile_hit(ft, sx, sy, g)) f(i, t, q3.w);
-      }
-  }
+  if (origin & 0x80000000u) big(i);  // footprint wider than the 8x8-tile mask window
 }
 template <class F>
 __device__ __forceinline__ void for_each_pair(const Params& p, int v, int row, int tid, int t0, int t1, F&& f) {
   const int N = p.d.num_gaussians;
-  const int end = min(N, (row + 1) * kChunk);
-  for (int i = row * kChunk + tid; i < end; i += kBinThreads) {
+  const int end = min(N, (row + 1) * p.chunk);
+  for (int i = row * p.chunk + tid; i < end; i += kBinThreads) {
     const GeomRec* rec = p.geom + (size_t)v * N + i;
-    walk_pairs(p, rec, rec->q3, i, t0, t1, f);
+    const float4 q3 = rec->q3;
+    walk_pairs(p, q3, i, t0, t1, f, [&](int) {
+      const Foot ft = foot_of_record(rec, p.g);
+      big_walk_lane(ft, p.g, [&](int t) { if (t >= t0 && t < t1) f(i, t, q3.w); });
+    });
   }
 }
 
@@ -724,7 +796,8 @@ template <bool kScan>
 __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
   __shared__ uint32_t cursor[kTileWindow];
   __shared__ unsigned long long wtot[kBinThreads / 64];
-  __shared__ uint32_t smax;
+  __shared__ uint32_t smax, nbig;
+  __shared__ int bigs[kBigList];
   const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T;
   const uint32_t* rowp = p.counts + ((size_t)v * p.rows + row) * T;
@@ -738,11 +811,11 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
     const int per = (VT + kBinThreads - 1) / kBinThreads;  // <= 8
     const int b = tid * per, e = min(VT, b + per);
     const int lo_t = v * T, hi_t = lo_t + min(T, kTileWindow);  // kScan implies T <= kEmitScanMax <= kTileWindow: one window
-    const int N = p.d.num_gaussians, gend = min(N, (row + 1) * kChunk);
+    const int N = p.d.num_gaussians, gend = min(N, (row + 1) * p.chunk);
     // every global read of this workgroup is issued up front (tile totals, this row's prefixes, the records of the
     // Gaussians it will walk) so that one memory latency covers them all
     uint32_t tot[kEmitScanMax / kBinThreads], rowv[kEmitScanMax / kBinThreads];
-    float4 q3r[kChunk / kBinThreads];
+    float4 q3r[kChunkMax / kBinThreads];
 #pragma unroll
     for (int q = 0; q < kEmitScanMax / kBinThreads; ++q) {
       const bool on = q < per && b + q < e;
@@ -750,8 +823,8 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
       rowv[q] = (on && b + q >= lo_t && b + q < hi_t) ? rowp[b + q - lo_t] : 0u;
     }
 #pragma unroll
-    for (int u = 0; u < kChunk / kBinThreads; ++u) {
-      const int i = row * kChunk + tid + u * kBinThreads;
+    for (int u = 0; u < kChunkMax / kBinThreads; ++u) {
+      const int i = row * p.chunk + tid + u * kBinThreads;
       q3r[u] = i < gend ? p.geom[(size_t)v * N + i].q3 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     unsigned long long sum = 0;
@@ -770,7 +843,7 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
       const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, 64);
       if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
     }
-    if (tid == 0) smax = 0;
+    if (tid == 0) { smax = 0; nbig = 0; }
     if (lane == 63) wtot[w] = incl;
     __syncthreads();
     unsigned long long basew = 0, total = 0;
@@ -805,15 +878,35 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
     }
     if (overflow) return;
     GSR_STAMP(3);
+    auto put = [&](int gi, int t, float depth) {
+      const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
+      if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
+        p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
+    };
 #pragma unroll
-    for (int u = 0; u < kChunk / kBinThreads; ++u) {
-      const int i = row * kChunk + tid + u * kBinThreads;
+    for (int u = 0; u < kChunkMax / kBinThreads; ++u) {
+      const int i = row * p.chunk + tid + u * kBinThreads;
       if (i < gend)
-        walk_pairs(p, p.geom + (size_t)v * N + i, q3r[u], i, 0, T, [&](int gi, int t, float depth) {
-          const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
-          if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
-            p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
+        walk_pairs(p, q3r[u], i, 0, T, put, [&](int gi) {
+          const uint32_t slot = atomicAdd(&nbig, 1u);
+          if (slot < (uint32_t)kBigList) {
+            bigs[slot] = gi;
+          } else {
+            const Foot ft = foot_of_record(p.geom + (size_t)v * N + gi, p.g);
+            big_walk_lane(ft, p.g, [&](int t) { put(gi, t, q3r[u].w); });
+          }
         });
+    }
+    __syncthreads();
+    {  // wide footprints: one wave each, 64 candidate tiles per step
+      const int nb = (int)min(nbig, (uint32_t)kBigList);
+      for (int e = w; e < nb; e += kBinThreads / 64) {
+        const int gi = bigs[e];
+        const GeomRec* rec = p.geom + (size_t)v * N + gi;
+        const Foot ft = foot_of_record(rec, p.g);
+        const float depth = rec->q3.w;
+        big_walk_wave(ft, p.g, lane, [&](int t) { put(gi, t, depth); });
+      }
     }
     GSR_STAMP(4);
     return;
@@ -1781,7 +1874,8 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   Params p{};
   p.d = *d;
   p.g = make_grid(d->width, d->height);
-  p.rows = (d->num_gaussians + kChunk - 1) / kChunk;
+  p.chunk = choose_chunk(*d);
+  p.rows = (d->num_gaussians + p.chunk - 1) / p.chunk;
   p.views = views; p.means = means; p.cov6 = cov6; p.opac = opac; p.colors = colors; p.extra = extra;
   const Layout L = make_layout(*d);
   char* b = static_cast<char*>(bin);
@@ -1911,12 +2005,13 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
   if (!scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
   GSR_MARK();
-  if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));  // long signalled by now: colour ends before the scans do
   if (scan_in_emit) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   GSR_MARK();
   hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
   GSR_MARK();
+  // join: the colour kernel (~22 us alone at 300k x 25 coefficients) has had preprocess + prefix + emit + sort to finish
+  if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));
   if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
   else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
   GSR_MARK();

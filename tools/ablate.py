@@ -53,7 +53,8 @@ def main():
     print("sort_tiles phases (us, median over tiles; start skew median %.2f): " % torch.median(sst[:, 0] - base).item() +
           ", ".join(f"{names[k]} {torch.median(sst[:, k + 1] - sst[:, k]).item():.2f}" for k in range(6)) +
           f" | total median {torch.median(sst[:, 6] - sst[:, 0]).item():.2f} max {(sst[:, 6] - sst[:, 0]).max().item():.2f} | kernel span {(sst[:, 6].max() - base).item():.2f}", flush=True)
-    rows = (n + 2047) // 2048
+    chunk = min(range(2048, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)  # choose_chunk(), V = 1
+    rows = (n + chunk - 1) // chunk
     kb = plan["bin"][lay["keys"]: lay["keys"] + (8 * n) * 8].view(torch.int64)
     est = kb[(8 * n) - rows * 8:].reshape(rows, 8).flip(0).cpu().double() * 0.01
     names = ["tile totals loaded", "scan", "cursors+ranges", "pair walk"]
@@ -61,6 +62,13 @@ def main():
     print("emit phases (us, median over row blocks; start skew max %.2f): " % (est[:, 0] - base).max().item() +
           ", ".join(f"{names[k]} {torch.median(est[:, k + 1] - est[:, k]).item():.2f}" for k in range(4)) +
           f" | total median {torch.median(est[:, 4] - est[:, 0]).item():.2f} max {(est[:, 4] - est[:, 0]).max().item():.2f} | kernel span {(est[:, 4].max() - base).item():.2f}", flush=True)
+    pst = kb[8 * n - 8192 - rows * 8: 8 * n - 8192].reshape(rows, 8).flip(0).cpu().double() * 0.01
+    pst = pst[:-1]
+    names = ["zero hist", "gaussian 1 (wave 0)", "gaussian 2 (wave 0)", "all waves done", "store"]
+    base = pst[:, 0].min()
+    print("preprocess_count phases (us, median over row blocks; start skew max %.2f): " % (pst[:, 0] - base).max().item() +
+          ", ".join(f"{names[k]} {torch.median(pst[:, k + 1] - pst[:, k]).item():.2f}" for k in range(5)) +
+          f" | total median {torch.median(pst[:, 5] - pst[:, 0]).item():.2f} max {(pst[:, 5] - pst[:, 0]).max().item():.2f} | kernel span {(pst[:, 5].max() - base).item():.2f}", flush=True)
     for name, fl in FLAGS.items():
         plan = be.make_plan(cfg, dev, capacity=8 * n)
         plan["dims"].flags = fl
