@@ -23,6 +23,7 @@
 // trees as the fp32 oracle (IEEE +,-,*,/ and sqrt are correctly rounded on both sides).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #include "../../include/gsr.h"
 
@@ -447,7 +448,7 @@ constexpr int kPreThreads = 256;
 // Everything preprocess does for Gaussian i of view v; `hit(tile)` is called once per (8x8 tile, splat) pair it lists.
 // Footprints wider than the 8x8-tile mask window are handed to `big(i, foot)` (the caller walks them).
 template <class F, class B>
-__device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&& hit, B&& big) {
+__device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i, F&& hit, B&& big) {
   const int N = p.d.num_gaussians;
   const int set = v / p.d.views_per_set;
   const GsrView& cam = p.views[v];
@@ -521,20 +522,50 @@ __device__ __forceinline__ void preprocess_one(const Params& p, int v, int i, F&
   }
   rec.q3 = make_float4(__uint_as_float((uint32_t)mask), __uint_as_float((uint32_t)(mask >> 32)), __uint_as_float(origin),
                        vis ? pvz : 0.f);
-  if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE)) p.geom[oi] = rec;
+  return rec;
+}
+
+// The wave's 64 records are 4 KB of consecutive memory.  Written lane by lane they are 16-byte requests at a 64-byte
+// stride - a quarter of what the CU's store path carries per request, which made the record store the longest part of
+// preprocess.  Through a 4 KB per-wave LDS transpose (XOR-swizzled, 2-way conflicts on the write, none on the read)
+// every store instruction covers 1 KB of consecutive bytes instead.  `valid` = records of this wave that exist.
+__device__ __forceinline__ void store_records_wave(GeomRec* dst, int valid, const GeomRec& rec, float4* lds, int lane) {
+  const int sw = (lane >> 1) & 3;
+  lds[lane * 4 + (0 ^ sw)] = rec.q0;
+  lds[lane * 4 + (1 ^ sw)] = rec.q1;
+  lds[lane * 4 + (2 ^ sw)] = rec.q2;
+  lds[lane * 4 + (3 ^ sw)] = rec.q3;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float4* out = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = k * 64 + lane, rr = c >> 2;
+    const float4 x = lds[rr * 4 + ((c & 3) ^ ((rr >> 1) & 3))];
+    if (rr < valid) out[c] = x;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
-  const int i = blockIdx.x * kPreThreads + threadIdx.x;
-  if (i >= p.d.num_gaussians) return;
-  preprocess_one(p, blockIdx.y, i, [](int) {}, [](int, const Foot&) {});
+  __shared__ float4 stage[kPreThreads / 64][256];
+  const int i = blockIdx.x * kPreThreads + threadIdx.x, N = p.d.num_gaussians, v = blockIdx.y;
+  const int lane = threadIdx.x & 63, first = i - lane;
+  if (first >= N) return;
+  GeomRec rec{};
+  if (i < N) rec = preprocess_one(p, v, i, [](int) {}, [](int, const Foot&) {});
+  if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
+    store_records_wave(p.geom + (size_t)v * N + first, N - first, rec, stage[threadIdx.x >> 6], lane);
 }
 
 // Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the `chunk` Gaussians of
 // one row of the count matrix, histograms their pairs in LDS while it projects them and stores the row at the end -
 // k_count's result without a second pass over the records and without its launch.
 __global__ __launch_bounds__(kBinThreads) void k_preprocess_count(const Params p) {
-  __shared__ uint32_t hist[kTileWindow];
+  extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB (record transpose), then T histogram counters
+  uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kBinThreads / 64) * 256);
   __shared__ float bigs[kBigList][8];
   __shared__ uint32_t nbig;
   const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
@@ -549,8 +580,12 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_count(const Params p
   GSR_STAMP(1);
   const int end = min(N, (row + 1) * p.chunk);
   int it = 2;
-  for (int i = row * p.chunk + tid; i < end; i += kBinThreads) {
-    preprocess_one(p, v, i, [&](int t) { atomicAdd(&hist[t], 1u); },
+  float4* stage = dyn_stage + (tid >> 6) * 256;
+  for (int first = row * p.chunk + (tid & ~63); first < end; first += kBinThreads) {  // wave-uniform trip count
+    const int i = first + (tid & 63);
+    GeomRec rec{};
+    if (i < end)
+      rec = preprocess_one(p, v, i, [&](int t) { atomicAdd(&hist[t], 1u); },
                    [&](int, const Foot& f) {
                      const uint32_t slot = atomicAdd(&nbig, 1u);
                      if (slot < (uint32_t)kBigList) {
@@ -561,6 +596,8 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_count(const Params p
                        big_walk_lane(f, p.g, [&](int t) { atomicAdd(&hist[t], 1u); });
                      }
                    });
+    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
+      store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, tid & 63);
     GSR_STAMP(it);
     ++it;
   }
@@ -710,38 +747,57 @@ __global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
   }
 }
 
-// One workgroup = 64 consecutive (view, tile) columns x 16 row groups; two passes over the column (sum, then
-// write exclusive prefixes), partial sums exchanged through LDS.
+// Column prefix of the count matrix.  One workgroup = 16 consecutive (view, tile) columns x 64 row groups (a 64-byte
+// segment of every row), so a 1024-tile image spreads over 64 workgroups; a thread keeps its <= kPrefixRegs rows in
+// registers between the sum and the write-back (one trip to memory), partial sums are exchanged through LDS.
+constexpr int kPrefixRegs = 8;
 __global__ __launch_bounds__(1024) void k_tile_prefix(const Params p) {
-  __shared__ uint32_t part[16][64];
-  const int cx = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  __shared__ uint32_t part[64][17];
+  const int cx = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const size_t VT = (size_t)p.d.num_views * p.g.T;
-  const size_t col = (size_t)blockIdx.x * 64 + cx;
+  const size_t col = (size_t)blockIdx.x * 16 + cx;
   const int R = p.rows, T = p.g.T;
-  const int rpg = (R + 15) / 16, r0 = rg * rpg, r1 = min(R, r0 + rpg);
+  const int rpg = (R + 63) / 64, r0 = rg * rpg, r1 = min(R, r0 + rpg);
   const bool ok = col < VT;
   const size_t v = ok ? col / T : 0, t = ok ? col - v * T : 0;
   uint32_t* base = p.counts + (v * R) * (size_t)T + t;
+  const bool in_regs = rpg <= kPrefixRegs;
+  uint32_t c[kPrefixRegs];
   uint32_t sum = 0;
-  if (ok) {
+  if (in_regs) {
+#pragma unroll
+    for (int k = 0; k < kPrefixRegs; ++k) {
+      c[k] = (ok && r0 + k < r1) ? base[(size_t)(r0 + k) * T] : 0u;
+      sum += c[k];
+    }
+  } else if (ok) {
 #pragma unroll 8
     for (int r = r0; r < r1; ++r) sum += base[(size_t)r * T];
   }
   part[rg][cx] = sum;
   __syncthreads();
   uint32_t run = 0, total = 0;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) {
+#pragma unroll 16
+  for (int k = 0; k < 64; ++k) {
     const uint32_t x = part[k][cx];
     run += (k < rg) ? x : 0u;
     total += x;
   }
   if (ok) {
+    if (in_regs) {
+#pragma unroll
+      for (int k = 0; k < kPrefixRegs; ++k)
+        if (r0 + k < r1) {
+          base[(size_t)(r0 + k) * T] = run;
+          run += c[k];
+        }
+    } else {
 #pragma unroll 8
-    for (int r = r0; r < r1; ++r) {
-      const uint32_t c = base[(size_t)r * T];
-      base[(size_t)r * T] = run;
-      run += c;
+      for (int r = r0; r < r1; ++r) {
+        const uint32_t x = base[(size_t)r * T];
+        base[(size_t)r * T] = run;
+        run += x;
+      }
     }
     if (rg == 0) p.tile_total[col] = total;
   }
@@ -1995,13 +2051,24 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     GSR_CHECK(hipEventRecord(ss->join, ss->stream));
   }
   const bool fused_count = p.g.T <= kTileWindow && !(d.flags & GSR_FLAG_ABLATE_NO_COUNT);
-  if (fused_count) hipLaunchKernelGGL(k_preprocess_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  if (fused_count) {
+    static std::atomic<unsigned long long> lds_set{0ull};  // per device: > 64 KB of dynamic LDS has to be asked for
+    int dev = 0;
+    GSR_CHECK(hipGetDevice(&dev));
+    if (!((lds_set.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
+      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_count),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBinThreads / 64 * 4096 + kTileWindow * 4));
+      lds_set.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(k_preprocess_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads),
+                       kBinThreads / 64 * 4096 + (size_t)p.g.T * 4, st, p);
+  }
   else hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   GSR_MARK();
   if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
   GSR_MARK();
   if (!fused_count) hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
-  hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 63) / 64)), dim3(1024), 0, st, p);
+  hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 15) / 16)), dim3(1024), 0, st, p);
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
   if (!scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
   GSR_MARK();
