@@ -21,7 +21,7 @@ SCREEN_GRAD_FLOATS = 12
 FLAG_SH_PLANAR = 0x4
 FLAG_COV_3X3 = 0x8
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 
 
 class GsrDims(ctypes.Structure):

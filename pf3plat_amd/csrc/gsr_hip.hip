@@ -1177,28 +1177,35 @@ __device__ __forceinline__ float splat_p2(float a2, float b2, float c2, float dx
 }
 
 // ------------------------------------------------------------------------------------------------
-// K6: forward blend ([EXT] forward.cu renderCUDA; oracle blend_forward).  One workgroup of four wavefronts per
-// 8x8 tile, lane = pixel in every wave, SPECIALISED and pipelined over batches of kFB list entries:
-//   helpers (waves 1-3), stage E : alpha(pixel, splat) for a third of a batch each -> LDS sX[batch % 3][entry][pixel]
-//                                  (0 where the reference would skip: power > 0 or alpha < 1/255); T-independent
-//   scan    (wave 0),    stage S : the only sequential part.  Free-running transmittance Tf <- Tf (1 - alpha) is the
-//                                  single loop-carried dependence (one multiply per entry); since Tf never increases,
-//                                  "the reference loop has stopped" <=> Tf (1 - alpha) < 1e-4 now.  Overwrites alpha in
-//                                  place with the blend weight w = alpha Tf (0 once stopped / when skipped).
-//   helpers,             stage A : colour (and extra-channel) accumulation sum_j c_j w_j over their third of the
-//                                  previous batch, plus the last-contributor index
-//   wave 1 also gathers the splat records two batches ahead (global gather issued before its E/A share, LDS write after).
-// Why: a lone wavefront issues one VALU instruction per ~6 cycles on MI355X (measured), and a 256x256 view only has
-// 1024 tiles for 1024 SIMDs - so the dependent chain is cut to ~8 instructions per entry on one wave and everything
-// else runs on co-resident helper waves.  Per-pixel arithmetic is that of the sequential reference loop; only the
-// colour sum is split into three partial sums (added in wave order at the end).
+// K6: forward blend ([EXT] forward.cu renderCUDA; oracle blend_forward).  One workgroup of four wavefronts per 8x8 tile,
+// lane = pixel in every wave; the depth-ordered list is cut into batches of kFB entries and every batch into four
+// SEGMENTS of kFS consecutive entries, one per wave.  The only dependence between entries is the transmittance
+// T <- T (1 - alpha), a product - so a segment needs from its predecessors nothing but the product of their (1 - alpha):
+//   stage E (batch i+1): the wave evaluates alpha(pixel, splat) of its segment into REGISTERS (0 where the reference
+//                        skips: power > 0 or alpha < 1/255) and publishes the segment product P = prod (1 - alpha);
+//   stage A (batch i)  : every wave reads the four products of the batch, forms the transmittance at the start of its
+//                        own segment (Tb P0 .. P(w-1), the same multiplication chain in every wave, so all waves hold
+//                        bit-identical values), then runs the reference's per-entry loop over its kFS entries from
+//                        there: test T (1 - alpha) < 1e-4, weight alpha T, colour / extra accumulation, last contributor.
+// Since T never increases, "the reference loop has stopped" <=> T (1 - alpha) < 1e-4 now, so the free-running product
+// decides per entry exactly what the sequential loop decides; the reported final T is the smallest T that passed.
+// Per-pixel arithmetic is the reference's except that T crosses a segment boundary as T_start x (segment product) rather
+// than entry by entry (an fp32 re-association, ~1e-7 relative), and the colour sum is split in four partial sums.
+// Wave (b mod 4) gathers the records of batch b: list ids three iterations ahead, records two ahead, LDS one ahead.
+// Why this shape: a lone wavefront issues one VALU instruction per ~6 cycles on MI355X (measured) and a 256x256 view
+// only has 1024 tiles for 1024 SIMDs, so a tile needs several waves; with segments no wave carries a sequential chain
+// longer than kFS entries and no alpha travels through LDS.
 // ------------------------------------------------------------------------------------------------
 // Four waves per workgroup = one per SIMD: with a fifth wave every workgroup puts two waves on the same SIMD and the
 // per-SIMD register file then admits only 3 workgroups per CU (768 of the 1024 tiles of a 256x256 view; measured).
-constexpr int kFwdHelpers = 3;
-constexpr int kFE = 12;                               // entries per helper per batch (3 groups of 4)
-constexpr int kFB = kFE * kFwdHelpers;                // 36 list entries per batch
-constexpr int kFwdThreads = 64 * (1 + kFwdHelpers);   // 256
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr int kFwdWaves = 4;
+#ifndef GSR_KFS
+#define GSR_KFS 8
+#endif
+constexpr int kFS = GSR_KFS;                  // entries per wave per batch (even)
+constexpr int kFB = kFS * kFwdWaves;          // 32 list entries per batch
+constexpr int kFwdThreads = 64 * kFwdWaves;   // 256
 
 __device__ __forceinline__ void stage_batch(const GeomRec* geom, const float4* rgbc, uint32_t n, uint32_t base, int lane,
                                             uint32_t id, bool want_extra, float4& g, float2& g2, float4& c) {
@@ -1215,14 +1222,13 @@ __device__ __forceinline__ void stage_batch(const GeomRec* geom, const float4* r
 }
 
 template <bool kExtra>
-__global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
-  __shared__ float sX[3][kFB][64];
-  __shared__ float4 sGeo[4][kFB];   // x, y, a2, b2
-  __shared__ float2 sGeo2[4][kFB];  // c2, opacity
-  __shared__ float4 sCol[4][kFB];   // r, g, b, extra
-  __shared__ float sPart[kFwdHelpers][4][64];
-  __shared__ uint32_t sLast[kFwdHelpers][64];
-  __shared__ int sStop;
+__global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
+  // records of a batch, laid out for PAIRS of consecutive entries (e, e+1) so that one ds_read_b128 yields the two
+  // operands of two packed-fp32 instructions: [x x' y y'], [a2 a2' b2 b2'], [c2 c2' o o'], [r r' g g'], [b b' ex ex']
+  __shared__ float4 sXY[4][kFB / 2], sAB[4][kFB / 2], sCO[4][kFB / 2], sRG[4][kFB / 2], sBE[4][kFB / 2];
+  __shared__ float sP[2][kFwdWaves][64];  // segment products of batch b in sP[b & 1]
+  __shared__ float sPart[kFwdWaves][5][64];
+  __shared__ uint32_t sLast[kFwdWaves][64];
   const Grid& g = p.g;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v = blockIdx.y;
@@ -1250,127 +1256,127 @@ __global__ __launch_bounds__(kFwdThreads) void k_blend_fwd(const Params p) {
     }
     return;
   }
-  float T = 1.f, Tf = inside ? 1.f : 0.f;      // scan wave: reported / free-running transmittance
-  float C0 = 0.f, C1 = 0.f, C2 = 0.f, E = 0.f;  // helper waves: partial colour sums
+  float Tb = inside ? 1.f : 0.f;               // free-running transmittance at the start of the batch (same in all waves)
+  float Tmin = 1.f;                             // smallest transmittance that passed the test in this wave's segments
+  f2 al[kFS / 2];                               // alphas of this wave's segment of the batch about to be accumulated
   uint32_t last = 0, consumed = 0;
-  if (threadIdx.x == 0) sStop = 0;
   const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
   unsigned long long tm0 = 0, tm1 = 0, rt0 = 0;
   if (dbg) { tm0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  const int e0 = wave * kFS;
 
-  auto eval = [&](uint32_t b) {  // stage E for this helper's entries of batch b
-    const int gb = b & 3, xb = b % 3, e0 = (wave - 1) * kFE;
-#pragma unroll 4
-    for (int e = e0; e < e0 + kFE; ++e) {
-      const float4 a = sGeo[gb][e];
-      const float2 a2 = sGeo2[gb][e];
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
-      const float alpha = fminf(0.99f, a2.y * __builtin_amdgcn_exp2f(p2));
-      const bool keep = !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
-      sX[xb][e][lane] = keep ? alpha : 0.f;
+  const f2 px2 = {pxf, pxf}, py2 = {pyf, pyf};
+  auto eval = [&](uint32_t b) {  // stage E, two entries per step (v_pk_*_f32: same rounding per component as scalar code)
+    const int gb = b & 3;
+    f2 P2 = {1.f, 1.f};
+#pragma unroll
+    for (int u = 0; u < kFS; u += 2) {
+      const float4 xy = sXY[gb][(e0 + u) >> 1], ab = sAB[gb][(e0 + u) >> 1], co = sCO[gb][(e0 + u) >> 1];
+      const f2 dx = f2{xy.x, xy.y} - px2, dy = f2{xy.z, xy.w} - py2;
+      const f2 a2 = {ab.x, ab.y}, b2 = {ab.z, ab.w}, c2 = {co.x, co.y}, o = {co.z, co.w};
+      const f2 t = __builtin_elementwise_fma(b2, dy, a2 * dx);
+      const f2 p2 = __builtin_elementwise_fma(c2 * dy, dy, t * dx);
+      const f2 ao = o * f2{__builtin_amdgcn_exp2f(p2.x), __builtin_amdgcn_exp2f(p2.y)};
+      const float alpha0 = fminf(0.99f, ao.x), alpha1 = fminf(0.99f, ao.y);
+      const bool keep0 = !(p2.x > 0.f) && !(alpha0 < 1.0f / 255.0f), keep1 = !(p2.y > 0.f) && !(alpha1 < 1.0f / 255.0f);
+      al[u >> 1] = f2{keep0 ? alpha0 : 0.f, keep1 ? alpha1 : 0.f};
+      P2 *= f2{1.f, 1.f} - al[u >> 1];
+    }
+    sP[b & 1][wave][lane] = P2.x * P2.y;
+  };
+  f2 CR = {0.f, 0.f}, CG = {0.f, 0.f}, CB = {0.f, 0.f}, CE = {0.f, 0.f};  // colour sums over even / odd entries
+  auto accum = [&](uint32_t b, float Tf) {  // stage A; Tf = transmittance at the start of this wave's segment
+    const int cb = b & 3;
+#pragma unroll
+    for (int u = 0; u < kFS; u += 2) {
+      const f2 om = f2{1.f, 1.f} - al[u >> 1];
+      const float Tn0 = Tf * om.x, Tn1 = Tn0 * om.y;
+      const bool alive0 = !(Tn0 < 0.0001f), alive1 = !(Tn1 < 0.0001f);
+      const f2 wr = al[u >> 1] * f2{Tf, Tn0};
+      const f2 w = {alive0 ? wr.x : 0.f, alive1 ? wr.y : 0.f};
+      Tmin = alive0 ? Tn0 : Tmin;
+      Tmin = alive1 ? Tn1 : Tmin;
+      Tf = Tn1;
+      const float4 rg = sRG[cb][(e0 + u) >> 1], be = sBE[cb][(e0 + u) >> 1];
+      CR = __builtin_elementwise_fma(f2{rg.x, rg.y}, w, CR);
+      CG = __builtin_elementwise_fma(f2{rg.z, rg.w}, w, CG);
+      CB = __builtin_elementwise_fma(f2{be.x, be.y}, w, CB);
+      if (kExtra) CE = __builtin_elementwise_fma(f2{be.z, be.w}, w, CE);
+      const uint32_t idx = b * kFB + e0 + u;
+      last = (w.x > 0.f) ? idx + 1 : last;
+      last = (w.y > 0.f) ? idx + 2 : last;
     }
   };
-  auto accum = [&](uint32_t b) {  // stage A for this helper's entries of batch b
-    const int cb = b & 3, xb = b % 3, e0 = (wave - 1) * kFE;
-#pragma unroll 4
-    for (int e = e0; e < e0 + kFE; ++e) {
-      const float w = sX[xb][e][lane];
-      const float4 c = sCol[cb][e];
-      C0 = __builtin_fmaf(c.x, w, C0);
-      C1 = __builtin_fmaf(c.y, w, C1);
-      C2 = __builtin_fmaf(c.z, w, C2);
-      if (kExtra) E = __builtin_fmaf(c.w, w, E);
-      last = (w > 0.f) ? b * kFB + e + 1 : last;
-    }
+  auto put_records = [&](int sb, const float4& q, const float2& q2, const float4& c) {  // lane = entry of the batch
+    const int o = (lane >> 1) * 4 + (lane & 1);
+    float* xy = reinterpret_cast<float*>(sXY[sb]); float* ab = reinterpret_cast<float*>(sAB[sb]);
+    float* co = reinterpret_cast<float*>(sCO[sb]); float* rg2 = reinterpret_cast<float*>(sRG[sb]);
+    float* be = reinterpret_cast<float*>(sBE[sb]);
+    xy[o] = q.x; xy[o + 2] = q.y; ab[o] = q.z; ab[o + 2] = q.w; co[o] = q2.x; co[o + 2] = q2.y;
+    rg2[o] = c.x; rg2[o + 2] = c.y; be[o] = c.z; be[o + 2] = c.w;
   };
 
-  uint32_t ib = 0;  // batch at which the loop stopped
   if (nbat > 0) {
-    // ---- prologue: stage batches 0 (wave 1) and 1 (wave 2), evaluate batch 0
+    // ---- prologue: waves 0 / 1 stage batches 0 / 1, wave 2 fetches the list ids of batch 2; everyone evaluates batch 0
     float4 sg = make_float4(0, 0, 0, 0), sc = sg;
     float2 sg2 = make_float2(0, 0);
     uint32_t id_next = 0;
-    if (lane < kFB && (wave == 1 || (wave == 2 && nbat > 1))) {
-      const uint32_t b = (uint32_t)(wave - 1);
-      const uint32_t id = (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u;
-      stage_batch(geom, rgbc, n, b * kFB, lane, id, kExtra, sg, sg2, sc);
-      sGeo[b][lane] = sg; sGeo2[b][lane] = sg2; sCol[b][lane] = sc;
-      if (wave == 1) id_next = (2u * kFB + lane < n) ? plist[2 * kFB + lane] : 0u;
+    if (lane < kFB) {
+      if (wave == 0 || (wave == 1 && nbat > 1)) {
+        const uint32_t b = (uint32_t)wave;
+        const uint32_t id = (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u;
+        stage_batch(geom, rgbc, n, b * kFB, lane, id, kExtra, sg, sg2, sc);
+        put_records((int)b, sg, sg2, sc);
+      } else if (wave == 2) {
+        id_next = (2u * kFB + lane < n) ? plist[2 * kFB + lane] : 0u;
+      }
     }
     __syncthreads();
-    if (wave >= 1) eval(0);
+    eval(0);
     __syncthreads();
     if (dbg) tm1 = __builtin_readcyclecounter();
-    // ---- steady state, iteration i: S(i) | A(i-1), E(i+1), gather(i+2)
+    // ---- steady state, iteration i: A(i), E(i+1) | records of batch i+2 gathered, list ids of batch i+3 fetched
     for (uint32_t i = 0; i < nbat; ++i) {
-      ib = i;
-      if (wave == 0) {
-        const int xb = i % 3;
-        // groups of 4 entries; the LDS reads of the next group are issued before the dependent chain of this one
-        float an[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) an[u] = sX[xb][u][lane];
-#pragma unroll 1
-        for (int e0 = 0; e0 < kFB; e0 += 4) {
-          float al[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) al[u] = an[u];
-          const int en = (e0 + 4 < kFB) ? e0 + 4 : 0;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) an[u] = sX[xb][en + u][lane];
-          float wv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const float Tn = Tf * (1.f - al[u]);
-            const bool alive = !(Tn < 0.0001f);
-            wv[u] = alive ? al[u] * Tf : 0.f;
-            T = alive ? Tn : T;
-            Tf = Tn;
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) sX[xb][e0 + u][lane] = wv[u];
-        }
-        consumed = (i + 1) * kFB;
-        const bool all_dead = __all(Tf < 0.0001f);
-        if (lane == 0 && (all_dead || i + 1 == nbat)) sStop = (int)(i + 1);  // stamped with the iteration
-      } else {
-        const uint32_t bs = i + 2;
-        const bool do_stage = (wave == 1) && (bs < nbat) && (lane < kFB);
-        if (do_stage) {
-          stage_batch(geom, rgbc, n, bs * kFB, lane, id_next, kExtra, sg, sg2, sc);  // global gather in flight
-          id_next = ((bs + 1) * kFB + lane < n) ? plist[(bs + 1) * kFB + lane] : 0u;
-        }
-        if (i >= 1) accum(i - 1);
-        if (i + 1 < nbat) eval(i + 1);
-        if (do_stage) {
-          const int sb = bs & 3;
-          sGeo[sb][lane] = sg; sGeo2[sb][lane] = sg2; sCol[sb][lane] = sc;
-        }
+      const float P0 = sP[i & 1][0][lane], P1 = sP[i & 1][1][lane], P2 = sP[i & 1][2][lane], P3 = sP[i & 1][3][lane];
+      const uint32_t bs = i + 2;
+      const bool do_stage = (wave == (int)(bs & 3)) && (bs < nbat) && (lane < kFB);
+      if (do_stage) stage_batch(geom, rgbc, n, bs * kFB, lane, id_next, kExtra, sg, sg2, sc);  // global gather in flight
+      if (wave == (int)((i + 3) & 3) && lane < kFB) id_next = ((i + 3) * kFB + lane < n) ? plist[(i + 3) * kFB + lane] : 0u;
+      const float t1 = Tb * P0, t2 = t1 * P1, t3 = t2 * P2, t4 = t3 * P3;  // the same chain in every wave
+      accum(i, wave == 0 ? Tb : wave == 1 ? t1 : wave == 2 ? t2 : t3);
+      if (i + 1 < nbat) eval(i + 1);
+      if (do_stage) {
+        put_records((int)(bs & 3), sg, sg2, sc);
       }
+      Tb = t4;
+      consumed = (i + 1) * kFB;
       __syncthreads();
-      if (sStop == (int)(i + 1)) break;  // a later iteration's stamp can never equal this one's
+      if (__all(Tb < 0.0001f)) break;  // bit-identical Tb in all four waves: a workgroup-uniform decision
     }
-    if (wave >= 1) accum(ib);  // drain: weights of the last scanned batch
   }
-  if (wave >= 1) {
-    sPart[wave - 1][0][lane] = C0; sPart[wave - 1][1][lane] = C1; sPart[wave - 1][2][lane] = C2;
-    if (kExtra) sPart[wave - 1][3][lane] = E;
-    sLast[wave - 1][lane] = last;
-  }
+  float C0 = CR.x + CR.y, C1 = CG.x + CG.y, C2 = CB.x + CB.y, E = CE.x + CE.y;  // this wave's partial colour sums
+  sPart[wave][0][lane] = C0; sPart[wave][1][lane] = C1; sPart[wave][2][lane] = C2;
+  if (kExtra) sPart[wave][3][lane] = E;
+  sPart[wave][4][lane] = Tmin;
+  sLast[wave][lane] = last;
   __syncthreads();
   if (dbg && threadIdx.x == 0) {
     unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
-    o[0] = tm0; o[1] = ((unsigned long long)blockIdx.x << 32) | (unsigned)(tm1 - tm0); o[2] = __builtin_readcyclecounter();
+    // where it ran: HW_ID (id 4: wave, simd, pipe, cu, sh, se ...) and XCC_ID (id 20), 16 bits each
+    const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
+                        ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
+    o[0] = tm0; o[1] = ((unsigned long long)hw << 32) | (unsigned)(tm1 - tm0); o[2] = __builtin_readcyclecounter();
     o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
   }
   if (wave == 0) {
     if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
     if (inside) {
+      float T = Tmin;
 #pragma unroll
-      for (int h = 0; h < kFwdHelpers; ++h) {
+      for (int h = 1; h < kFwdWaves; ++h) {
         C0 += sPart[h][0][lane]; C1 += sPart[h][1][lane]; C2 += sPart[h][2][lane];
         if (kExtra) E += sPart[h][3][lane];
+        T = fminf(T, sPart[h][4][lane]);
         last = max(last, sLast[h][lane]);
       }
       const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;

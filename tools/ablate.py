@@ -36,10 +36,14 @@ def main():
     rs = ((raw[:, 3] >> 32) & 0xffffffff).double() * 0.01  # us
     re = (raw[:, 3] & 0xffffffff).double() * 0.01
     print("blend_fwd wall clock (us): start skew", q0(rs - rs.min()), "| end", q0(re - rs.min()), "| duration", q0(re - rs), flush=True)
-    bid = (raw[:, 1] >> 32) & 0xffffffff
-    late = (rs - rs.min()) > 5.0
-    print("late tiles:", int(late.sum()), "of 1024; blockIdx of late tiles: min", int(bid[late].min()) if late.any() else -1,
-          "max", int(bid[late].max()) if late.any() else -1, "| blockIdx of on-time tiles: max", int(bid[~late].max()), flush=True)
+    hw = (raw[:, 1] >> 32) & 0xffffffff
+    cu = ((hw >> 16) & 0xf) * 4096 + ((hw >> 13) & 0x7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)  # xcc, se, sh, cu
+    ucu, inv, cnt = torch.unique(cu, return_inverse=True, return_counts=True)
+    cu_end = torch.zeros(len(ucu), dtype=torch.float64).scatter_reduce(0, inv, re - rs.min(), "amax")
+    cu_walk = torch.zeros(len(ucu), dtype=torch.float64).scatter_add(0, inv, walked)
+    print(f"blend_fwd placement: {len(ucu)} distinct CUs for 1024 tiles; tiles per CU min {int(cnt.min())} max {int(cnt.max())} "
+          f"hist {torch.bincount(cnt).tolist()} | per-CU end (us) {q0(cu_end)} | per-CU walked entries {q0(cu_walk)} | "
+          f"corr(end, walked) {torch.corrcoef(torch.stack([cu_end, cu_walk]))[0, 1].item():.2f} corr(end, tiles) {torch.corrcoef(torch.stack([cu_end, cnt.double()]))[0, 1].item():.2f}", flush=True)
     st[:, 1] = st[:, 0] + (raw[:, 1] & 0xffffffff).double()
     t0 = st[:, 0] - st[:, 0].min()
     dur = st[:, 2] - st[:, 0]

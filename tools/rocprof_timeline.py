@@ -1,0 +1,47 @@
+"""Eager-mode timeline of the forward launch chain from a rocprofv3 kernel trace (rocpd sqlite database):
+for a window of consecutive forward passes, the start / end of every gsr:: kernel relative to the pass's first kernel.
+usage: python tools/rocprof_timeline.py <results.db> [n_passes]"""
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def main():
+    db = sys.argv[1]
+    npass = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    c = sqlite3.connect(db)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    rows = list(c.execute("select name, start, end, grid_x, grid_y from kernels order by start"))
+    rows = [r for r in rows if r[0].startswith("gsr::") or "gsr::" in r[0]]
+    # passes begin at k_preprocess_count with grid_y == 1 (single-view bench config)
+    passes, cur = [], None
+    for name, st, en, gx, gy in rows:
+        short = name.split("(")[0].replace("gsr::", "").replace("void ", "")
+        if short.startswith("k_preprocess_count") and gy == 1:
+            cur = []
+            passes.append(cur)
+        if cur is not None:
+            cur.append((short, st, en))
+    passes = [p for p in passes if len(p) == 6 and p[-1][0].startswith("k_blend_fwd")]
+    passes = passes[len(passes) // 2: len(passes) // 2 + npass]
+    acc = defaultdict(lambda: [0.0, 0.0, 0])
+    period = []
+    for a, b in zip(passes[:-1], passes[1:]):
+        period.append((b[0][1] - a[0][1]) / 1000.0)
+    for p in passes:
+        t0 = min(x[1] for x in p)
+        for short, st, en in p:
+            a = acc[short]
+            a[0] += (st - t0) / 1000.0
+            a[1] += (en - t0) / 1000.0
+            a[2] += 1
+    print(f"{len(passes)} passes; columns: {cols}")
+    if period:
+        period.sort()
+        print(f"pass-to-pass period us: median {period[len(period)//2]:.2f} min {period[0]:.2f}")
+    for k, (s, e, n) in sorted(acc.items(), key=lambda kv: kv[1][0] / kv[1][2]):
+        print(f"{k:28s} start {s/n:7.2f}  end {e/n:7.2f}  dur {(e-s)/n:6.2f}")
+
+
+if __name__ == "__main__":
+    main()
