@@ -64,6 +64,49 @@ def backward_bytes(n, nv, r16, hw, k_sh):
     return hw * (12 + 8) + r16 * (8 + 36) + nv * 80 + nv * (12 + 24 + kc) + n * (12 + 24 + 4 + kc)
 
 
+def pmc_traffic(kernel, n):
+    """HBM bytes per launch of `kernel` from the TCC counters, one rocprofv3 pass per counter (FETCH_SIZE and WRITE_SIZE do
+    not fit one pass), each profiling a child run of this file (--traffic-child).  Units and the gfx950 correction are those
+    of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB, and FETCH_SIZE reports half the bytes of
+    a wide coalesced read, so traffic = 2 * FETCH + WRITE (an upper bound for the gather-type kernels).  None if rocprofv3 is
+    unavailable or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None
+    raw = {}
+    here = os.path.abspath(__file__)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="gsr_pmc_", dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=os.path.dirname(here) + os.pathsep + os.environ.get("PYTHONPATH", ""))
+            subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
+                            sys.executable, here, "--traffic-child", "--gaussians", str(n)],
+                           cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == ctr and kernel.split("::")[-1] in r["Kernel_Name"]:
+                        vals.append(float(r["Counter_Value"]))
+            shutil.rmtree(d, ignore_errors=True)
+            if not vals:
+                return None
+            vals = vals[len(vals) // 3:]  # steady state
+            raw[ctr] = 1024.0 * sum(vals) / len(vals)
+    except Exception as e:  # pragma: no cover - measurement aid
+        print(f"[bench] PMC traffic pass failed ({type(e).__name__}: {e}); roofline.traffic stays null", file=sys.stderr)
+        return None
+    return {"traffic": 2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"], "fetch_size_raw_bytes": raw["FETCH_SIZE"],
+            "write_size_raw_bytes": raw["WRITE_SIZE"],
+            "note": "per launch; rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the "
+                    "guide's gfx950 correction (exact for coalesced streams, an upper bound for gathers); WRITE uncalibrated"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -72,6 +115,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches only (no HIP-graph replay)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gaussians", type=int, default=N_GAUSS, help=argparse.SUPPRESS)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # the run those passes profile
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,6 +160,12 @@ def main():
 
     def step():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+
+    if args.traffic_child:  # profiled by pmc_traffic(): a handful of eager passes of the headline chain, nothing else
+        for _ in range(12):
+            step()
+        torch.cuda.synchronize()
+        return
 
     def barrier():
         torch.cuda.synchronize()
@@ -218,7 +269,7 @@ def main():
         dom = max(acc, key=acc.get)
         chain_ms = sum(acc.values())
         ach = stage_bytes[dom] / (acc[dom] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": {"preprocess": "gsr::k_preprocess", "color": "gsr::k_color", "tile_scan": "gsr::k_tile_scan",
+        result["roofline"] = {"bound": "hbm", "kernel": {"preprocess": "gsr::k_preprocess_count", "color": "gsr::k_color", "tile_scan": "gsr::k_tile_scan",
                                                          "emit": "gsr::k_emit", "sort": "gsr::k_sort_tiles",
                                                          "blend": "gsr::k_blend_fwd"}[dom],
                               "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -228,6 +279,11 @@ def main():
                                     "algorithmic_bytes": ab["total"], "N": n, "N_v": nv, "R16": r16}
         result["stage_ms"] = {k_: round(v_, 5) for k_, v_ in acc.items()}
         result["stage_ms"]["sum_with_event_gaps"] = round(chain_ms, 5)
+        if not args.no_traffic and world == 1:
+            tr = pmc_traffic(result["roofline"]["kernel"], n)
+            if tr is not None:
+                result["roofline"]["traffic"] = tr["traffic"]
+                result["roofline"]["traffic_detail"] = tr
 
         # ---- fwd + bwd (configs[2]): dense seeded dL/dcolor
         gen = torch.Generator().manual_seed(3)
