@@ -1393,27 +1393,31 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// B1: backward blend ([EXT] backward.cu renderCUDA; oracle blend_backward).  One workgroup of four wavefronts per
-// 8x8 tile, specialised and pipelined over batches of kBB list entries walked back to front:
-//   helpers (waves 1-3), stage E, lane = pixel : alpha (0 unless the forward pass blended this splat at this
-//            pixel: not skipped and index < the pixel's last contributor) and cg = colour . dL/dpixel  -> LDS
-//   chain   (wave 0),    stage C, lane = pixel : the sequential replay, in closed form so that it is 8 VALU ops:
-//              r = 1/(1-alpha);  T <- T r  (transmittance in front of the splat);  w = alpha T;
-//              dL/dalpha = T cg - r (Bg + T_final bg.g);   Bg <- Bg + w cg
-//            where Bg = sum over deeper splats of w cg.  This equals the reference's accum_rec recurrence:
-//            accum_rec_j = B_j / T_{j+1} with B_j = sum_{m>j} c_m w_m (proof in DESIGN.md).  Overwrites alpha with w
-//            and cg with dL/dalpha in place.
-//   helpers,             stage R, lane = (entry row, 4 pixels): per-splat gradients.  Each 16-lane DPP row owns one
-//            list entry, each lane accumulates 4 pixels in registers, a 4-step row_ror all-reduce finishes the sum and
-//            ONE atomic instruction (40 active lanes) adds 4 splats x 10 values into the per-(view,Gaussian)
-//            screen-space accumulator:
+// B1: backward blend ([EXT] backward.cu renderCUDA; oracle blend_backward).  One workgroup of four wavefronts per 8x8 tile.
+// The reference replays the list back to front with T <- T/(1-alpha) and accum <- alpha c + (1-alpha) accum; in closed
+// form (proof in DESIGN.md 3.2), with w = alpha T and Bg = sum over DEEPER splats of w (c.g) + T_final bg.g:
+//     dL/dalpha = T (c.g) - Bg / (1 - alpha),          Bg <- Bg + w (c.g),          T <- T / (1 - alpha)
+// Both recurrences are linear in (T, Bg), so - exactly as in the forward kernel - the list is cut into batches of kBB
+// entries (walked back to front) and every batch into four SEGMENTS of 8 consecutive entries, one per wave:
+//   stage E (batch it+1), lane = pixel: G = exp2(power) and alpha (both 0 unless the forward blended this splat at this
+//            pixel: not skipped and index < the pixel's last contributor), c.g and r = rcp(1-alpha) into REGISTERS, and
+//            the segment's own replay from (T, Bg) = (1, 0): the product R of its r's and its local sum B' -> LDS;
+//   stage A (batch it),   lane = pixel: every wave reads the four (R, B') pairs and forms (T, Bg) at the back end of
+//            its segment by the same chain as every other wave, then replays its 8 entries from there: w and
+//            q = G dL/dalpha go to a per-wave LDS tile (no barrier: written and read by the same wave);
+//   stage R (batch it),   lane = (entry 0..7, pixel row 0..7): per-splat gradients.  Each lane sums its row of 8 pixels
+//            in registers - only q, q dx, q dx^2 and w g need per-pixel work, dy is constant along a row - a 3-step DPP
+//            all-reduce over the 8 lanes of an entry finishes the sums, and two atomic instructions add 8 splats x 10
+//            values into the per-(view, Gaussian) screen-space accumulator:
 //              scratch[.. * 12 + {0,1: dmean2D  2,3,4: dconic  5: dopacity  6,7,8: dcolor  9: dextra}]
-//   wave 1 also gathers the splat records two batches ahead.
-// A helper evaluates and reduces the SAME entries (groups h and h+3 of a batch), so E of the next batch may reuse the
-// LDS slot its own R has just consumed: one barrier per batch.
+// Wave (it mod 4) gathers the records of iteration it: list ids three iterations ahead, records two ahead, LDS one ahead.
+// One barrier per batch.  SQ counters of the previous shape (one chain wave + three helpers exchanging alpha, c.g, w and
+// dL/dalpha through LDS, exp2 evaluated again in the reduction): 88 VALU instructions per entry and tile, VALU-issue bound.
 // ------------------------------------------------------------------------------------------------
-constexpr int kBB = 24;  // list entries per batch = 6 groups of 4; helper h owns groups h and h + 3
-constexpr int kBwdThreads = 256;
+constexpr int kBS = 8;                       // entries per wave per batch = entries per reduction pass
+constexpr int kBwdWaves = 4;
+constexpr int kBB = kBS * kBwdWaves;         // 32 list entries per batch
+constexpr int kBwdThreads = 64 * kBwdWaves;  // 256
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_row_add(float v) {
@@ -1427,10 +1431,19 @@ __device__ __forceinline__ float row_allreduce(float v) {
   v = dpp_row_add<0x121>(v);  // row_ror:1
   return v;
 }
+// Sum over aligned groups of 8 lanes, result in every lane of the group.
+__device__ __forceinline__ float oct_allreduce(float v) {
+  v = dpp_row_add<0x141>(v);  // row_half_mirror: i <-> 7 - i
+  v = dpp_row_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_row_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  return v;
+}
 
-__global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
-  __shared__ __attribute__((aligned(16))) float sA[2][kBB][64];  // E: alpha -> C: weight w
-  __shared__ __attribute__((aligned(16))) float sD[2][kBB][64];  // E: cg    -> C: dL/dalpha
+template <bool kExtra>
+__global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
+  __shared__ __attribute__((aligned(16))) float sW[kBwdWaves][kBS][64];  // A -> R, per wave: blend weight w
+  __shared__ __attribute__((aligned(16))) float sQ[kBwdWaves][kBS][64];  // A -> R, per wave: G dL/dalpha
+  __shared__ float sR[2][kBwdWaves][64], sB[2][kBwdWaves][64];           // E -> A: segment (R, B') of iteration it in [it & 1]
   __shared__ float4 sGeo[4][kBB];   // x, y, a2, b2
   __shared__ float4 sGeo2[4][kBB];  // c2, opacity, id bits, 0
   __shared__ float4 sCol[4][kBB];   // r, g, b, extra
@@ -1447,11 +1460,11 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
   const uint32_t* plist = p.point_list + rg.x;
   float* scratch = p.scratch + (size_t)v * p.d.num_gaussians * GSR_SCREEN_GRAD_FLOATS;
   const GsrView& cam = p.views[v];
-  const bool has_extra = p.d.has_extra != 0 && p.dL_dextra_img != nullptr;
   const float* dcol = p.dL_dcolor + (size_t)v * 3 * HW;
-  const float* dext = has_extra ? p.dL_dextra_img + (size_t)v * HW : nullptr;
+  const float* dext = kExtra ? p.dL_dextra_img + (size_t)v * HW : nullptr;
+  (void)n;
 
-  // ---- lane = pixel view (chain, stage E)
+  // ---- lane = pixel view (stages E, A)
   const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
   const bool inside = pxi < g.W && pyi < g.H;
   const float pxf = (float)pxi, pyf = (float)pyi;
@@ -1462,18 +1475,18 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
   float g0 = 0, g1 = 0, g2 = 0, ge = 0;
   if (inside) {
     g0 = dcol[pix]; g1 = dcol[HW + pix]; g2 = dcol[2 * HW + pix];
-    if (has_extra) ge = dext[pix];
+    if (kExtra) ge = dext[pix];
   }
-  // ---- lane = (entry row, 4 pixels) view (stage R)
-  const int row = lane >> 4, li = lane & 15;
-  const int rpx0 = tx * 8 + 4 * (li & 1), rpy = ty * 8 + (li >> 1);
-  float rg0[4], rg1[4], rg2[4], rge[4];
+  // ---- lane = (entry, pixel row) view (stage R): dL/dpixel of this lane's row of 8 pixels
+  const int er = lane >> 3, pr = lane & 7;
+  const int rpy = ty * 8 + pr, rpx0 = tx * 8;
+  float rg0[8], rg1[8], rg2[8], rge[8];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const bool in = (rpx0 + k < g.W) && (rpy < g.H) && wave >= 1;
+  for (int k = 0; k < 8; ++k) {
+    const bool in = (rpx0 + k < g.W) && (rpy < g.H);
     const size_t q = (size_t)rpy * g.W + rpx0 + k;
     rg0[k] = in ? dcol[q] : 0.f; rg1[k] = in ? dcol[HW + q] : 0.f; rg2[k] = in ? dcol[2 * HW + q] : 0.f;
-    rge[k] = (in && has_extra) ? dext[q] : 0.f;
+    rge[k] = (kExtra && in) ? dext[q] : 0.f;
   }
   const float hW = 0.5f * (float)g.W, hH = 0.5f * (float)g.H;
 
@@ -1488,7 +1501,7 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
       const GeomRec* r = geom + id;
       float4 q0 = r->q0, q1 = r->q1;
       const float4 col = rgbc[id];
-      const float ex = has_extra ? r->q2.y : 0.f;
+      const float ex = kExtra ? r->q2.y : 0.f;
       to_exp2_domain(q0, q1);
       sg = q0; sg2 = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f); sc = make_float4(col.x, col.y, col.z, ex);
     }
@@ -1498,134 +1511,132 @@ __global__ __launch_bounds__(kBwdThreads) void k_blend_bwd(const Params p) {
     const uint32_t idx = batch_of(it) * kBB + lane;
     return (lane < kBB && idx < nmax) ? plist[idx] : 0u;
   };
-  auto eval = [&](uint32_t it) {  // stage E for this helper's 8 entries
-    const int ring = it & 3, slot = it & 1;
-    const uint32_t base = batch_of(it) * kBB;
-#pragma unroll 2
-    for (int q = 0; q < 8; ++q) {
-      const int e = 4 * ((wave - 1) + 3 * (q >> 2)) + (q & 3);
-      const float4 a = sGeo[ring][e], a2 = sGeo2[ring][e], c = sCol[ring][e];
+
+  float al[kBS], Gc[kBS], cgv[kBS], rr[kBS];  // this wave's segment of the batch about to be replayed
+  const int e0 = wave * kBS;
+  auto eval = [&](uint32_t it) {  // stage E
+    const int ring = it & 3;
+    const uint32_t base = batch_of(it) * kBB + e0;
+#pragma unroll
+    for (int u = 0; u < kBS; ++u) {
+      const float4 a = sGeo[ring][e0 + u], a2 = sGeo2[ring][e0 + u], c = sCol[ring][e0 + u];
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
-      const float alpha = fminf(0.99f, a2.y * __builtin_amdgcn_exp2f(p2));
-      const bool contrib = (base + e < my_last) && !(p2 > 0.f) && !(alpha < 1.0f / 255.0f);
+      const float G = __builtin_amdgcn_exp2f(p2);
+      const float og = a2.y * G;
+      const bool contrib = (base + u < my_last) && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
+      al[u] = contrib ? fminf(0.99f, og) : 0.f;
+      Gc[u] = contrib ? G : 0.f;
       float cg = c.x * g0;
       cg = __builtin_fmaf(c.y, g1, cg);
       cg = __builtin_fmaf(c.z, g2, cg);
-      cg = __builtin_fmaf(c.w, ge, cg);
-      sA[slot][e][lane] = contrib ? alpha : 0.f;
-      sD[slot][e][lane] = cg;
+      if (kExtra) cg = __builtin_fmaf(c.w, ge, cg);
+      cgv[u] = cg;
+      rr[u] = __builtin_amdgcn_rcpf(1.f - al[u]);
+    }
+    float Tl = 1.f, Bl = 0.f;  // the segment's replay from (1, 0), back to front
+#pragma unroll
+    for (int u = kBS - 1; u >= 0; --u) {
+      Tl *= rr[u];
+      Bl = __builtin_fmaf(al[u] * Tl, cgv[u], Bl);
+    }
+    sR[it & 1][wave][lane] = Tl;
+    sB[it & 1][wave][lane] = Bl;
+  };
+  auto replay = [&](float T, float B) {  // stage A: (T, B) at the back end of this wave's segment
+#pragma unroll
+    for (int u = kBS - 1; u >= 0; --u) {
+      T *= rr[u];  // transmittance in front of the splat
+      const float w = al[u] * T;
+      const float d = __builtin_fmaf(T, cgv[u], -(B * rr[u]));
+      B = __builtin_fmaf(w, cgv[u], B);
+      sW[wave][u][lane] = w;
+      sQ[wave][u][lane] = Gc[u] * d;
     }
   };
-  auto reduce = [&](uint32_t it) {  // stage R for this helper's 2 groups of 4 entries
-    const int ring = it & 3, slot = it & 1;
-#pragma unroll 1
-    for (int gq = 0; gq < 2; ++gq) {
-      const int e = 4 * ((wave - 1) + 3 * gq) + row;
-      const float4 w4 = *reinterpret_cast<const float4*>(&sA[slot][e][4 * li]);
-      const float4 d4 = *reinterpret_cast<const float4*>(&sD[slot][e][4 * li]);
-      const float4 a = sGeo[ring][e], a2 = sGeo2[ring][e];
-      const float wk[4] = {w4.x, w4.y, w4.z, w4.w}, dk[4] = {d4.x, d4.y, d4.z, d4.w};
-      // Per pixel only the moments of s = dL/dG * G are accumulated (s, s dx, s dy, s dx^2, s dx dy, s dy^2); the conic enters
-      // after the reduction because dG/ddelx = ln2 (2 a2 gdx + b2 gdy) and dG/ddely = ln2 (2 c2 gdy + b2 gdx) are linear in them.
-      float Sx = 0, Sy = 0, Sxx = 0, Sxy = 0, Syy = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
-      bool any_valid = false;
-      const float dy = a.y - (float)rpy;
+  auto reduce = [&](uint32_t it) {  // stage R: entry e0 + er of iteration it, pixel row pr
+    const int ring = it & 3;
+    const float4 w0 = *reinterpret_cast<const float4*>(&sW[wave][er][8 * pr]);
+    const float4 w1 = *reinterpret_cast<const float4*>(&sW[wave][er][8 * pr + 4]);
+    const float4 q0 = *reinterpret_cast<const float4*>(&sQ[wave][er][8 * pr]);
+    const float4 q1 = *reinterpret_cast<const float4*>(&sQ[wave][er][8 * pr + 4]);
+    const float4 a = sGeo[ring][e0 + er], a2 = sGeo2[ring][e0 + er];
+    const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+    const float qk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    // Only the moments of q = G dL/dalpha are accumulated per pixel; opacity and conic enter after the reduction because
+    // dL/dG = o dL/dalpha and dG/ddelx = ln2 (2 a2 gdx + b2 gdy), dG/ddely = ln2 (2 c2 gdy + b2 gdx) are linear in them.
+    float S0 = 0, Sx = 0, Sxx = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
+    const float dx0 = a.x - (float)rpx0, dy = a.y - (float)rpy;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const bool valid = wk[k] > 0.f;
-        any_valid = any_valid || valid;
-        const float dx = a.x - (float)(rpx0 + k);
-        const float G = __builtin_amdgcn_exp2f(splat_p2(a.z, a.w, a2.x, dx, dy));
-        const float q = G * (valid ? dk[k] : 0.f);  // G dL/dalpha
-        const float sq = a2.y * q;                  // dL/dG * G
-        const float tx = sq * dx, ty = sq * dy;
-        v5 += q;
-        Sx += tx; Sy += ty;
-        Sxx = __builtin_fmaf(tx, dx, Sxx);
-        Sxy = __builtin_fmaf(tx, dy, Sxy);
-        Syy = __builtin_fmaf(ty, dy, Syy);
-        v6 = __builtin_fmaf(wk[k], rg0[k], v6);
-        v7 = __builtin_fmaf(wk[k], rg1[k], v7);
-        v8 = __builtin_fmaf(wk[k], rg2[k], v8);
-        v9 = __builtin_fmaf(wk[k], rge[k], v9);
-      }
-      const unsigned long long bal = __ballot(any_valid);
-      if (((bal >> (16 * row)) & 0xffffull) == 0ull) continue;  // row-uniform: nothing blended from this splat in this tile
-      Sx = row_allreduce(Sx); Sy = row_allreduce(Sy); Sxx = row_allreduce(Sxx); Sxy = row_allreduce(Sxy); Syy = row_allreduce(Syy);
-      v5 = row_allreduce(v5); v6 = row_allreduce(v6); v7 = row_allreduce(v7); v8 = row_allreduce(v8);
-      if (has_extra) v9 = row_allreduce(v9);
-      // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
-      const float v0 = hW * kLn2 * (2.f * a.z * Sx + a.w * Sy);
-      const float v1 = hH * kLn2 * (2.f * a2.x * Sy + a.w * Sx);
-      const float v2 = -0.5f * Sxx, v3 = -0.5f * Sxy, v4 = -0.5f * Syy;
-      if (li < 10) {
-        float val = v0;
-        val = li == 1 ? v1 : val; val = li == 2 ? v2 : val; val = li == 3 ? v3 : val; val = li == 4 ? v4 : val;
-        val = li == 5 ? v5 : val; val = li == 6 ? v6 : val; val = li == 7 ? v7 : val; val = li == 8 ? v8 : val;
-        val = li == 9 ? v9 : val;
-        unsafeAtomicAdd(scratch + (size_t)__float_as_uint(a2.z) * GSR_SCREEN_GRAD_FLOATS + li, val);
-      }
+    for (int k = 0; k < 8; ++k) {
+      const float dx = dx0 - (float)k;
+      const float tq = qk[k] * dx;
+      S0 += qk[k];
+      Sx += tq;
+      Sxx = __builtin_fmaf(tq, dx, Sxx);
+      v6 = __builtin_fmaf(wk[k], rg0[k], v6);
+      v7 = __builtin_fmaf(wk[k], rg1[k], v7);
+      v8 = __builtin_fmaf(wk[k], rg2[k], v8);
+      if (kExtra) v9 = __builtin_fmaf(wk[k], rge[k], v9);
     }
+    float Sy = dy * S0, Sxy = dy * Sx, Syy = dy * Sy;
+    S0 = oct_allreduce(S0); Sx = oct_allreduce(Sx); Sy = oct_allreduce(Sy);
+    Sxx = oct_allreduce(Sxx); Sxy = oct_allreduce(Sxy); Syy = oct_allreduce(Syy);
+    v6 = oct_allreduce(v6); v7 = oct_allreduce(v7); v8 = oct_allreduce(v8);
+    if (kExtra) v9 = oct_allreduce(v9);
+    // a splat that no pixel of the tile blended (or whose pixels carry no gradient) adds exact zeros: skip its atomics
+    const bool any = (S0 != 0.f) || (Sx != 0.f) || (Sy != 0.f) || (Sxx != 0.f) || (v6 != 0.f) || (v7 != 0.f) || (v8 != 0.f) || (v9 != 0.f);
+    if (!any) return;
+    // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
+    const float o = a2.y;
+    const float v0 = hW * kLn2 * o * (2.f * a.z * Sx + a.w * Sy);
+    const float v1 = hH * kLn2 * o * (2.f * a2.x * Sy + a.w * Sx);
+    const float mh = -0.5f * o;
+    float val = v0;
+    val = pr == 1 ? v1 : val; val = pr == 2 ? mh * Sxx : val; val = pr == 3 ? mh * Sxy : val; val = pr == 4 ? mh * Syy : val;
+    val = pr == 5 ? S0 : val; val = pr == 6 ? v6 : val; val = pr == 7 ? v7 : val;
+    float* dst = scratch + (size_t)__float_as_uint(a2.z) * GSR_SCREEN_GRAD_FLOATS;
+    unsafeAtomicAdd(dst + pr, val);
+    if (pr < (kExtra ? 2 : 1)) unsafeAtomicAdd(dst + 8 + pr, pr == 0 ? v8 : v9);
   };
 
-  // ---- prologue: stage iterations 0 (wave 1) and 1 (wave 2), evaluate iteration 0
+  // ---- prologue: waves 0 / 1 stage iterations 0 / 1, wave 2 fetches the list ids of iteration 2; everyone evaluates 0
   float4 sg, sg2, sc;
   uint32_t id_next = 0;
-  if (wave == 1 || (wave == 2 && nbat > 1)) {
-    const uint32_t it0 = (uint32_t)(wave - 1);
+  if (wave == 0 || (wave == 1 && nbat > 1)) {
+    const uint32_t it0 = (uint32_t)wave;
     stage(it0, sg, sg2, sc, load_ids(it0));
     if (lane < kBB) { sGeo[it0][lane] = sg; sGeo2[it0][lane] = sg2; sCol[it0][lane] = sc; }
-    if (wave == 1) id_next = load_ids(2);
+  } else if (wave == 2) {
+    id_next = load_ids(2);
   }
   __syncthreads();
-  if (wave >= 1) eval(0);
+  eval(0);
   __syncthreads();
   const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
-  float T = T_final;
-  float BgK = T_final * (cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2);  // Bg + T_final bg.g  (extra channel has bg 0)
+  float Tb = T_final;                                                         // (T, Bg) at the back end of the batch:
+  float Bb = T_final * (cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2);  // the same in all four waves
   for (uint32_t it = 0; it < nbat; ++it) {
-    if (wave == 0) {
-      const int slot = it & 1;
-      // groups of 4 entries, back to front; the LDS reads of the next group are issued before this group's dependent chain
-      float an[4], cn[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { an[u] = sA[slot][kBB - 1 - u][lane]; cn[u] = sD[slot][kBB - 1 - u][lane]; }
-#pragma unroll 1
-      for (int e0 = kBB - 1; e0 >= 0; e0 -= 4) {
-        float al[4], cg[4], wv[4], dv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { al[u] = an[u]; cg[u] = cn[u]; }
-        const int en = (e0 - 4 >= 0) ? e0 - 4 : kBB - 1;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { an[u] = sA[slot][en - u][lane]; cn[u] = sD[slot][en - u][lane]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float r = __builtin_amdgcn_rcpf(1.f - al[u]);
-          T = T * r;
-          wv[u] = al[u] * T;
-          dv[u] = __builtin_fmaf(T, cg[u], -(BgK * r));
-          BgK = __builtin_fmaf(wv[u], cg[u], BgK);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { sA[slot][e0 - u][lane] = wv[u]; sD[slot][e0 - u][lane] = dv[u]; }
-      }
-    } else {
-      const bool do_stage = (wave == 1) && (it + 2 < nbat);
-      if (do_stage) {
-        stage(it + 2, sg, sg2, sc, id_next);  // global gather in flight
-        id_next = load_ids(it + 3);
-      }
-      if (it >= 1) reduce(it - 1);
-      if (it + 1 < nbat) eval(it + 1);
-      if (do_stage && lane < kBB) {
-        const int ring = (it + 2) & 3;
-        sGeo[ring][lane] = sg; sGeo2[ring][lane] = sg2; sCol[ring][lane] = sc;
-      }
+    const float R0 = sR[it & 1][0][lane], R1 = sR[it & 1][1][lane], R2 = sR[it & 1][2][lane], R3 = sR[it & 1][3][lane];
+    const float B0 = sB[it & 1][0][lane], B1 = sB[it & 1][1][lane], B2 = sB[it & 1][2][lane], B3 = sB[it & 1][3][lane];
+    const bool do_stage = (wave == (int)((it + 2) & 3)) && (it + 2 < nbat);
+    if (do_stage) stage(it + 2, sg, sg2, sc, id_next);  // global gather in flight
+    if (wave == (int)((it + 3) & 3)) id_next = load_ids(it + 3);
+    // back to front: wave 3's segment is the deepest.  The same chain in every wave.
+    const float t3 = Tb, b3 = Bb;
+    const float t2 = t3 * R3, b2 = __builtin_fmaf(t3, B3, b3);
+    const float t1 = t2 * R2, b1 = __builtin_fmaf(t2, B2, b2);
+    const float t0 = t1 * R1, b0 = __builtin_fmaf(t1, B1, b1);
+    Tb = t0 * R0; Bb = __builtin_fmaf(t0, B0, b0);
+    replay(wave == 3 ? t3 : wave == 2 ? t2 : wave == 1 ? t1 : t0, wave == 3 ? b3 : wave == 2 ? b2 : wave == 1 ? b1 : b0);
+    reduce(it);
+    if (it + 1 < nbat) eval(it + 1);
+    if (do_stage && lane < kBB) {
+      const int ring = (it + 2) & 3;
+      sGeo[ring][lane] = sg; sGeo2[ring][lane] = sg2; sCol[ring][lane] = sc;
     }
     __syncthreads();
   }
-  if (wave >= 1) reduce(nbat - 1);  // drain
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2147,7 +2158,8 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   int e = 0;
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipMemsetAsync(scratch, 0, V * N * GSR_SCREEN_GRAD_FLOATS * sizeof(float), st));
-  hipLaunchKernelGGL(k_blend_bwd, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
+  if (p.dL_dextra_img) hipLaunchKernelGGL(k_blend_bwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_blend_bwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
