@@ -1661,35 +1661,58 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   // private to their lane, so no barrier is needed in between) before the cooperative store.  Half the LDS of an
   // in + out pair => twice the resident waves for this latency-bound kernel.
   float* sh_in = lds;
+  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0 && p.dL_dmeans2D != nullptr;
+  unsigned long long stamps[5] = {0, 0, 0, 0, 0};
+  if (dbg) stamps[0] = __builtin_amdgcn_s_memrealtime();
+  // this lane's own inputs are requested before the (long) SH staging so that one memory latency covers both
+  float rmx = 0, rmy = 0, rmz = 0, rcov[6] = {0, 0, 0, 0, 0, 0};
+  auto load_row = [&](int vv, float (&sg)[12]) {  // screen-space gradient row of (view, Gaussian): 48 B, three 16-byte loads
+    const float4* s = reinterpret_cast<const float4*>(p.scratch + ((size_t)(set * Vs + vv) * N + i) * GSR_SCREEN_GRAD_FLOATS);
+    const float4 s0 = s[0], s1 = s[1], s2 = s[2];
+    sg[0] = s0.x; sg[1] = s0.y; sg[2] = s0.z; sg[3] = s0.w; sg[4] = s1.x; sg[5] = s1.y; sg[6] = s1.z; sg[7] = s1.w;
+    sg[8] = s2.x; sg[9] = s2.y; sg[10] = s2.z; sg[11] = s2.w;
+  };
+  float sg_first[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (in_range) {
+    rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2];
+    load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, rcov);
+    load_row(0, sg_first);
+  }
   if (M > 0) {
     stage_rows(sh_in, p.colors + ((size_t)set * N + g0) * rowf, cnt, rowf, ldstride, lane);
     __syncthreads();
   }
-  float rmx = 0, rmy = 0, rmz = 0, rcov[6] = {0, 0, 0, 0, 0, 0};
-  if (in_range) {
-    rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2];
-    load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, rcov);
-  }
+  // With one view per set the SH gradient of coefficient k can take the LDS slot of coefficient k as soon as the mean
+  // gradient has used it: one walk.  With several views the coefficients must survive all of them: two walks (below).
+  const bool one_walk = (Vs == 1);
+  if (dbg) stamps[1] = __builtin_amdgcn_s_memrealtime();
   float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0};
+  bool seen = false;
   for (int vv = 0; vv < Vs; ++vv) {
     const int v = set * Vs + vv;
     const GsrView& cam = p.views[v];
     const size_t oi = (size_t)v * N + (in_range ? i : 0);
-    uint32_t bits = 0;
-    if (in_range) bits = __float_as_uint(p.geom[oi].q2.w);
-    const bool vis = in_range && (bits & 0x0fffffffu) != 0;
-    if (vis && M > 0) bits |= __float_as_uint(p.rgbc[oi].w) << 28;
-    float sg[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    if (vis) {
-      const float* s = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
+    float sg[12];
 #pragma unroll
-      for (int k = 0; k < 10; ++k) sg[k] = s[k];
+    for (int k = 0; k < 12; ++k) sg[k] = sg_first[k];
+    if (vv > 0) {
+#pragma unroll
+      for (int k = 0; k < 12; ++k) sg[k] = 0.f;
+      if (in_range) load_row(vv, sg);
     }
+    // A (view, Gaussian) the blend never touched (culled, off screen, or simply unseen) has an all-zero row and adds
+    // nothing below - and for a culled one the projection math is not even defined - so the row itself is the test.
+    bool vis = false;
+#pragma unroll
+    for (int k = 0; k < 10; ++k) vis = vis || (sg[k] != 0.f);
+    uint32_t bits = 0;
+    if (vis && M > 0) bits = __float_as_uint(p.rgbc[oi].w) << 28;
     if (in_range) {
       if (p.dL_dextra) p.dL_dextra[oi] = sg[9];
       if (p.dL_dmeans2D) { p.dL_dmeans2D[3 * oi + 0] = sg[0]; p.dL_dmeans2D[3 * oi + 1] = sg[1]; p.dL_dmeans2D[3 * oi + 2] = 0.f; }
     }
     if (!vis) continue;
+    seen = true;
     const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
     float cov6[6];
 #pragma unroll
@@ -1760,12 +1783,16 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const int ks = planar ? 1 : 3, cs = planar ? M : 1;
       float ddx = 0, ddy = 0, ddz = 0;
       const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
-      sh_visit(deg, x, y, z, [&](int k, float, float bx, float by, float bz) {
+      float* shw = sh_in + lane * ldstride;
+      sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
         if (k < M) {
           const float sd = sh[k * ks + 0 * cs] * d0 + sh[k * ks + 1 * cs] * d1 + sh[k * ks + 2 * cs] * d2;
           ddx += bx * sd; ddy += by * sd; ddz += bz * sd;
+          if (one_walk) { shw[k * ks + 0 * cs] = bk * d0; shw[k * ks + 1 * cs] = bk * d1; shw[k * ks + 2 * cs] = bk * d2; }
         }
       });
+      if (one_walk)  // coefficients above the evaluated degree get no gradient
+        for (int k = (deg + 1) * (deg + 1); k < M; ++k) { shw[k * ks + 0 * cs] = 0.f; shw[k * ks + 1 * cs] = 0.f; shw[k * ks + 2 * cs] = 0.f; }
       const float sum2 = ox * ox + oy * oy + oz * oz;
       const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
       dm[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
@@ -1787,6 +1814,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
   }
+  if (dbg) stamps[2] = __builtin_amdgcn_s_memrealtime();
   if (in_range) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) p.dL_dmeans[3 * gi + j] = dmean[j];
@@ -1800,7 +1828,15 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     p.dL_dopac[gi] = dop;
     if (M == 0) { p.dL_dcolors[3 * gi + 0] = dcol[0]; p.dL_dcolors[3 * gi + 1] = dcol[1]; p.dL_dcolors[3 * gi + 2] = dcol[2]; }
   }
-  if (M > 0) {
+  if (dbg) stamps[3] = __builtin_amdgcn_s_memrealtime();
+  if (M > 0 && one_walk) {
+    if (!seen) {  // this lane's Gaussian received no gradient: its row still holds the coefficients
+      float* dsh = sh_in + lane * ldstride;
+      for (int k = 0; k < rowf; ++k) dsh[k] = 0.f;
+    }
+    __syncthreads();
+    unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_in, cnt, rowf, ldstride, lane);
+  } else if (M > 0) {
     float* dsh = sh_in + lane * ldstride;  // this lane's row: the coefficients are no longer needed
     for (int k = 0; k < rowf; ++k) dsh[k] = 0.f;
     const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
@@ -1810,10 +1846,11 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const int v = set * Vs + vv;
       const GsrView& cam = p.views[v];
       const size_t oi = (size_t)v * N + i;
-      if ((__float_as_uint(p.geom[oi].q2.w) & 0x0fffffffu) == 0) continue;
-      const uint32_t cl = __float_as_uint(p.rgbc[oi].w);
       const float* sgp = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
-      const float d0 = (cl & 1u) ? 0.f : sgp[6], d1 = (cl & 2u) ? 0.f : sgp[7], d2 = (cl & 4u) ? 0.f : sgp[8];
+      const float c0 = sgp[6], c1 = sgp[7], c2 = sgp[8];
+      if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;
+      const uint32_t cl = __float_as_uint(p.rgbc[oi].w);
+      const float d0 = (cl & 1u) ? 0.f : c0, d1 = (cl & 2u) ? 0.f : c1, d2 = (cl & 4u) ? 0.f : c2;
       const float ox = rmx * cam.scale - cam.campos[0], oy = rmy * cam.scale - cam.campos[1], oz = rmz * cam.scale - cam.campos[2];
       const float len = sqrtf(ox * ox + oy * oy + oz * oz);
       sh_visit(deg, ox / len, oy / len, oz / len, [&](int k, float bk, float, float, float) {
@@ -1822,6 +1859,11 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     }
     __syncthreads();
     unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_in, cnt, rowf, ldstride, lane);
+  }
+  if (dbg && lane == 0) {  // measurement aid: phase stamps (100 MHz) over this workgroup's first dL/dmeans2D entries
+    stamps[4] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(p.dL_dmeans2D + 3 * ((size_t)set * Vs * N + g0));
+    for (int q = 0; q < 5; ++q) o[q] = stamps[q];
   }
 }
 

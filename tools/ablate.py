@@ -102,5 +102,36 @@ def main():
                   "max", per_tile_max.max().item(), "| per-pixel n_contrib mean", per_px.item(), flush=True)
 
 
+
+
+def bwd_phases():
+    """Phase stamps of k_preprocess_bwd (debug flag): staging, view walk, per-Gaussian outputs, SH gradient store."""
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(2, n, (256, 256))
+    means, cov6, opac, shs = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
+    vb = synthetic.scene_viewbuf(sc).to(dev)
+    cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False)
+    be = HipBackend()
+    plan = be.make_plan(cfg, dev, capacity=8 * n, backward=True)
+    g = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(3)).to(dev)
+    be.run_forward(plan, vb, means, cov6, opac, shs)
+    plan["dims"].flags = 0x2000
+    for _ in range(3):
+        be.run_backward(plan, vb, means, cov6, opac, shs, None, g)
+    torch.cuda.synchronize()
+    nb = (n + 63) // 64
+    nb -= 1  # full workgroups only
+    raw = plan["d_means2d"].reshape(-1)[: nb * 192].reshape(nb, 192)[:, :10].contiguous().view(torch.int64).reshape(nb, 5).cpu().double() * 0.01
+    q0 = lambda x: [round(v, 2) for v in torch.quantile(x, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)).tolist()]
+    names = ["SH staging", "view walk", "outputs", "SH grad store"]
+    print("preprocess_bwd phases (us, quantiles over workgroups): " +
+          " | ".join(f"{names[k]} {q0(raw[:, k + 1] - raw[:, k])}" for k in range(4)) +
+          f" | total {q0(raw[:, 4] - raw[:, 0])} | kernel span {(raw[:, 4].max() - raw[:, 0].min()).item():.2f} | start skew {q0(raw[:, 0] - raw[:, 0].min())}", flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "bwd":
+        bwd_phases()
+    else:
+        main()
