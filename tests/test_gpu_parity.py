@@ -245,3 +245,32 @@ def test_lazy_status_policy_poisons_and_raises_on_late_overflow():
     c4, _, _, _ = be.forward(cfg, vb, means, cov6 * 400.0, opac, colors, None)  # hint raised: fits now
     be.check_pending(wait=True)
     assert torch.isfinite(c4).all() and be.last_status["num_pairs"] > 1.25 * n1 and not be.last_status["overflow"]
+
+
+# ------------------------------------------------------------------ launch-path coverage: every binning variant the host code can pick
+def test_image_with_more_than_8192_tiles_uses_windowed_count_and_separate_scan():
+    """776 x 776 => 98 x 98 = 9604 8x8 tiles > the 8192-tile LDS window: k_preprocess + k_count (two windows) + k_tile_scan +
+    k_emit<false> instead of the fused kernels."""
+    cfg, res = _scene_case(21, 3000, (776, 776), with_extra=False)
+    assert cfg.height * cfg.width // 64 > 8192
+    _all_checks(cfg, res, max_tiles=128)
+
+
+def test_three_views_of_512x512_scan_is_a_separate_kernel():
+    """V x T = 3 x 4096 > 8192 tile totals: counting stays fused in preprocess, the range scan runs as its own kernel."""
+    cfg, res = _scene_case(22, 2500, (512, 512), views=3, with_extra=True)
+    _all_checks(cfg, res, max_tiles=64)
+
+
+def test_footprints_wider_than_the_mask_window_deferred_and_inline():
+    """700 splats that each cover a 128 x 128 image (16 x 16 tiles > the 8 x 8-tile mask window): more than the 256 wide
+    footprints a binning workgroup defers to whole-wave walks, so the in-line per-lane walk is exercised too."""
+    def f():
+        rng = np.random.default_rng(7)
+        n = 700
+        means = np.stack([rng.uniform(-1.0, 1.0, n), rng.uniform(-1.0, 1.0, n), rng.uniform(2, 6, n)], -1)
+        cov6 = np.tile([[16.0, 0, 0, 16.0, 0, 16.0]], (n, 1)) * rng.uniform(0.5, 1.5, (n, 1))
+        return dict(means=means, cov6=cov6, opac=rng.uniform(0.01, 0.05, n), colors=rng.uniform(0, 1, (n, 3)))
+    cfg, res = _custom(f, hw=(128, 128))
+    assert res["hip"]["status"]["max_list"] >= 600
+    _all_checks(cfg, res, max_tiles=64)
