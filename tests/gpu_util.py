@@ -77,6 +77,23 @@ def run_both(cfg: RasterConfig, viewbuf_cpu, means, cov6, opac, colors, extra=No
     return out
 
 
+def run_hip(cfg: RasterConfig, viewbuf_cpu, means, cov6, opac, colors, extra=None, g_color=None, g_extra=None):
+    """HIP backend only (cases the oracle has no defined answer for): -> dict(color, extra, radii, status[, grads])."""
+    dev = torch.device("cuda:0")
+    hip = rasterizer.HipBackend()
+    args_gpu = tuple(None if a is None else a.to(dev).contiguous() for a in (means, cov6, opac, colors, extra))
+    vb_gpu = viewbuf_cpu.to(dev)
+    hc, he, hr, hsaved = hip.forward(cfg, vb_gpu, *args_gpu)
+    torch.cuda.synchronize()
+    out = dict(color=hc.cpu().numpy(), extra=None if he is None else he.cpu().numpy(), radii=hr.cpu().numpy(), status=hip.last_status)
+    if g_color is not None:
+        hg = hip.backward(cfg, hsaved, vb_gpu, *args_gpu, g_color.to(dev), None if g_extra is None else g_extra.to(dev), True)
+        torch.cuda.synchronize()
+        names = ("means", "cov6", "opac", "colors", "extra", "means2d")
+        out["grads"] = {n: (None if t is None else t.cpu().numpy()) for n, t in zip(names, hg)}
+    return out
+
+
 def scene_tensors(scene, use_sh=True):
     from pf3plat_amd.synthetic import scene_operator_inputs
 

@@ -274,3 +274,48 @@ def test_footprints_wider_than_the_mask_window_deferred_and_inline():
     cfg, res = _custom(f, hw=(128, 128))
     assert res["hip"]["status"]["max_list"] >= 600
     _all_checks(cfg, res, max_tiles=64)
+
+
+def test_non_finite_inputs_are_culled_and_do_not_disturb_the_rest():
+    """NaN / Inf means or covariances: the splat is culled (radius 0); NaN opacity: the splat keeps its geometric radius (the
+    radius does not depend on opacity) but lists no tile, because `alpha >= 1/255` can hold nowhere.  Everything else renders
+    as if those splats were absent, gradients stay finite, and no kernel waits on a decision that can never become true."""
+    def base():
+        return random_small_scene(9, 400, sh_coeffs=0, dtype=np.float32)
+
+    def poisoned():
+        sc = base()
+        sc["means"][0] = np.nan
+        sc["means"][1, 2] = np.inf
+        sc["cov6"][2] = np.inf
+        sc["cov6"][3, 0] = np.nan
+        sc["opac"][4] = np.nan
+        sc["means"][5] = [1e30, -1e30, 1e30]
+        return sc
+
+    def removed():
+        sc = base()
+        for k in ("means", "cov6", "opac", "colors"):
+            sc[k] = sc[k][6:]
+        return sc
+
+    p = poisoned()
+    n = p["means"].shape[0]
+    cam = make_camera()
+    vb = gpu_util.viewbuf_from_cams([cam], [(0.2, 0.4, 0.6)])
+    t = lambda a: torch.tensor(np.asarray(a, dtype=np.float32))[None]
+    rng = np.random.default_rng(0)
+    gc = torch.tensor(rng.uniform(0, 1, (1, 3, 32, 32)).astype(np.float32))
+    hip_p = gpu_util.run_hip(RasterConfig(1, 1, 1, n, 32, 32, 0, 0, 4, False), vb, t(p["means"]), t(p["cov6"]), t(p["opac"]),
+                             t(p["colors"]), None, gc, None)
+    r = removed()
+    hip_r = gpu_util.run_hip(RasterConfig(1, 1, 1, n - 6, 32, 32, 0, 0, 4, False), vb, t(r["means"]), t(r["cov6"]), t(r["opac"]),
+                             t(r["colors"]), None, gc, None)
+    assert np.all(hip_p["radii"][0, [0, 1, 2, 3, 5]] == 0)
+    assert np.isfinite(hip_p["color"]).all()
+    np.testing.assert_array_equal(hip_p["color"], hip_r["color"])
+    for k in ("means", "cov6", "opac", "colors"):
+        g = hip_p["grads"][k]
+        assert np.isfinite(g).all(), k
+        assert np.all(g[0, :6] == 0), k
+        np.testing.assert_allclose(g[0, 6:], hip_r["grads"][k][0], rtol=1e-4, atol=1e-5)  # fp32 atomics: order-dependent sums
