@@ -153,10 +153,7 @@ def main():
     plan = be.make_plan(cfg, dev, capacity=8 * n, backward=True)
     be.run_forward(plan, viewbuf, means, cov6, opac, shs)
     st = be.read_status(plan)
-    if st["overflow"]:
-        plan = be.make_plan(cfg, dev, capacity=int(st["num_pairs"] * 1.1), backward=True)
-    else:
-        plan = be.make_plan(cfg, dev, capacity=int(st["num_pairs"] * 1.1) + 4096, backward=True)
+    plan = be.make_plan(cfg, dev, capacity=be.capacity_for(cfg, st, headroom=1.1), backward=True)
 
     def step():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
@@ -391,7 +388,7 @@ def main():
                 sc8 = synthetic.make_scene(2, n, (H, W), d_sh=D_SH, num_views=8, view_offsets=offs)
                 vb8 = synthetic.scene_viewbuf(sc8).to(dev)
                 cfg8 = RasterConfig(8, 1, 8, n, H, W, 4, D_SH, 4, False)
-                plan8 = be.make_plan(cfg8, dev, capacity=8 * int(status["num_pairs"] * 1.2))
+                plan8 = be.make_plan(cfg8, dev, capacity=be.capacity_for(cfg8, {"num_pairs": 8 * status["num_pairs"], "max_list": status["max_list"]}, headroom=1.3))
                 for _ in range(5):
                     be.run_forward(plan8, vb8, means, cov6, opac, shs)
                 torch.cuda.synchronize()

@@ -63,7 +63,10 @@ extern "C" {
 #define GSR_FLAG_ABLATE_EMIT_NO_STORE 0x400  /* emit: skip the key stores */
 #define GSR_FLAG_ABLATE_EMIT_NO_ATOMIC 0x800 /* emit: skip the slot atomics */
 #define GSR_FLAG_ABLATE_NO_GEOM_STORE 0x1000 /* preprocess: skip the projected-record store */
-#define GSR_FLAG_DEBUG_TIMING 0x2000         /* forward blend: per-tile cycle stamps into the (then unused) key buffer */
+#define GSR_FLAG_DEBUG_TIMING 0x2000
+/* Test aid: take the windowed binning path (preprocess, count, prefix, scan, emit, sort) even when the image has few enough
+ * tiles for the fused one (k_preprocess_bin + gathering sort). */
+#define GSR_FLAG_WINDOWED_BINNING 0x4000         /* forward blend: per-tile cycle stamps into the (then unused) key buffer */
 
 /* One camera = the non-tensor fields of upstream's GaussianRasterizationSettings
  * (constructed at cuda_splatting.py:99-112), 48 floats = 192 bytes. */
@@ -91,13 +94,13 @@ typedef struct GsrDims {
   int32_t max_sh_eval;    /* highest SH band evaluated (4; 3 = vanilla upstream) */
   int32_t has_extra;      /* 1 => `extra`/`out_extra` are used */
   int32_t flags;          /* bit0: prefiltered (ignored, as upstream without debug); bit1: debug */
-  int64_t pair_capacity;  /* capacity of the (tile,splat) pair workspaces, in pairs */
+  int64_t pair_capacity;  /* capacity of the (tile,splat) pair workspaces, in pairs; see gsr_capacity_for */
 } GsrDims;
 
 /* Host-visible status block written by gsr_forward at the start of the `bin` workspace. */
 typedef struct GsrStatus {
   uint64_t num_pairs;     /* total (8x8-tile, splat) pairs this call needs ("num_rendered") */
-  uint32_t overflow;      /* 1 => num_pairs > pair_capacity: nothing was blended, call again bigger */
+  uint32_t overflow;      /* 1 => pair_capacity too small (gsr_capacity_for): nothing was blended, call again bigger */
   uint32_t max_list;      /* longest per-tile list */
   uint64_t reserved[6];
 } GsrStatus;
@@ -111,6 +114,12 @@ const char* gsr_build_info(void);
  * lists (scales with pair_capacity); img: per-pixel final transmittance + contributor count.
  * Replaces upstream's geomBuffer/binningBuffer/imgBuffer resize callbacks. */
 int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes);
+
+/* The pair_capacity that suits a call of these dims, given the status block of an earlier (possibly overflowed) call on
+ * the same inputs.  Half of the index list is cut into one fixed slot per (view, tile), the other half is a shared region
+ * for lists longer than a slot: 2 x num_pairs always suffices; 2 x views x tiles x max_list additionally keeps every list
+ * in its slot (no shared counter on the sort path).  Returns the larger.  Host-only arithmetic; callers add headroom. */
+int64_t gsr_capacity_for(const GsrDims* dims, uint64_t num_pairs, uint32_t max_list);
 
 /* Forward: replaces upstream `_C.rasterize_gaussians` (called through
  * GaussianRasterizer.forward at cuda_splatting.py:116-124).  `extra`/`out_extra` may be NULL when

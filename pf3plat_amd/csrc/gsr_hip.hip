@@ -36,6 +36,8 @@ constexpr int kBinThreads = 1024; // threads of a binning workgroup (count / emi
 constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup (32 KiB)
 constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
 constexpr int kSortThreads = 256; // threads cooperating on one tile's sort
+constexpr int kPage = 1024;        // pairs per page of the key buffer: a binning workgroup's private region is whole pages
+constexpr int kStagePairs = 8192;  // pairs a binning workgroup collects in LDS (the 64 KB record-transpose area) before one linear copy-out
 constexpr float kNear = 0.2f;     // [EXT] auxiliary.h in_frustum: p_view.z <= 0.2f culls
 
 struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one record = half a cache line
@@ -67,7 +69,10 @@ __host__ __device__ inline Grid make_grid(int W, int H) {
 struct Layout {
   size_t geom_bytes, bin_bytes, img_bytes;
   size_t o_rgbc;  // in geom
-  size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list;  // in bin
+  size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list, o_blk, o_blktot;  // in bin
+  size_t key_slots;  // keys: one fixed slot of kStagePairs keys per binning workgroup, then ...
+  size_t key_pages;  // ... a pool of pages of kPage keys (regions / scratch too long for a slot)
+  size_t stride;     // fused binning: entries of the index list owned by every (view, tile)
   size_t o_finalT, o_ncontrib;                                   // in img
 };
 
@@ -97,11 +102,19 @@ static Layout make_layout(const GsrDims& d) {
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
   const size_t rows = (N + choose_chunk(d) - 1) / choose_chunk(d);
-  L.o_counts = o; o = align_up(o + VT * (rows > 0 ? rows : 1) * 4, 256);
+  L.o_counts = o; o = align_up(o + VT * (rows > 0 ? rows : 1) * 8, 256);  // uint2 (offset in the row's region, count)
   L.o_total = o; o = align_up(o + VT * 4, 256);
   L.o_ranges = o; o = align_up(o + VT * 8, 256);
-  L.o_keys = o; o = align_up(o + cap * 8, 256);
+  // keys: a fixed slot per binning workgroup (all it needs unless it lists more than kStagePairs pairs), then a page pool
+  // for the longer regions and for the contiguous scratch of per-tile lists too long for the LDS sort (every pair twice)
+  const size_t blocks = V * (rows > 0 ? rows : 1);
+  L.key_slots = blocks * (size_t)kStagePairs;
+  L.key_pages = (2 * cap + kPage - 1) / kPage + 64;
+  L.o_keys = o; o = align_up(o + (L.key_slots + L.key_pages * kPage) * 8, 256);
   L.o_list = o; o = align_up(o + cap * 4, 256);
+  L.o_blk = o; o = align_up(o + blocks * 4, 256);
+  L.o_blktot = o; o = align_up(o + blocks * 4, 256);
+  L.stride = VT > 0 ? cap / (2 * VT) : 0;  // half of the index list in per-tile slots, the rest a shared tail (longer lists)
   L.bin_bytes = o;
   const size_t px = V * (size_t)d.height * d.width;
   L.o_finalT = 0;
@@ -123,7 +136,16 @@ struct Params {
   GeomRec* geom;
   float4* rgbc;
   GsrStatus* status;
-  uint32_t* counts;
+  uint32_t* counts;      // windowed path: u32 count matrix; fused path: the same storage as uint2 (offset, count)
+  uint2* pair_mat;
+  uint32_t* blk_base;    // fused path: first key of every binning workgroup's region (0xffffffff: not stored)
+  uint32_t* blk_total;   // fused path: pairs listed by every binning workgroup
+  uint32_t key_pages;    // pages in the pool behind the fixed slots
+  uint32_t pool_off;     // first key of the pool
+  uint32_t stride;       // index-list entries owned by every (view, tile)
+  uint32_t tail_off, tail_cap;  // the rest of the index list: lists longer than `stride`, bump-allocated
+  uint32_t* tail_counter;
+  uint32_t* page_counter;  // in the status block: pages of the key buffer handed out so far
   uint32_t* tile_total;
   uint2* ranges;
   unsigned long long* keys;
@@ -397,6 +419,39 @@ __device__ __forceinline__ void big_walk_wave(const Foot& ft, const Grid& g, int
 }
 constexpr int kBigList = 256;  // deferred wide footprints per binning workgroup (more are walked in line)
 
+__device__ __forceinline__ Foot foot_of_record(const GeomRec* rec, const Grid& g) {
+  const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
+  return make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
+}
+// Walks the (tile) pairs of one Gaussian from its record's q3 word (hit mask, origin, depth).
+template <class F, class B>
+__device__ __forceinline__ void walk_pairs(const Params& p, const float4 q3, int i, int t0, int t1, F&& f, B&& big) {
+  const Grid& g = p.g;
+  const uint32_t origin = __float_as_uint(q3.z);
+  unsigned long long m = ((unsigned long long)__float_as_uint(q3.y) << 32) | __float_as_uint(q3.x);
+  const int sx0 = (int)(origin & 0xfffu), sy0 = (int)((origin >> 12) & 0xfffu);
+  while (m) {
+    const int b = __ffsll((long long)m) - 1;
+    m &= m - 1;
+    const int t = (sy0 + (b >> 3)) * g.sgx + sx0 + (b & 7);
+    if (t >= t0 && t < t1) f(i, t, q3.w);
+  }
+  if (origin & 0x80000000u) big(i);  // footprint wider than the 8x8-tile mask window
+}
+template <class F>
+__device__ __forceinline__ void for_each_pair(const Params& p, int v, int row, int tid, int t0, int t1, F&& f) {
+  const int N = p.d.num_gaussians;
+  const int end = min(N, (row + 1) * p.chunk);
+  for (int i = row * p.chunk + tid; i < end; i += kBinThreads) {
+    const GeomRec* rec = p.geom + (size_t)v * N + i;
+    const float4 q3 = rec->q3;
+    walk_pairs(p, q3, i, t0, t1, f, [&](int) {
+      const Foot ft = foot_of_record(rec, p.g);
+      big_walk_lane(ft, p.g, [&](int t) { if (t >= t0 && t < t1) f(i, t, q3.w); });
+    });
+  }
+}
+
 // Wave-cooperative copy of `cnt` rows of `rowf` floats from global to LDS (row stride ldstride floats).
 __device__ __forceinline__ void stage_rows(float* lds, const float* src, int cnt, int rowf, int ldstride, int lane) {
   const int total = cnt * rowf;
@@ -516,7 +571,7 @@ __device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i,
         }
       } else {
         origin |= 0x80000000u;
-        big(i, f);
+        big(i, f, pvz);
       }
     }
   }
@@ -555,7 +610,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   const int lane = threadIdx.x & 63, first = i - lane;
   if (first >= N) return;
   GeomRec rec{};
-  if (i < N) rec = preprocess_one(p, v, i, [](int) {}, [](int, const Foot&) {});
+  if (i < N) rec = preprocess_one(p, v, i, [](int) {}, [](int, const Foot&, float) {});
   if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
     store_records_wave(p.geom + (size_t)v * N + first, N - first, rec, stage[threadIdx.x >> 6], lane);
 }
@@ -563,64 +618,177 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
 // Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the `chunk` Gaussians of
 // one row of the count matrix, histograms their pairs in LDS while it projects them and stores the row at the end -
 // k_count's result without a second pass over the records and without its launch.
-__global__ __launch_bounds__(kBinThreads) void k_preprocess_count(const Params p) {
-  extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB (record transpose), then T histogram counters
+// Measurement aid: eight 64-bit stamps per slot at the very end of the key buffer (pages handed out last, so unused in
+// any run that does not overflow).
+__device__ __forceinline__ unsigned long long* dbg_stamps(const Params& p, size_t slot) {
+  return p.keys + (size_t)p.pool_off + (size_t)p.key_pages * kPage - (slot + 1) * 8;
+}
+
+__device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
+  Foot f;
+  f.cx = b[0]; f.cy = b[1]; f.A = b[2]; f.B = b[3]; f.C = b[4]; f.tau = b[5];
+  f.nBiC = -f.B / f.C; f.nBiA = -f.B / f.A;
+  const int xs = __float_as_int(b[6]), ys = __float_as_int(b[7]);
+  f.sx0 = xs & 0xffff; f.sx1 = xs >> 16; f.sy0 = ys & 0xffff; f.sy1 = ys >> 16;
+  const float detc = f.A * f.C - f.B * f.B;
+  f.convex = (f.A > 0.f) && (f.C > 0.f) && (detc > 0.f) && (detc < 3.0e38f);
+  f.detc = detc; f.hx = 0.f; f.hy = 0.f;
+  return f;
+}
+
+// K1 (images of up to kTileWindow tiles): preprocess AND the whole binning of this workgroup's `chunk` Gaussians.
+//   1. preprocess the Gaussians; histogram their (tile, splat) pairs per tile in LDS; records leave through the transpose;
+//   2. exclusive scan of the histogram over the tiles = where each tile's pairs start INSIDE this workgroup's own region
+//      of the key buffer; the row (offset, count) per tile goes to the pair matrix [view][row][tile];
+//   3. the region itself is the workgroup's own fixed slot of kStagePairs keys (no atomics at all), or - for the rare workgroup
+//      that lists more - a run of pages taken from a bump counter (one device atomic);
+//   4. the pairs are walked again from the hit masks still in registers, take their slot with an LDS atomic and are
+//      collected in LDS (the 64 KB transpose area, free by now) so that the region is written by one linear copy - keys
+//      stored pair by pair are 64 separate 8-byte requests per instruction and were the longest phase of the old emit.
+// Nothing here depends on another workgroup: no count matrix prefix, no tile scan, no second pass over the records.
+// k_sort_tiles<true> later collects a tile's list from the <= rows regions (column (v, :, t) of the pair matrix).
+// The bump counter is left at zero by the blend kernel of the previous call; a dirty counter can only cause a (reported)
+// overflow, never an out-of-range store.  (Same-address device atomics cost ~17 ns each on this chip, one after the other:
+// a counter hit by every workgroup of a launch is a serial section, hence the fixed slots here and in the sort.)
+__global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) {
+  extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters
   uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kBinThreads / 64) * 256);
-  __shared__ float bigs[kBigList][8];
-  __shared__ uint32_t nbig;
-  const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
+  __shared__ float bigs[kBigList][10];
+  __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T, N = p.d.num_gaussians;
   const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
-  unsigned long long* stamp = p.keys + (size_t)p.d.pair_capacity - 8192 - (size_t)(blockIdx.x + 1) * 8;
+  unsigned long long* stamp = dbg_stamps(p, (size_t)(blockIdx.y * gridDim.x + blockIdx.x));
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
   for (int k = tid; k < T; k += kBinThreads) hist[k] = 0;
-  if (tid == 0) nbig = 0;
-  __syncthreads();
-  GSR_STAMP(1);
-  const int end = min(N, (row + 1) * p.chunk);
-  int it = 2;
-  float4* stage = dyn_stage + (tid >> 6) * 256;
-  for (int first = row * p.chunk + (tid & ~63); first < end; first += kBinThreads) {  // wave-uniform trip count
-    const int i = first + (tid & 63);
-    GeomRec rec{};
-    if (i < end)
-      rec = preprocess_one(p, v, i, [&](int t) { atomicAdd(&hist[t], 1u); },
-                   [&](int, const Foot& f) {
-                     const uint32_t slot = atomicAdd(&nbig, 1u);
-                     if (slot < (uint32_t)kBigList) {
-                       float* b = bigs[slot];
-                       b[0] = f.cx; b[1] = f.cy; b[2] = f.A; b[3] = f.B; b[4] = f.C; b[5] = f.tau;
-                       b[6] = __int_as_float(f.sx0 | (f.sx1 << 16)); b[7] = __int_as_float(f.sy0 | (f.sy1 << 16));
-                     } else {
-                       big_walk_lane(f, p.g, [&](int t) { atomicAdd(&hist[t], 1u); });
-                     }
-                   });
-    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
-      store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, tid & 63);
-    GSR_STAMP(it);
-    ++it;
-  }
-  __syncthreads();
-  {  // wide footprints: one wave each, 64 candidate tiles per step
-    const int nb = (int)min(nbig, (uint32_t)kBigList), lane = tid & 63;
-    for (int e = tid >> 6; e < nb; e += kBinThreads / 64) {
-      const float* b = bigs[e];
-      Foot f;
-      f.cx = b[0]; f.cy = b[1]; f.A = b[2]; f.B = b[3]; f.C = b[4]; f.tau = b[5];
-      f.nBiC = -f.B / f.C; f.nBiA = -f.B / f.A;
-      const int xs = __float_as_int(b[6]), ys = __float_as_int(b[7]);
-      f.sx0 = xs & 0xffff; f.sx1 = xs >> 16; f.sy0 = ys & 0xffff; f.sy1 = ys >> 16;
-      const float detc = f.A * f.C - f.B * f.B;
-      f.convex = (f.A > 0.f) && (f.C > 0.f) && (detc > 0.f) && (detc < 3.0e38f);
-      big_walk_wave(f, p.g, lane, [&](int t) { atomicAdd(&hist[t], 1u); });
+  if (tid == 0) {
+    nbig = 0;
+    if (row == 0 && v == 0) {  // only k_sort_tiles touches these, and it runs after this kernel
+      p.status->overflow = 0; p.status->max_list = 0; *p.tail_counter = 0u;
     }
   }
   __syncthreads();
+  const int end = min(N, (row + 1) * p.chunk);
+  float4* stage = dyn_stage + w * 256;
+  constexpr int kIters = kChunkMax / kBinThreads;
+  float4 q3s[kIters];
+  uint32_t inl = 0;  // bit it: this lane's wide footprint of iteration it did not fit the deferred list
+  auto count = [&](int t) { atomicAdd(&hist[t], 1u); };
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int first = row * p.chunk + (tid & ~63) + it * kBinThreads;
+    q3s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (first >= end) continue;  // wave-uniform
+    const int i = first + lane;
+    GeomRec rec{};
+    if (i < end) {
+      rec = preprocess_one(p, v, i, count, [&](int gi, const Foot& f, float depth) {
+        const uint32_t slot = atomicAdd(&nbig, 1u);
+        if (slot < (uint32_t)kBigList) {
+          float* b = bigs[slot];
+          b[0] = f.cx; b[1] = f.cy; b[2] = f.A; b[3] = f.B; b[4] = f.C; b[5] = f.tau;
+          b[6] = __int_as_float(f.sx0 | (f.sx1 << 16)); b[7] = __int_as_float(f.sy0 | (f.sy1 << 16));
+          b[8] = __int_as_float(gi); b[9] = depth;
+        } else {
+          inl |= 1u << it;
+          big_walk_lane(f, p.g, count);
+        }
+      });
+      q3s[it] = rec.q3;
+    }
+    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
+      store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
+  }
+  __syncthreads();
+  const int nb = (int)min(nbig, (uint32_t)kBigList);
+  for (int e = w; e < nb; e += kBinThreads / 64)  // wide footprints: one wave each, 64 candidate tiles per step
+    big_walk_wave(foot_from_lds(bigs[e], p.g), p.g, lane, count);
+  __syncthreads();
+  GSR_STAMP(1);
+  // ---- 2. exclusive scan of the histogram over the tiles (thread t owns `per` consecutive tiles)
+  const int per = (T + kBinThreads - 1) / kBinThreads;  // <= kTileWindow / kBinThreads
+  const int b0 = tid * per;
+  uint32_t cnt[kTileWindow / kBinThreads], sum = 0;
+#pragma unroll
+  for (int q = 0; q < kTileWindow / kBinThreads; ++q) {
+    cnt[q] = (q < per && b0 + q < T) ? hist[b0 + q] : 0u;
+    sum += cnt[q];
+  }
+  uint32_t incl = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64);
+    if (lane >= o) incl += x;
+  }
+  if (lane == 63) wtot[w] = incl;
+  __syncthreads();  // also: every histogram counter has been read
+  uint32_t basew = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < kBinThreads / 64; ++k) {
+    const uint32_t x = wtot[k];
+    basew += (k < w) ? x : 0u;
+    total += x;
+  }
+  // ---- 3. this workgroup's region of the key buffer: its own fixed slot, or (more than kStagePairs pairs) pool pages
+  if (tid == 0) {
+    const size_t blk = (size_t)v * p.rows + row;
+    uint32_t base = (uint32_t)(blk * kStagePairs);
+    if (total > (uint32_t)kStagePairs) {
+      const uint32_t npages = (total + kPage - 1) / kPage;
+      const uint32_t first = atomicAdd(p.page_counter, npages);
+      base = (first <= p.key_pages && npages <= p.key_pages - first) ? p.pool_off + first * (uint32_t)kPage : 0xffffffffu;
+    }
+    sBase = base;
+    p.blk_base[blk] = base;
+    p.blk_total[blk] = total;
+  }
+  uint2* mrow = p.pair_mat + ((size_t)v * p.rows + row) * T;
+  uint32_t run = basew + incl - sum;
+#pragma unroll
+  for (int q = 0; q < kTileWindow / kBinThreads; ++q)
+    if (q < per && b0 + q < T) {
+      mrow[b0 + q] = make_uint2(run, cnt[q]);
+      hist[b0 + q] = run;  // from here on: the tile's cursor inside the region
+      run += cnt[q];
+    }
+  __syncthreads();
+  GSR_STAMP(2);
+  const uint32_t base = sBase;
+  if (base == 0xffffffffu || total == 0) return;  // key buffer too small (k_sort_tiles reports it) / nothing to list
+  // ---- 4. the pairs, again, now to their slots
+  const bool staged = total <= (uint32_t)kStagePairs;
+  unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(dyn_stage);
+  unsigned long long* region = p.keys + base;
+  auto put = [&](int gi, int t, float depth) {
+    const uint32_t slot = atomicAdd(&hist[t], 1u);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
+    if (staged) lds_keys[slot] = key;
+    else region[slot] = key;
+  };
+#pragma unroll
+  for (int it = 0; it < kIters; ++it) {
+    const int i = row * p.chunk + (tid & ~63) + it * kBinThreads + lane;
+    if (i >= end) continue;
+    walk_pairs(p, q3s[it], i, 0, T, put, [&](int gi) {
+      if (!((inl >> it) & 1u)) return;  // deferred: walked by a whole wave below
+      const Foot ft = foot_of_record(p.geom + (size_t)v * N + gi, p.g);  // this wave's own store, complete since the barriers
+      const float depth = q3s[it].w;
+      big_walk_lane(ft, p.g, [&](int t) { put(gi, t, depth); });
+    });
+  }
+  for (int e = w; e < nb; e += kBinThreads / 64) {
+    const float* b = bigs[e];
+    const int gi = __float_as_int(b[8]);
+    const float depth = b[9];
+    big_walk_wave(foot_from_lds(b, p.g), p.g, lane, [&](int t) { put(gi, t, depth); });
+  }
+  GSR_STAMP(3);
+  if (staged) {
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += kBinThreads) region[k] = lds_keys[k];
+  }
   GSR_STAMP(4);
-  uint32_t* out = p.counts + ((size_t)v * p.rows + row) * T;
-  for (int k = tid; k < T; k += kBinThreads) out[k] = hist[k];
-  GSR_STAMP(5);
 #undef GSR_STAMP
 }
 
@@ -697,39 +865,6 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
 //   K4 emit  : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
 // Count and emit walk the same footprints with the same code, so slots match counts exactly.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ Foot foot_of_record(const GeomRec* rec, const Grid& g) {
-  const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
-  return make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
-}
-// Walks the (tile) pairs of one Gaussian from its record's q3 word (hit mask, origin, depth).
-template <class F, class B>
-__device__ __forceinline__ void walk_pairs(const Params& p, const float4 q3, int i, int t0, int t1, F&& f, B&& big) {
-  const Grid& g = p.g;
-  const uint32_t origin = __float_as_uint(q3.z);
-  unsigned long long m = ((unsigned long long)__float_as_uint(q3.y) << 32) | __float_as_uint(q3.x);
-  const int sx0 = (int)(origin & 0xfffu), sy0 = (int)((origin >> 12) & 0xfffu);
-  while (m) {
-    const int b = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    const int t = (sy0 + (b >> 3)) * g.sgx + sx0 + (b & 7);
-    if (t >= t0 && t < t1) f(i, t, q3.w);
-  }
-  if (origin & 0x80000000u) big(i);  // footprint wider than the 8x8-tile mask window
-}
-template <class F>
-__device__ __forceinline__ void for_each_pair(const Params& p, int v, int row, int tid, int t0, int t1, F&& f) {
-  const int N = p.d.num_gaussians;
-  const int end = min(N, (row + 1) * p.chunk);
-  for (int i = row * p.chunk + tid; i < end; i += kBinThreads) {
-    const GeomRec* rec = p.geom + (size_t)v * N + i;
-    const float4 q3 = rec->q3;
-    walk_pairs(p, q3, i, t0, t1, f, [&](int) {
-      const Foot ft = foot_of_record(rec, p.g);
-      big_walk_lane(ft, p.g, [&](int t) { if (t >= t0 && t < t1) f(i, t, q3.w); });
-    });
-  }
-}
-
 __global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
   __shared__ uint32_t hist[kTileWindow];
   const int tid = threadIdx.x, row = blockIdx.x, v = blockIdx.y;
@@ -1060,24 +1195,131 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 // 64-bit (depth, index) compare.  ~40 B of LDS traffic per key instead of ~800 B for an in-LDS bitonic network.
 // Degenerate depth distributions (a span longer than kSpanMax) fall back to the bitonic network on the same LDS
 // array; lists longer than kSortLds sort in place in global memory with the same network.
+// kGather = false: the tile's keys are a contiguous range (ranges[]) written by k_emit.
+// kGather = true : the tile's keys sit in up to `rows` runs, one per binning workgroup (k_preprocess_bin): column
+//   (view, :, tile) of the pair matrix says where and how many.  The workgroup sums the column, copies the runs into LDS in
+//   row order - after which everything is as in the contiguous case - and writes the sorted indices into the tile's own
+//   fixed slot of the index list (`stride` = pair_capacity / (2 x views x tiles) entries; a longer list takes a run of the
+//   shared second half from a bump counter: correct for any distribution as long as pair_capacity >= 2 x pairs, and free of
+//   shared counters when pair_capacity >= 2 x views x tiles x longest list).
+template <bool kGather>
 __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   __shared__ unsigned long long sk[kSortLds];
   __shared__ uint32_t hist[kBuckets];  // counts, then (same storage) scatter cursors
   __shared__ uint32_t red[8];
+  __shared__ uint32_t sInfo[4];
   uint32_t* cur = hist;
   const int tid = threadIdx.x;
   const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
-  unsigned long long* stamp = reinterpret_cast<unsigned long long*>(p.counts) + (size_t)blockIdx.x * 8;
+  unsigned long long* stamp = dbg_stamps(p, 8192 + blockIdx.x);
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
-  const uint2 rg = p.ranges[blockIdx.x];
-  const int n = (int)(rg.y - rg.x);
-  if (n == 0) return;
-  unsigned long long* keys = p.keys + rg.x;
-  uint32_t* out = p.point_list + rg.x;
-  if (n == 1) {
-    if (tid == 0) out[0] = (uint32_t)keys[0];
-    return;
+  int n;
+  unsigned long long* keys;  // global memory: contiguous keys (kGather: only for lists longer than the LDS sort)
+  uint32_t* out;
+  if (kGather) {
+    const int T = p.g.T, R = p.rows;
+    const int v = blockIdx.x / T, t = blockIdx.x - v * T;
+    const uint2* col = p.pair_mat + (size_t)v * R * T + t;
+    const uint32_t* bb = p.blk_base + (size_t)v * R;
+    // the length of the list, and whether every run was stored.  With up to kSortThreads rows (the usual case) a thread keeps
+    // its row's (offset, count) and region base in registers; with more the column is read again for the copy.
+    const bool one_stride = R <= kSortThreads;
+    uint2 e0 = make_uint2(0u, 0u);
+    uint32_t bb0 = 0, cnt_sum = 0, missing = 0;
+    if (one_stride) {
+      if (tid < R) { e0 = col[(size_t)tid * T]; bb0 = bb[tid]; }
+      cnt_sum = e0.y;
+      missing = (e0.y != 0u && bb0 == 0xffffffffu) ? 1u : 0u;
+    } else {
+      for (int r = tid; r < R; r += kSortThreads) {
+        const uint32_t c = col[(size_t)r * T].y;
+        cnt_sum += c;
+        missing |= (c != 0u && bb[r] == 0xffffffffu) ? 1u : 0u;
+      }
+    }
+    uint32_t total;
+    const uint32_t start0 = block_exclusive_scan(cnt_sum, red, tid, total);
+    const bool any_missing = __syncthreads_or((int)missing) != 0;
+    n = (int)total;
+    if (tid == 0) {
+      // the tile's range of the index list: its own fixed slot of `stride` entries (no counter shared with other tiles), or -
+      // a list longer than that - a run of the tail region behind the slots, taken from a bump counter
+      uint32_t rbase = blockIdx.x * p.stride, ok = any_missing ? 0u : 1u, scratch = 0;
+      if ((uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
+      if (ok && (uint32_t)n > p.stride) {
+        const uint32_t at = atomicAdd(p.tail_counter, (uint32_t)n);
+        if (at <= p.tail_cap && (uint32_t)n <= p.tail_cap - at) rbase = p.tail_off + at;
+        else ok = 0;
+      }
+      if (ok && n > kSortLds) {  // contiguous scratch for the in-place global sort, from the page pool
+        const uint32_t np = ((uint32_t)n + kPage - 1) / kPage;
+        const uint32_t first = atomicAdd(p.page_counter, np);
+        if (first <= p.key_pages && np <= p.key_pages - first) scratch = p.pool_off + first * (uint32_t)kPage;
+        else ok = 0;
+      }
+      if (!ok) p.status->overflow = 1u;
+      p.ranges[blockIdx.x] = ok ? make_uint2(rbase, rbase + (uint32_t)n) : make_uint2(0u, 0u);
+      sInfo[0] = rbase; sInfo[1] = ok; sInfo[2] = scratch;
+    }
+    if (blockIdx.x == 0) {  // total pair count = sum of the binning workgroups' totals
+      unsigned long long part = 0;
+      for (int k = tid; k < p.d.num_views * R; k += kSortThreads) part += p.blk_total[k];
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+      __shared__ unsigned long long sPart[kSortThreads / 64];
+      if ((tid & 63) == 0) sPart[tid >> 6] = part;
+      __syncthreads();
+      if (tid == 0) p.status->num_pairs = sPart[0] + sPart[1] + sPart[2] + sPart[3];
+    }
+    __syncthreads();
+    if (!sInfo[1] || n == 0) return;
+    out = p.point_list + sInfo[0];
+    keys = p.keys + sInfo[2];
+    unsigned long long* dst = n > kSortLds ? keys : sk;
+    // copy the runs, in row order; four keys in flight per thread (runs are ~5 keys long)
+    auto copy_run = [&](const unsigned long long* src, uint32_t cnt, uint32_t start) {
+      uint32_t j = 0;
+      for (; j + 4 <= cnt; j += 4) {
+        const unsigned long long k0 = src[j], k1 = src[j + 1], k2 = src[j + 2], k3 = src[j + 3];
+        dst[start + j] = k0; dst[start + j + 1] = k1; dst[start + j + 2] = k2; dst[start + j + 3] = k3;
+      }
+      unsigned long long k0 = 0, k1 = 0, k2 = 0;
+      if (j < cnt) k0 = src[j];
+      if (j + 1 < cnt) k1 = src[j + 1];
+      if (j + 2 < cnt) k2 = src[j + 2];
+      if (j < cnt) dst[start + j] = k0;
+      if (j + 1 < cnt) dst[start + j + 1] = k1;
+      if (j + 2 < cnt) dst[start + j + 2] = k2;
+    };
+    if (one_stride) {
+      if (e0.y) copy_run(p.keys + bb0 + e0.x, e0.y, start0);
+      __syncthreads();
+    } else {
+      uint32_t carry = 0;
+      for (int r0 = 0; r0 < R; r0 += kSortThreads) {
+        const int r = r0 + tid;
+        const uint2 e = r < R ? col[(size_t)r * T] : make_uint2(0u, 0u);
+        uint32_t tot;
+        const uint32_t start = carry + block_exclusive_scan(e.y, red, tid, tot);
+        carry += tot;
+        if (e.y) copy_run(p.keys + bb[r] + e.x, e.y, start);
+        __syncthreads();  // red[] is reused by the next stride
+      }
+    }
+    if (n == 1) {
+      if (tid == 0) out[0] = (uint32_t)dst[0];
+      return;
+    }
+  } else {
+    const uint2 rg = p.ranges[blockIdx.x];
+    n = (int)(rg.y - rg.x);
+    if (n == 0) return;
+    keys = p.keys + rg.x;
+    out = p.point_list + rg.x;
+    if (n == 1) {
+      if (tid == 0) out[0] = (uint32_t)keys[0];
+      return;
+    }
   }
   int lgnp = 1;
   while ((1 << lgnp) < n) ++lgnp;
@@ -1093,7 +1335,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     const int k = tid + q * kSortThreads;
-    kreg[q] = (k < n) ? keys[k] : ~0ull;
+    kreg[q] = (k < n) ? (kGather ? sk[k] : keys[k]) : ~0ull;
     if (k < n) {
       const uint32_t d = (uint32_t)(kreg[q] >> 32);
       lo = d < lo ? d : lo;
@@ -1244,6 +1486,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
   const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
 
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.page_counter = 0u;  // leave the bump counter clean for the next call
   if (p.status->overflow) {  // pair workspace too small: nothing was binned.  Poison the outputs so the condition cannot go
     if (wave == 0 && inside) {  // unnoticed even when the caller defers reading the status block.
       const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
@@ -1998,6 +2241,20 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   p.rgbc = geom ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rgbc) : nullptr;
   p.status = reinterpret_cast<GsrStatus*>(b + L.o_status);
   p.counts = reinterpret_cast<uint32_t*>(b + L.o_counts);
+  p.pair_mat = reinterpret_cast<uint2*>(b + L.o_counts);
+  p.blk_base = reinterpret_cast<uint32_t*>(b + L.o_blk);
+  p.blk_total = reinterpret_cast<uint32_t*>(b + L.o_blktot);
+  p.key_pages = (uint32_t)L.key_pages;
+  p.pool_off = (uint32_t)L.key_slots;
+  p.stride = (uint32_t)(L.stride > 0xffffffffull ? 0xffffffffull : L.stride);
+  {
+    const unsigned long long VTs = (unsigned long long)d->num_views * p.g.T * p.stride;
+    const unsigned long long capq = d->pair_capacity > 0 ? (unsigned long long)d->pair_capacity : 0ull;
+    p.tail_off = (uint32_t)(VTs > 0xffffffffull ? 0xffffffffull : VTs);
+    p.tail_cap = (uint32_t)(capq > VTs ? (capq - VTs > 0xffffffffull ? 0xffffffffull : capq - VTs) : 0ull);
+  }
+  p.tail_counter = reinterpret_cast<uint32_t*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[1]);
+  p.page_counter = reinterpret_cast<uint32_t*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[0]);
   p.tile_total = reinterpret_cast<uint32_t*>(b + L.o_total);
   p.ranges = reinterpret_cast<uint2*>(b + L.o_ranges);
   p.keys = reinterpret_cast<unsigned long long*>(b + L.o_keys);
@@ -2060,6 +2317,13 @@ int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_byt
   return GSR_OK;
 }
 
+int64_t gsr_capacity_for(const GsrDims* dims, uint64_t num_pairs, uint32_t max_list) {
+  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+  const Grid g = make_grid(dims->width, dims->height);
+  const uint64_t slots = (uint64_t)dims->num_views * (uint64_t)g.T * (uint64_t)max_list;
+  return (int64_t)(2 * (slots > num_pairs ? slots : num_pairs));
+}
+
 // Debug aid for tests: byte offsets of the sub-buffers inside bin (6) and img (2).
 int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8) {
   if (!dims_ok(dims) || !offsets8) return GSR_ERR_INVALID_ARGUMENT;
@@ -2109,34 +2373,42 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, ss->stream, p);
     GSR_CHECK(hipEventRecord(ss->join, ss->stream));
   }
-  const bool fused_count = p.g.T <= kTileWindow && !(d.flags & GSR_FLAG_ABLATE_NO_COUNT);
-  if (fused_count) {
+  // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin + gathering sort: 2 launches);
+  // larger ones the windowed path (preprocess, count, prefix, scan, emit, sort: 5-6 launches).
+  const bool fused_bin = p.g.T <= kTileWindow && !(d.flags & (GSR_FLAG_ABLATE_NO_COUNT | GSR_FLAG_WINDOWED_BINNING));
+  if (fused_bin) {
     static std::atomic<unsigned long long> lds_set{0ull};  // per device: > 64 KB of dynamic LDS has to be asked for
     int dev = 0;
     GSR_CHECK(hipGetDevice(&dev));
     if (!((lds_set.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
-      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_count),
+      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kBinThreads / 64 * 4096 + kTileWindow * 4));
       lds_set.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(k_preprocess_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads),
+    hipLaunchKernelGGL(k_preprocess_bin, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads),
                        kBinThreads / 64 * 4096 + (size_t)p.g.T * 4, st, p);
+  } else {
+    hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   }
-  else hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   GSR_MARK();
   if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
   GSR_MARK();
-  if (!fused_count) hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
-  hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 15) / 16)), dim3(1024), 0, st, p);
+  if (!fused_bin) {
+    hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+    hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 15) / 16)), dim3(1024), 0, st, p);
+  }
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
-  if (!scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
+  if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
   GSR_MARK();
-  if (scan_in_emit) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
-  else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  if (!fused_bin) {
+    if (scan_in_emit) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+    else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
+  }
   GSR_MARK();
-  hipLaunchKernelGGL(k_sort_tiles, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+  if (fused_bin) hipLaunchKernelGGL(k_sort_tiles<true>, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+  else hipLaunchKernelGGL(k_sort_tiles<false>, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
   GSR_MARK();
-  // join: the colour kernel (~22 us alone at 300k x 25 coefficients) has had preprocess + prefix + emit + sort to finish
+  // join: the colour kernel (~22 us alone at 300k x 25 coefficients) has had the whole binning chain to finish
   if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));
   if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
   else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);

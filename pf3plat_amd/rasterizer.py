@@ -97,7 +97,7 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.load()
-        self.capacity_hint = {}  # (V, N, H, W) -> pairs needed last time
+        self.capacity_hint = {}  # (V, N, H, W) -> pair_capacity that suits what was seen last time (headroom included)
         self.sync_policy = "lazy"  # or "sync": see forward()
         self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
         self.pending = []  # (pinned status copy, event, shape key) of lazy forwards not yet verified
@@ -130,11 +130,21 @@ class HipBackend:
                 raise RuntimeError(
                     "pf3plat_amd rasterizer: tensors must be on a ROCm device (there is no CPU fallback path)")
 
+    def capacity_for(self, cfg: RasterConfig, status: dict, headroom: float = 1.25) -> int:
+        """pair_capacity that lets a call of this shape succeed, from the status block of an earlier call (gsr_capacity_for:
+        every (view, tile) owns capacity / (views x tiles) entries of the index list, so the longest list decides) + headroom."""
+        dims = self._dims(cfg, 0)
+        need = self.lib.gsr_capacity_for(ctypes.byref(dims), int(status["num_pairs"] * headroom) + 4096,
+                                         int(status["max_list"] * headroom) + 16)
+        if need < 0:
+            raise RuntimeError(f"gsr_capacity_for failed with code {need}")
+        return int(need)
+
     def _default_capacity(self, cfg: RasterConfig) -> int:
         key = (cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width)
         hint = self.capacity_hint.get(key)
         if hint is not None:
-            return int(hint * 1.25) + 4096
+            return int(hint)
         return cfg.num_views * max(8 * cfg.num_gaussians, 1 << 18)
 
     # ---- plans: outputs + workspaces allocated once, launch chains enqueued many times (bench / HIP-graph capture)
@@ -151,6 +161,9 @@ class HipBackend:
             geom=torch.empty(gb, dtype=u8, device=device), bin=torch.empty(bb, dtype=u8, device=device),
             img=torch.empty(ib, dtype=u8, device=device),
         )
+        # the status block holds the bump counter of the key pages: the library leaves it at zero after every forward, the
+        # owner of a fresh workspace zeroes it once (a dirty counter is safe but can cause a spurious, reported, overflow)
+        plan["bin"][:64].zero_()
         if backward:
             if colors_shape is None:
                 if cfg.sh_coeffs > 0:
@@ -238,28 +251,28 @@ class HipBackend:
                 host.copy_(plan["bin"][:16], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
-                self.pending.append((host, ev, key))
+                self.pending.append((host, ev, key, cfg))
                 return out
             self.last_status = st = self.read_status(plan)
-            self.capacity_hint[key] = st["num_pairs"]
+            self.capacity_hint[key] = self.capacity_for(cfg, st)
             if not st["overflow"]:
                 return out
-            cap = int(st["num_pairs"] * 1.05) + 4096
+            cap = self.capacity_for(cfg, st, headroom=1.05)
         raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
 
     def check_pending(self, wait: bool = False):
         """Verify the status blocks of earlier lazy/deferred forwards (those whose async copy has landed; all if `wait`)."""
         keep = []
-        for host, ev, key in self.pending:
+        for host, ev, key, cfg in self.pending:
             if wait:
                 ev.synchronize()
             elif not ev.query():
-                keep.append((host, ev, key))
+                keep.append((host, ev, key, cfg))
                 continue
             num_pairs = int(host[:8].view(torch.int64).item())
             overflow = int(host[8:12].view(torch.int32).item())
             self.last_status = {"num_pairs": num_pairs, "overflow": overflow, "max_list": int(host[12:16].view(torch.int32).item())}
-            self.capacity_hint[key] = max(num_pairs, 1)
+            self.capacity_hint[key] = self.capacity_for(cfg, self.last_status)
             if overflow:
                 self.pending = [p for p in self.pending if p[0] is not host]
                 raise RuntimeError(

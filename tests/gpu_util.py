@@ -40,8 +40,8 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
     num_pairs = int(st[:8].view(torch.int64).item())
     ranges = b[lay["ranges"]: lay["ranges"] + V * T * 8].view(torch.int32).reshape(V, T, 2).numpy()
     cap = int(dims.pair_capacity)
-    plist = b[lay["point_list"]: lay["point_list"] + cap * 4].view(torch.int32).numpy()[:num_pairs]
-    keys = b[lay["keys"]: lay["keys"] + cap * 8].view(torch.int64).numpy()[:num_pairs]
+    plist = b[lay["point_list"]: lay["point_list"] + cap * 4].view(torch.int32).numpy()  # a tile's list: ranges[v, t]
+    keys = b[lay["keys"]: lay["keys"] + cap * 8].view(torch.int64).numpy()
     im = img.cpu()
     final_T = im[lay["final_T"]: lay["final_T"] + V * H * W * 4].view(torch.float32).reshape(V, H, W).numpy()
     n_contrib = im[lay["n_contrib"]: lay["n_contrib"] + V * H * W * 4].view(torch.int32).reshape(V, H, W).numpy()
