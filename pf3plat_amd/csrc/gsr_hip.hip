@@ -52,6 +52,8 @@ struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one
 // (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); computed once in preprocess, consumed by count and emit.
 // Footprints wider than 8 tiles set `big` and are re-derived from q0/q1 by the binning kernels.
 
+typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(8)));  // two keys, 8-byte aligned
+
 struct Grid {
   int W, H, gx16, gy16, sgx, sgy, sw, sh, T;  // sw/sh: 8x8 tiles that contain at least one pixel
 };
@@ -110,7 +112,7 @@ static Layout make_layout(const GsrDims& d) {
   const size_t blocks = V * (rows > 0 ? rows : 1);
   L.key_slots = blocks * (size_t)kStagePairs;
   L.key_pages = (2 * cap + kPage - 1) / kPage + 64;
-  L.o_keys = o; o = align_up(o + (L.key_slots + L.key_pages * kPage) * 8, 256);
+  L.o_keys = o; o = align_up(o + (L.key_slots + L.key_pages * kPage) * 8 + 64, 256);  // + padding: 16-byte reads may overrun a run by one key
   L.o_list = o; o = align_up(o + cap * 4, 256);
   L.o_blk = o; o = align_up(o + blocks * 4, 256);
   L.o_blktot = o; o = align_up(o + blocks * 4, 256);
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
 // Measurement aid: eight 64-bit stamps per slot at the very end of the key buffer (pages handed out last, so unused in
 // any run that does not overflow).
 __device__ __forceinline__ unsigned long long* dbg_stamps(const Params& p, size_t slot) {
-  return p.keys + (size_t)p.pool_off + (size_t)p.key_pages * kPage - (slot + 1) * 8;
+  return p.keys + (size_t)p.pool_off + (size_t)p.key_pages * kPage - (slot + 1) * 8;  // (the padding lies behind)
 }
 
 __device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
@@ -796,6 +798,7 @@ constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's
 
 __global__ __launch_bounds__(64) void k_color(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x, set = blockIdx.y;
   const int N = p.d.num_gaussians, Vs = p.d.views_per_set;
   const int g0 = blockIdx.x * 64;
@@ -838,6 +841,8 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
   const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
   const int ks = planar ? 1 : 3, cs = planar ? M : 1;  // coefficient k of channel c sits at k * ks + c * cs
   const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0 && set == 0 && lane == 0;
+  if (dbg) dbg_stamps(p, 16384 + blockIdx.x)[0] = t_start;
   for (int vv = 0; vv < Vs; ++vv) {
     const int v = set * Vs + vv;
     const GsrView& cam = p.views[v];
@@ -853,6 +858,7 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
     const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
     p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
   }
+  if (dbg) dbg_stamps(p, 16384 + blockIdx.x)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1212,7 +1218,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   const int tid = threadIdx.x;
   const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
   unsigned long long* stamp = dbg_stamps(p, 8192 + blockIdx.x);
+  unsigned long long* stamp2 = dbg_stamps(p, 8192 + gridDim.x + blockIdx.x);
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GSR_STAMP2(k) do { if (dbg && tid == 0) stamp2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
   int n;
   unsigned long long* keys;  // global memory: contiguous keys (kGather: only for lists longer than the LDS sort)
@@ -1238,15 +1246,20 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
         missing |= (c != 0u && bb[r] == 0xffffffffu) ? 1u : 0u;
       }
     }
+    GSR_STAMP2(0);
     uint32_t total;
     const uint32_t start0 = block_exclusive_scan(cnt_sum, red, tid, total);
     const bool any_missing = __syncthreads_or((int)missing) != 0;
     n = (int)total;
-    if (tid == 0) {
-      // the tile's range of the index list: its own fixed slot of `stride` entries (no counter shared with other tiles), or -
-      // a list longer than that - a run of the tail region behind the slots, taken from a bump counter
+    // The tile's range of the index list: its own fixed slot of `stride` entries (no counter shared with other tiles), or -
+    // a list longer than that - a run of the tail region behind the slots, taken from a bump counter.  The usual case
+    // (every run stored, list fits its slot and the LDS sort) needs no decision by one thread and no barrier.
+    const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kSortLds;
+    if (tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
+    if (plain) {
+      if (tid == 0) p.ranges[blockIdx.x] = make_uint2(blockIdx.x * p.stride, blockIdx.x * p.stride + (uint32_t)n);
+    } else if (tid == 0) {
       uint32_t rbase = blockIdx.x * p.stride, ok = any_missing ? 0u : 1u, scratch = 0;
-      if ((uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
       if (ok && (uint32_t)n > p.stride) {
         const uint32_t at = atomicAdd(p.tail_counter, (uint32_t)n);
         if (at <= p.tail_cap && (uint32_t)n <= p.tail_cap - at) rbase = p.tail_off + at;
@@ -1271,29 +1284,39 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       __syncthreads();
       if (tid == 0) p.status->num_pairs = sPart[0] + sPart[1] + sPart[2] + sPart[3];
     }
-    __syncthreads();
-    if (!sInfo[1] || n == 0) return;
-    out = p.point_list + sInfo[0];
-    keys = p.keys + sInfo[2];
+    uint32_t rbase = blockIdx.x * p.stride, scratch = 0;
+    if (!plain) {  // workgroup-uniform
+      __syncthreads();
+      if (!sInfo[1]) return;
+      rbase = sInfo[0]; scratch = sInfo[2];
+    }
+    if (n == 0) return;
+    GSR_STAMP2(1);
+    out = p.point_list + rbase;
+    keys = p.keys + scratch;
     unsigned long long* dst = n > kSortLds ? keys : sk;
-    // copy the runs, in row order; four keys in flight per thread (runs are ~5 keys long)
+    // copy the runs, in row order: six keys per step as three 16-byte loads issued together (runs are ~5 keys long; a lane's
+    // request is what the memory pipeline counts, so 16 bytes per lane halve the cost of this scattered read).  The loads may
+    // run one key past the run: still inside the key buffer (it is padded).
     auto copy_run = [&](const unsigned long long* src, uint32_t cnt, uint32_t start) {
-      uint32_t j = 0;
-      for (; j + 4 <= cnt; j += 4) {
-        const unsigned long long k0 = src[j], k1 = src[j + 1], k2 = src[j + 2], k3 = src[j + 3];
-        dst[start + j] = k0; dst[start + j + 1] = k1; dst[start + j + 2] = k2; dst[start + j + 3] = k3;
+      for (uint32_t j = 0; j < cnt; j += 6) {
+        const ull2 a = *reinterpret_cast<const ull2*>(src + j);
+        ull2 b = {0ull, 0ull}, c = {0ull, 0ull};
+        if (j + 2 < cnt) b = *reinterpret_cast<const ull2*>(src + j + 2);
+        if (j + 4 < cnt) c = *reinterpret_cast<const ull2*>(src + j + 4);
+        unsigned long long* d = dst + start + j;
+        d[0] = a.x;
+        if (j + 1 < cnt) d[1] = a.y;
+        if (j + 2 < cnt) d[2] = b.x;
+        if (j + 3 < cnt) d[3] = b.y;
+        if (j + 4 < cnt) d[4] = c.x;
+        if (j + 5 < cnt) d[5] = c.y;
       }
-      unsigned long long k0 = 0, k1 = 0, k2 = 0;
-      if (j < cnt) k0 = src[j];
-      if (j + 1 < cnt) k1 = src[j + 1];
-      if (j + 2 < cnt) k2 = src[j + 2];
-      if (j < cnt) dst[start + j] = k0;
-      if (j + 1 < cnt) dst[start + j + 1] = k1;
-      if (j + 2 < cnt) dst[start + j + 2] = k2;
     };
     if (one_stride) {
       if (e0.y) copy_run(p.keys + bb0 + e0.x, e0.y, start0);
       __syncthreads();
+      GSR_STAMP2(2);
     } else {
       uint32_t carry = 0;
       for (int r0 = 0; r0 < R; r0 += kSortThreads) {
@@ -1397,6 +1420,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
   GSR_STAMP(6);
 #undef GSR_STAMP
+#undef GSR_STAMP2
 }
 
 // ------------------------------------------------------------------------------------------------

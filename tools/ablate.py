@@ -25,6 +25,8 @@ def main():
     q0 = lambda x: [round(v, 2) for v in torch.quantile(x, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)).tolist()]
     # per-tile cycle stamps of the forward blend
     plan = be.make_plan(cfg, dev, capacity=8 * n)
+    be.run_forward(plan, vb, means, cov6, opac, shs)
+    plan = be.make_plan(cfg, dev, capacity=be.capacity_for(cfg, be.read_status(plan), headroom=1.1))
     plan["dims"].flags = 0x2000
     for _ in range(3):
         be.run_forward(plan, vb, means, cov6, opac, shs)
@@ -51,28 +53,46 @@ def main():
     q = lambda x: [round(v, 0) for v in torch.quantile(x, torch.tensor([0.0, 0.1, 0.5, 0.9, 1.0], dtype=torch.float64)).tolist()]
     print("blend_fwd per-tile (cycle counter ticks): start skew", q(t0), "| prologue", q(pro), "| total", q(dur),
           "| ticks per walked entry", q((dur - pro) / walked.clamp(min=1)), "| end-start span", (st[:, 2].max() - st[:, 0].min()).item(), flush=True)
-    sst = plan["bin"][lay["counts"]: lay["counts"] + 1024 * 64].view(torch.int64).reshape(1024, 8).cpu().double() * 0.01
-    names = ["ranges+keys+minmax", "hist", "scan", "scatter", "finish", "store"]
-    base = sst[:, 0].min()
-    print("sort_tiles phases (us, median over tiles; start skew median %.2f): " % torch.median(sst[:, 0] - base).item() +
-          ", ".join(f"{names[k]} {torch.median(sst[:, k + 1] - sst[:, k]).item():.2f}" for k in range(6)) +
-          f" | total median {torch.median(sst[:, 6] - sst[:, 0]).item():.2f} max {(sst[:, 6] - sst[:, 0]).max().item():.2f} | kernel span {(sst[:, 6].max() - base).item():.2f}", flush=True)
+    # phase stamps live at the very end of the key buffer (dbg_stamps in gsr_hip.hip): slot s = 64 bytes ending (s + 1) * 64
+    # bytes before the index list; slots: binning workgroups from 0, sort tiles from 8192, sort gather from 8192 + tiles
     chunk = min(range(2048, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)  # choose_chunk(), V = 1
     rows = (n + chunk - 1) // chunk
-    kb = plan["bin"][lay["keys"]: lay["keys"] + (8 * n) * 8].view(torch.int64)
-    est = kb[(8 * n) - rows * 8:].reshape(rows, 8).flip(0).cpu().double() * 0.01
-    names = ["tile totals loaded", "scan", "cursors+ranges", "pair walk"]
-    base = est[:, 0].min()
-    print("emit phases (us, median over row blocks; start skew max %.2f): " % (est[:, 0] - base).max().item() +
-          ", ".join(f"{names[k]} {torch.median(est[:, k + 1] - est[:, k]).item():.2f}" for k in range(4)) +
-          f" | total median {torch.median(est[:, 4] - est[:, 0]).item():.2f} max {(est[:, 4] - est[:, 0]).max().item():.2f} | kernel span {(est[:, 4].max() - base).item():.2f}", flush=True)
-    pst = kb[8 * n - 8192 - rows * 8: 8 * n - 8192].reshape(rows, 8).flip(0).cpu().double() * 0.01
-    pst = pst[:-1]
-    names = ["zero hist", "gaussian 1 (wave 0)", "gaussian 2 (wave 0)", "all waves done", "store"]
-    base = pst[:, 0].min()
-    print("preprocess_count phases (us, median over row blocks; start skew max %.2f): " % (pst[:, 0] - base).max().item() +
-          ", ".join(f"{names[k]} {torch.median(pst[:, k + 1] - pst[:, k]).item():.2f}" for k in range(5)) +
-          f" | total median {torch.median(pst[:, 5] - pst[:, 0]).item():.2f} max {(pst[:, 5] - pst[:, 0]).max().item():.2f} | kernel span {(pst[:, 5].max() - base).item():.2f}", flush=True)
+    end = lay["point_list"] - 256  # the key buffer ends with 64 bytes of padding, rounded up to 256
+
+    def slots(first, count):
+        raw = plan["bin"][end - (first + count) * 64: end - first * 64].view(torch.int64).reshape(count, 8).flip(0).cpu().double() * 0.01
+        return raw
+
+    def line(title, st, names):
+        base = st[:, 0].min()
+        print(f"{title} (us, median; start skew max {(st[:, 0] - base).max().item():.2f}): " +
+              ", ".join(f"{nm} {torch.median(st[:, k + 1] - st[:, k]).item():.2f}" for k, nm in enumerate(names)) +
+              f" | total median {torch.median(st[:, len(names)] - st[:, 0]).item():.2f} max {(st[:, len(names)] - st[:, 0]).max().item():.2f}"
+              f" | kernel span {(st[:, len(names)].max() - base).item():.2f}", flush=True)
+
+    cst = slots(16384, (n + 63) // 64 - 1)
+    bst = slots(0, rows)
+    t0 = bst[:, 0].min()
+    rel = lambda a: round((a - t0).item(), 2)
+    blend_s = (raw[:, 3] >> 32).double() * 0.01
+    blend_e = (raw[:, 3] & 0xffffffff).double() * 0.01
+    wrap = lambda x: x  # the blend stamps keep only the low 32 bits of the 100 MHz counter
+    t0_32 = float(int(t0 * 100) & 0xffffffff) * 0.01
+    print("eager timeline (us from the first binning workgroup): preprocess_bin", rel(bst[:, 0].min()), "->", rel(bst[:, 4].max()),
+          "| color", rel(cst[:, 0].min()), "->", rel(cst[:, 1].max()), "(median workgroup start", rel(torch.median(cst[:, 0])), ")",
+          "| sort", rel(slots(8192, 1024)[:, 0].min()), "->", rel(slots(8192, 1024)[:, 6].max()),
+          "| blend", round((blend_e - t0_32).min().item(), 2), "->", round((blend_e - t0_32).max().item(), 2), flush=True)
+    line("preprocess_bin phases", slots(0, rows), ["preprocess + count", "scan + matrix row", "pair walk", "copy-out"])
+    sst = slots(8192, 1024)
+    gst = slots(8192 + 1024, 1024)
+    g = torch.stack([sst[:, 0], gst[:, 0], gst[:, 1], gst[:, 2], sst[:, 1]], 1)
+    line("sort gather phases", g, ["column + bases loaded", "scan, range, sync", "runs copied to LDS", "keys to registers + minmax"])
+    line("sort_tiles phases", sst, ["gather + keys + minmax", "hist", "scan", "scatter", "finish", "store"])
+    st0 = sst[:, 0] - sst[:, 0].min()
+    print("sort_tiles mean start (us) per 64 consecutive blockIdx:", [round(st0[k: k + 64].mean().item(), 1) for k in range(0, 1024, 64)], flush=True)
+    print("sort_tiles mean duration (us) per 64 consecutive blockIdx:", [round((sst[k: k + 64, 6] - sst[k: k + 64, 0]).mean().item(), 1) for k in range(0, 1024, 64)], flush=True)
+    print("sort_tiles start skew quantiles (us)", q0(sst[:, 0] - sst[:, 0].min()), "| end", q0(sst[:, 6] - sst[:, 0].min()),
+          "| duration", q0(sst[:, 6] - sst[:, 0]), flush=True)
     for name, fl in FLAGS.items():
         plan = be.make_plan(cfg, dev, capacity=8 * n)
         plan["dims"].flags = fl

@@ -13,16 +13,16 @@ def main():
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     rows = list(c.execute("select name, start, end, grid_x, grid_y from kernels order by start"))
     rows = [r for r in rows if r[0].startswith("gsr::") or "gsr::" in r[0]]
-    # passes begin at k_preprocess_count with grid_y == 1 (single-view bench config)
+    # passes begin at the preprocess kernel with grid_y == 1 (single-view bench config)
     passes, cur = [], None
     for name, st, en, gx, gy in rows:
         short = name.split("(")[0].replace("gsr::", "").replace("void ", "")
-        if short.startswith("k_preprocess_count") and gy == 1:
+        if (short.startswith("k_preprocess_bin") or short.startswith("k_preprocess_count")) and gy == 1:
             cur = []
             passes.append(cur)
         if cur is not None:
             cur.append((short, st, en))
-    passes = [p for p in passes if len(p) == 6 and p[-1][0].startswith("k_blend_fwd")]
+    passes = [p for p in passes if len(p) in (4, 6) and p[-1][0].startswith("k_blend_fwd")]
     passes = passes[len(passes) // 2: len(passes) // 2 + npass]
     acc = defaultdict(lambda: [0.0, 0.0, 0])
     period = []
