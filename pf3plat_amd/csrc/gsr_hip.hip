@@ -37,6 +37,9 @@ constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a bi
 constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
 constexpr int kSortThreads = 256; // threads cooperating on one tile's sort
 constexpr int kPage = 1024;        // pairs per page of the key buffer: a binning workgroup's private region is whole pages
+constexpr int kSlotStride = 8192 + 136;  // keys between the fixed slots of consecutive binning workgroups: NOT a multiple of the memory
+                                        // channel interleave - the sort reads the same tile from every slot at once, and with a
+                                        // power-of-two stride all those reads landed on one channel (gather 16 us instead of 3)
 constexpr int kStagePairs = 8192;  // pairs a binning workgroup collects in LDS (the 64 KB record-transpose area) before one linear copy-out
 constexpr float kNear = 0.2f;     // [EXT] auxiliary.h in_frustum: p_view.z <= 0.2f culls
 
@@ -104,13 +107,13 @@ static Layout make_layout(const GsrDims& d) {
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
   const size_t rows = (N + choose_chunk(d) - 1) / choose_chunk(d);
-  L.o_counts = o; o = align_up(o + VT * (rows > 0 ? rows : 1) * 8, 256);  // uint2 (offset in the row's region, count)
+  L.o_counts = o; o = align_up(o + V * (rows > 0 ? rows : 1) * (size_t)(g.T + 8) * 8, 256);  // uint2 (offset, count); rows padded by 8
   L.o_total = o; o = align_up(o + VT * 4, 256);
   L.o_ranges = o; o = align_up(o + VT * 8, 256);
   // keys: a fixed slot per binning workgroup (all it needs unless it lists more than kStagePairs pairs), then a page pool
   // for the longer regions and for the contiguous scratch of per-tile lists too long for the LDS sort (every pair twice)
   const size_t blocks = V * (rows > 0 ? rows : 1);
-  L.key_slots = blocks * (size_t)kStagePairs;
+  L.key_slots = blocks * (size_t)kSlotStride;
   L.key_pages = (2 * cap + kPage - 1) / kPage + 64;
   L.o_keys = o; o = align_up(o + (L.key_slots + L.key_pages * kPage) * 8 + 64, 256);  // + padding: 16-byte reads may overrun a run by one key
   L.o_list = o; o = align_up(o + cap * 4, 256);
@@ -338,12 +341,14 @@ __device__ __forceinline__ void ref_rect16(float x, float y, float r, const Grid
 __device__ __forceinline__ Foot make_foot(float x, float y, float A, float B, float C, float o, float r, const Grid& g) {
   Foot f;
   f.cx = x; f.cy = y; f.A = A; f.B = B; f.C = C;
-  f.nBiC = -B / C; f.nBiA = -B / A;
+  // Hardware reciprocal / square root / log2 (about 1 ulp) are enough here: every test built on the footprint carries a margin
+  // orders of magnitude above that, and the count and emit passes see bit-identical values either way.
+  f.nBiC = -B * __builtin_amdgcn_rcpf(C); f.nBiA = -B * __builtin_amdgcn_rcpf(A);
   int rx0, ry0, rx1, ry1;
   ref_rect16(x, y, r, g, rx0, ry0, rx1, ry1);
   f.sx0 = 2 * rx0; f.sy0 = 2 * ry0;
   f.sx1 = min(2 * rx1, g.sw); f.sy1 = min(2 * ry1, g.sh);
-  const float tau = 2.f * logf(255.f * o);
+  const float tau = (2.f * 0.6931471805599453f) * __builtin_amdgcn_logf(255.f * o);  // 2 ln(255 o)
   f.tau = tau + 1e-4f * fabsf(tau) + 0.02f;  // margin >> fp32 error of the blend's own power evaluation
   const float detc = A * C - B * B;
   f.convex = (A > 0.f) && (C > 0.f) && (detc > 0.f) && (detc < 3.0e38f);
@@ -352,7 +357,8 @@ __device__ __forceinline__ Foot make_foot(float x, float y, float A, float B, fl
     f.sx1 = f.sx0; f.sy1 = f.sy0;
   } else if (f.convex) {
     f.detc = detc;
-    f.hx = sqrtf(f.tau * C / detc); f.hy = sqrtf(f.tau * A / detc);
+    const float rdet = __builtin_amdgcn_rcpf(detc);
+    f.hx = __builtin_amdgcn_sqrtf(f.tau * C * rdet); f.hy = __builtin_amdgcn_sqrtf(f.tau * A * rdet);
     const float hx = f.hx + 0.5f, hy = f.hy + 0.5f;
     f.sx0 = max(f.sx0, f2i_clamped(floorf((x - hx) * 0.125f)));
     f.sx1 = min(f.sx1, f2i_clamped(floorf((x + hx) * 0.125f)) + 1);
@@ -394,9 +400,9 @@ __device__ __forceinline__ uint32_t row_hit_bits(const Foot& f, int sy, const Gr
   if (ya > yb) return 0u;
   const float yrt = f.nBiC * f.hx;  // y of the rightmost point; the leftmost is at -yrt
   const float yr = fminf(fmaxf(yrt, ya), yb), yl = fminf(fmaxf(-yrt, ya), yb);
-  const float inva = 1.f / f.A, at = f.A * f.tau;
-  const float xr = (-f.B * yr + sqrtf(fmaxf(0.f, at - f.detc * yr * yr))) * inva + 1e-3f;
-  const float xl = (-f.B * yl - sqrtf(fmaxf(0.f, at - f.detc * yl * yl))) * inva - 1e-3f;
+  const float inva = __builtin_amdgcn_rcpf(f.A), at = f.A * f.tau;
+  const float xr = (-f.B * yr + __builtin_amdgcn_sqrtf(fmaxf(0.f, at - f.detc * yr * yr))) * inva + 1e-3f;
+  const float xl = (-f.B * yl - __builtin_amdgcn_sqrtf(fmaxf(0.f, at - f.detc * yl * yl))) * inva - 1e-3f;
   const int lo = max(f.sx0, f2i_clamped(ceilf((xl + f.cx - 7.f) * 0.125f)));
   const int hi = min(f.sx1 - 1, f2i_clamped(floorf((xr + f.cx) * 0.125f)));
   if (hi < lo) return 0u;
@@ -629,7 +635,7 @@ __device__ __forceinline__ unsigned long long* dbg_stamps(const Params& p, size_
 __device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
   Foot f;
   f.cx = b[0]; f.cy = b[1]; f.A = b[2]; f.B = b[3]; f.C = b[4]; f.tau = b[5];
-  f.nBiC = -f.B / f.C; f.nBiA = -f.B / f.A;
+  f.nBiC = -f.B * __builtin_amdgcn_rcpf(f.C); f.nBiA = -f.B * __builtin_amdgcn_rcpf(f.A);
   const int xs = __float_as_int(b[6]), ys = __float_as_int(b[7]);
   f.sx0 = xs & 0xffff; f.sx1 = xs >> 16; f.sy0 = ys & 0xffff; f.sy1 = ys >> 16;
   const float detc = f.A * f.C - f.B * f.B;
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   // ---- 3. this workgroup's region of the key buffer: its own fixed slot, or (more than kStagePairs pairs) pool pages
   if (tid == 0) {
     const size_t blk = (size_t)v * p.rows + row;
-    uint32_t base = (uint32_t)(blk * kStagePairs);
+    uint32_t base = (uint32_t)(blk * kSlotStride);
     if (total > (uint32_t)kStagePairs) {
       const uint32_t npages = (total + kPage - 1) / kPage;
       const uint32_t first = atomicAdd(p.page_counter, npages);
@@ -745,7 +751,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     p.blk_base[blk] = base;
     p.blk_total[blk] = total;
   }
-  uint2* mrow = p.pair_mat + ((size_t)v * p.rows + row) * T;
+  uint2* mrow = p.pair_mat + ((size_t)v * p.rows + row) * (T + 8);  // + 8: a column must not sit on one memory channel
   uint32_t run = basew + incl - sum;
 #pragma unroll
   for (int q = 0; q < kTileWindow / kBinThreads; ++q)
@@ -1227,8 +1233,12 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   uint32_t* out;
   if (kGather) {
     const int T = p.g.T, R = p.rows;
-    const int v = blockIdx.x / T, t = blockIdx.x - v * T;
-    const uint2* col = p.pair_mat + (size_t)v * R * T + t;
+    // XCD-aware order: neighbouring tiles' runs share cache lines in every region, so give each XCD (= each L2) a contiguous
+    // range of tiles
+    const int tg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int v = tg / T, t = tg - v * T;
+    const uint2* col = p.pair_mat + (size_t)v * R * (T + 8) + t;
+    const size_t cstride = (size_t)T + 8;
     const uint32_t* bb = p.blk_base + (size_t)v * R;
     // the length of the list, and whether every run was stored.  With up to kSortThreads rows (the usual case) a thread keeps
     // its row's (offset, count) and region base in registers; with more the column is read again for the copy.
@@ -1236,12 +1246,12 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     uint2 e0 = make_uint2(0u, 0u);
     uint32_t bb0 = 0, cnt_sum = 0, missing = 0;
     if (one_stride) {
-      if (tid < R) { e0 = col[(size_t)tid * T]; bb0 = bb[tid]; }
+      if (tid < R) { e0 = col[(size_t)tid * cstride]; bb0 = bb[tid]; }
       cnt_sum = e0.y;
       missing = (e0.y != 0u && bb0 == 0xffffffffu) ? 1u : 0u;
     } else {
       for (int r = tid; r < R; r += kSortThreads) {
-        const uint32_t c = col[(size_t)r * T].y;
+        const uint32_t c = col[(size_t)r * cstride].y;
         cnt_sum += c;
         missing |= (c != 0u && bb[r] == 0xffffffffu) ? 1u : 0u;
       }
@@ -1257,9 +1267,9 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kSortLds;
     if (tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
     if (plain) {
-      if (tid == 0) p.ranges[blockIdx.x] = make_uint2(blockIdx.x * p.stride, blockIdx.x * p.stride + (uint32_t)n);
+      if (tid == 0) p.ranges[tg] = make_uint2((uint32_t)tg * p.stride, (uint32_t)tg * p.stride + (uint32_t)n);
     } else if (tid == 0) {
-      uint32_t rbase = blockIdx.x * p.stride, ok = any_missing ? 0u : 1u, scratch = 0;
+      uint32_t rbase = (uint32_t)tg * p.stride, ok = any_missing ? 0u : 1u, scratch = 0;
       if (ok && (uint32_t)n > p.stride) {
         const uint32_t at = atomicAdd(p.tail_counter, (uint32_t)n);
         if (at <= p.tail_cap && (uint32_t)n <= p.tail_cap - at) rbase = p.tail_off + at;
@@ -1272,7 +1282,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
         else ok = 0;
       }
       if (!ok) p.status->overflow = 1u;
-      p.ranges[blockIdx.x] = ok ? make_uint2(rbase, rbase + (uint32_t)n) : make_uint2(0u, 0u);
+      p.ranges[tg] = ok ? make_uint2(rbase, rbase + (uint32_t)n) : make_uint2(0u, 0u);
       sInfo[0] = rbase; sInfo[1] = ok; sInfo[2] = scratch;
     }
     if (blockIdx.x == 0) {  // total pair count = sum of the binning workgroups' totals
@@ -1284,7 +1294,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       __syncthreads();
       if (tid == 0) p.status->num_pairs = sPart[0] + sPart[1] + sPart[2] + sPart[3];
     }
-    uint32_t rbase = blockIdx.x * p.stride, scratch = 0;
+    uint32_t rbase = (uint32_t)tg * p.stride, scratch = 0;
     if (!plain) {  // workgroup-uniform
       __syncthreads();
       if (!sInfo[1]) return;
@@ -1321,7 +1331,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       uint32_t carry = 0;
       for (int r0 = 0; r0 < R; r0 += kSortThreads) {
         const int r = r0 + tid;
-        const uint2 e = r < R ? col[(size_t)r * T] : make_uint2(0u, 0u);
+        const uint2 e = r < R ? col[(size_t)r * cstride] : make_uint2(0u, 0u);
         uint32_t tot;
         const uint32_t start = carry + block_exclusive_scan(e.y, red, tid, tot);
         carry += tot;
@@ -2391,6 +2401,11 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   // stream so each stage is timed alone.
   SideStream* ss = ev ? nullptr : side_stream();
   GSR_MARK();
+  // profile mode: the colour kernel goes FIRST (it streams 90 MB through the caches; between binning and sort it would
+  // evict the keys the sort gathers, which the concurrent eager order does not do).  gsr_forward_profile swaps the two
+  // durations back into stage order.
+  if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
+  if (ev) GSR_MARK();
   if (do_color && ss) {
     GSR_CHECK(hipEventRecord(ss->fork, st));
     GSR_CHECK(hipStreamWaitEvent(ss->stream, ss->fork, 0));
@@ -2414,8 +2429,6 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   } else {
     hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   }
-  GSR_MARK();
-  if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
   GSR_MARK();
   if (!fused_bin) {
     hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
@@ -2466,6 +2479,8 @@ int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* 
     if (hipStreamSynchronize(st) != hipSuccess) rc = GSR_ERR_LAUNCH;
     for (int i = 0; i < GSR_FWD_STAGES && rc == GSR_OK; ++i)
       if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = GSR_ERR_LAUNCH;
+    const float color_ms = stage_ms[0];  // launched first in profile mode (see forward_impl)
+    stage_ms[0] = stage_ms[1]; stage_ms[1] = color_ms;
   } else {
     for (int i = 0; i < GSR_FWD_STAGES; ++i) stage_ms[i] = 0.f;
   }

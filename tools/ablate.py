@@ -57,7 +57,8 @@ def main():
     # bytes before the index list; slots: binning workgroups from 0, sort tiles from 8192, sort gather from 8192 + tiles
     chunk = min(range(2048, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)  # choose_chunk(), V = 1
     rows = (n + chunk - 1) // chunk
-    end = lay["point_list"] - 256  # the key buffer ends with 64 bytes of padding, rounded up to 256
+    cap = int(plan["dims"].pair_capacity)
+    end = lay["keys"] + (rows * (8192 + 136) + ((2 * cap + 1023) // 1024 + 64) * 1024) * 8  # make_layout(): slots + page pool
 
     def slots(first, count):
         raw = plan["bin"][end - (first + count) * 64: end - first * 64].view(torch.int64).reshape(count, 8).flip(0).cpu().double() * 0.01
@@ -93,6 +94,18 @@ def main():
     print("sort_tiles mean duration (us) per 64 consecutive blockIdx:", [round((sst[k: k + 64, 6] - sst[k: k + 64, 0]).mean().item(), 1) for k in range(0, 1024, 64)], flush=True)
     print("sort_tiles start skew quantiles (us)", q0(sst[:, 0] - sst[:, 0].min()), "| end", q0(sst[:, 6] - sst[:, 0].min()),
           "| duration", q0(sst[:, 6] - sst[:, 0]), flush=True)
+    # the same stamps with the chain serialised (profile mode: one stream, events between the stages)
+    for _ in range(3):
+        be.run_forward(plan, vb, means, cov6, opac, shs, profile=True)
+    torch.cuda.synchronize()
+    sst = slots(8192, 1024)
+    gst = slots(8192 + 1024, 1024)
+    g = torch.stack([sst[:, 0], gst[:, 0], gst[:, 1], gst[:, 2], sst[:, 1]], 1)
+    line("SERIAL sort gather phases", g, ["column + bases loaded", "scan, range, sync", "runs copied to LDS", "keys to registers + minmax"])
+    line("SERIAL sort_tiles phases", sst, ["gather + keys + minmax", "hist", "scan", "scatter", "finish", "store"])
+    st0 = sst[:, 0] - sst[:, 0].min()
+    print("SERIAL sort_tiles mean start (us) per 64 consecutive blockIdx:", [round(st0[k: k + 64].mean().item(), 1) for k in range(0, 1024, 64)], flush=True)
+    print("SERIAL sort_tiles mean duration (us) per 64 consecutive blockIdx:", [round((sst[k: k + 64, 6] - sst[k: k + 64, 0]).mean().item(), 1) for k in range(0, 1024, 64)], flush=True)
     for name, fl in FLAGS.items():
         plan = be.make_plan(cfg, dev, capacity=8 * n)
         plan["dims"].flags = fl
