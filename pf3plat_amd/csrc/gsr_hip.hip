@@ -1214,10 +1214,15 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 //   fixed slot of the index list (`stride` = pair_capacity / (2 x views x tiles) entries; a longer list takes a run of the
 //   shared second half from a bump counter: correct for any distribution as long as pair_capacity >= 2 x pairs, and free of
 //   shared counters when pair_capacity >= 2 x views x tiles x longest list).
-template <bool kGather>
+template <bool kGather, int kLds>
 __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
-  __shared__ unsigned long long sk[kSortLds];
-  __shared__ uint32_t hist[kBuckets];  // counts, then (same storage) scatter cursors
+  // kLds keys sort in LDS, over kLds / 4 depth buckets.  The 2048-key variant fits the LDS one k_color workgroup frees
+  // (18.2 KB < 19.2 KB): in the eager chain the sort starts while the colour kernel is still draining, and a 36 KB
+  // workgroup had to wait for two neighbouring colour workgroups to retire.
+  constexpr int kBk = kLds / 4, kBkBits = kLds == 4096 ? 10 : 9, kBpt = kBk / kSortThreads;
+  static_assert(kLds == 4096 || kLds == 2048, "bucket geometry");
+  __shared__ unsigned long long sk[kLds];
+  __shared__ uint32_t hist[kBk];  // counts, then (same storage) scatter cursors
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
   uint32_t* cur = hist;
@@ -1264,7 +1269,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     // The tile's range of the index list: its own fixed slot of `stride` entries (no counter shared with other tiles), or -
     // a list longer than that - a run of the tail region behind the slots, taken from a bump counter.  The usual case
     // (every run stored, list fits its slot and the LDS sort) needs no decision by one thread and no barrier.
-    const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kSortLds;
+    const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kLds;
     if (tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
     if (plain) {
       if (tid == 0) p.ranges[tg] = make_uint2((uint32_t)tg * p.stride, (uint32_t)tg * p.stride + (uint32_t)n);
@@ -1275,7 +1280,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
         if (at <= p.tail_cap && (uint32_t)n <= p.tail_cap - at) rbase = p.tail_off + at;
         else ok = 0;
       }
-      if (ok && n > kSortLds) {  // contiguous scratch for the in-place global sort, from the page pool
+      if (ok && n > kLds) {  // contiguous scratch for the in-place global sort, from the page pool
         const uint32_t np = ((uint32_t)n + kPage - 1) / kPage;
         const uint32_t first = atomicAdd(p.page_counter, np);
         if (first <= p.key_pages && np <= p.key_pages - first) scratch = p.pool_off + first * (uint32_t)kPage;
@@ -1304,7 +1309,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     GSR_STAMP2(1);
     out = p.point_list + rbase;
     keys = p.keys + scratch;
-    unsigned long long* dst = n > kSortLds ? keys : sk;
+    unsigned long long* dst = n > kLds ? keys : sk;
     // copy the runs, in row order: six keys per step as three 16-byte loads issued together (runs are ~5 keys long; a lane's
     // request is what the memory pipeline counts, so 16 bytes per lane halve the cost of this scattered read).  The loads may
     // run one key past the run: still inside the key buffer (it is padded).
@@ -1356,13 +1361,13 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   }
   int lgnp = 1;
   while ((1 << lgnp) < n) ++lgnp;
-  if (n > kSortLds) {
+  if (n > kLds) {
     __syncthreads();
     bitonic_block(keys, n, lgnp, tid);
     for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)keys[k];
     return;
   }
-  constexpr int Q = kSortLds / kSortThreads;
+  constexpr int Q = kLds / kSortThreads;
   unsigned long long kreg[Q];
   uint32_t lo = 0xffffffffu, hi = 0u;
 #pragma unroll
@@ -1376,7 +1381,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     }
   }
   GSR_STAMP(1);
-  for (int k = tid; k < kBuckets; k += kSortThreads) hist[k] = 0;
+  for (int k = tid; k < kBk; k += kSortThreads) hist[k] = 0;
   // block min / max of the depth bits
   hi = wave_max_u32(hi);
   lo = ~wave_max_u32(~lo);
@@ -1385,19 +1390,21 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   lo = min(min(red[0], red[1]), min(red[2], red[3]));
   hi = max(max(red[4], red[5]), max(red[6], red[7]));
   const uint32_t range = hi - lo;
-  const int shift = range < (uint32_t)kBuckets ? 0 : (32 - __clz((int)range)) - 10;
+  const int shift = range < (uint32_t)kBk ? 0 : (32 - __clz((int)range)) - kBkBits;
 #pragma unroll
   for (int q = 0; q < Q; ++q)
     if (tid + q * kSortThreads < n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - lo) >> shift], 1u);
   __syncthreads();
   GSR_STAMP(2);
-  // exclusive scan of the bucket counts: thread t owns buckets 4t .. 4t+3
-  const uint32_t c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
-  const uint32_t span = c0 + c1 + c2 + c3;
+  // exclusive scan of the bucket counts: thread t owns kBpt consecutive buckets
+  uint32_t c[kBpt], span = 0, cmax = 0;
+#pragma unroll
+  for (int q = 0; q < kBpt; ++q) { c[q] = hist[kBpt * tid + q]; span += c[q]; cmax = max(cmax, c[q]); }
   uint32_t total;
-  const uint32_t start = block_exclusive_scan(span, red, tid, total);
-  cur[4 * tid] = start; cur[4 * tid + 1] = start + c0; cur[4 * tid + 2] = start + c0 + c1; cur[4 * tid + 3] = start + c0 + c1 + c2;
-  const bool big = __syncthreads_or(max(max(c0, c1), max(c2, c3)) > (uint32_t)kSpanMax) != 0;
+  uint32_t start = block_exclusive_scan(span, red, tid, total);
+#pragma unroll
+  for (int q = 0; q < kBpt; ++q) { cur[kBpt * tid + q] = start; start += c[q]; }
+  const bool big = __syncthreads_or(cmax > (uint32_t)kSpanMax) != 0;
   GSR_STAMP(3);
   // scatter into bucket order
 #pragma unroll
@@ -2442,8 +2449,13 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   }
   GSR_MARK();
-  if (fused_bin) hipLaunchKernelGGL(k_sort_tiles<true>, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
-  else hipLaunchKernelGGL(k_sort_tiles<false>, dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+  if (fused_bin) {
+    // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
+    if (p.stride <= 2048u) hipLaunchKernelGGL((k_sort_tiles<true, 2048>), dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_sort_tiles<true, 4096>), dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((k_sort_tiles<false, 4096>), dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+  }
   GSR_MARK();
   // join: the colour kernel (~22 us alone at 300k x 25 coefficients) has had the whole binning chain to finish
   if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));
