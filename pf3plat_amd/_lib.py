@@ -20,6 +20,7 @@ GSR_ABI_VERSION = 1
 SCREEN_GRAD_FLOATS = 12
 FLAG_SH_PLANAR = 0x4
 FLAG_COV_3X3 = 0x8
+FLAG_WINDOWED_BINNING = 0x4000  # test aid: the windowed binning path on an image small enough for the fused one
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
 

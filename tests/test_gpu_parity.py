@@ -260,8 +260,29 @@ def test_image_with_more_than_8192_tiles_uses_windowed_count_and_separate_scan()
     _all_checks(cfg, res, max_tiles=128)
 
 
-def test_three_views_of_512x512_scan_is_a_separate_kernel():
-    """V x T = 3 x 4096 > 8192 tile totals: counting stays fused in preprocess, the range scan runs as its own kernel."""
+def test_windowed_binning_path_on_a_small_image_matches_the_fused_one():
+    """GSR_FLAG_WINDOWED_BINNING: count matrix + prefix + scan-in-emit + contiguous sort on a 64 x 64 image, against the oracle
+    and against the fused path (identical per-tile lists, identical images)."""
+    from pf3plat_amd import _lib
+    sc = synthetic.make_scene(23, 6000, (64, 64))
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    gc = torch.rand((1, 3, 64, 64), generator=torch.Generator().manual_seed(0))
+    out = {}
+    for name, fl in (("fused", 0), ("windowed", _lib.FLAG_WINDOWED_BINNING)):
+        cfg = RasterConfig(1, 1, 1, 6000, 64, 64, 4, 25, 4, False, fl)
+        out[name] = (cfg, gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, None))
+        _all_checks(*out[name])
+    wa, wb = out["fused"][1]["hip"]["ws"], out["windowed"][1]["hip"]["ws"]
+    np.testing.assert_array_equal(out["fused"][1]["hip"]["color"], out["windowed"][1]["hip"]["color"])
+    assert wa["num_pairs"] == wb["num_pairs"] and wa["max_list"] == wb["max_list"]
+    for t in range(wa["T"]):
+        (a0, a1), (b0, b1) = wa["ranges"][0, t], wb["ranges"][0, t]
+        np.testing.assert_array_equal(wa["point_list"][a0:a1], wb["point_list"][b0:b1])
+
+
+def test_three_views_of_512x512():
+    """V x T = 3 x 4096 tiles: three views of a larger image through the fused binning (multi-view pair matrix, slots)."""
     cfg, res = _scene_case(22, 2500, (512, 512), views=3, with_extra=True)
     _all_checks(cfg, res, max_tiles=64)
 
