@@ -153,6 +153,16 @@ int gsr_setup_views(int num_views, const float* extrinsics, const float* intrins
 int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present,
                      void* stream);
 
+/* Covariances from scales + rotations: what upstream's preprocess does when `scales`/`rotations` are given instead of
+ * `cov3D_precomp` ([EXT] forward.cu computeCov3D; quaternion (r, x, y, z), not normalised): cov6 (n, 6) = upper triangle of
+ * R diag((scale_modifier * s)^2) R^T, and its backward ([EXT] backward.cu computeCov3D) from the dL/dcov6 that gsr_backward
+ * returns (doubled off-diagonals).  dL_dscales / dL_drotations may be null.  Reference call site: the `scales=`, `rotations=`
+ * arguments of GaussianRasterizer.forward (PF3plat itself passes cov3D_precomp, cuda_splatting.py:123). */
+int gsr_cov_from_scale_rot(int64_t n, const float* scales, const float* rotations, float scale_modifier, float* cov6,
+                           void* stream);
+int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float* rotations, float scale_modifier,
+                                    const float* dL_dcov6, float* dL_dscales, float* dL_drotations, void* stream);
+
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
  * Forward stages: 0 preprocess (geometry + hit masks) 1 colour (SH; on the product path this one overlaps stages 0-4 on a

@@ -89,6 +89,10 @@ def load():
     lib.gsr_workspace_sizes.argtypes = [dp, szp, szp, szp]
     lib.gsr_workspace_layout.restype = ctypes.c_int
     lib.gsr_workspace_layout.argtypes = [dp, i64p]
+    lib.gsr_cov_from_scale_rot.restype = ctypes.c_int
+    lib.gsr_cov_from_scale_rot.argtypes = [ctypes.c_int64, vp, vp, ctypes.c_float, vp, vp]
+    lib.gsr_cov_from_scale_rot_backward.restype = ctypes.c_int
+    lib.gsr_cov_from_scale_rot_backward.argtypes = [ctypes.c_int64, vp, vp, ctypes.c_float, vp, vp, vp, vp]
     lib.gsr_capacity_for.restype = ctypes.c_int64
     lib.gsr_capacity_for.argtypes = [dp, ctypes.c_uint64, ctypes.c_uint32]
     lib.gsr_forward.restype = ctypes.c_int
@@ -113,7 +117,7 @@ def load():
 EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
-    "gsr_capacity_for",
+    "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward",
 )
 FWD_STAGES = ("preprocess", "color", "tile_scan", "emit", "sort", "blend")
 BWD_STAGES = ("blend_bwd", "preprocess_bwd")

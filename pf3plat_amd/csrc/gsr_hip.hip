@@ -2317,6 +2317,69 @@ using namespace gsr;
 
 static hipEvent_t* g_bwd_events = nullptr;
 
+// ------------------------------------------------------------------------------------------------
+// Covariance from scale + rotation ([EXT] forward.cu computeCov3D, backward.cu computeCov3D; oracle cov3d_from_scale_rot and the
+// use_scale_rot branch of preprocess_backward): Sigma = Rm diag((mod s)^2) Rm^T with Rm from the quaternion (r, x, y, z), NOT
+// normalised by the kernel (upstream has the division commented out).  28 B in, 24 B out per Gaussian; same expression
+// order as the oracle.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void quat_to_rm(const float* q, float* Rm) {
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  Rm[0] = 1.f - 2.f * (y * y + z * z); Rm[1] = 2.f * (x * y - r * z); Rm[2] = 2.f * (x * z + r * y);
+  Rm[3] = 2.f * (x * y + r * z); Rm[4] = 1.f - 2.f * (x * x + z * z); Rm[5] = 2.f * (y * z - r * x);
+  Rm[6] = 2.f * (x * z - r * y); Rm[7] = 2.f * (y * z + r * x); Rm[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+__global__ __launch_bounds__(256) void k_cov_from_scale_rot(long long n, const float* scales, const float* rots, float mod, float* cov6) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float q[4] = {rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]};
+  float Rm[9];
+  quat_to_rm(q, Rm);
+  const float sc[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
+  auto S = [&](int a, int b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) acc += Rm[3 * a + k] * sc[k] * sc[k] * Rm[3 * b + k];
+    return acc;
+  };
+  float* o = cov6 + 6 * i;
+  o[0] = S(0, 0); o[1] = S(0, 1); o[2] = S(0, 2); o[3] = S(1, 1); o[4] = S(1, 2); o[5] = S(2, 2);
+}
+
+__global__ __launch_bounds__(256) void k_cov_from_scale_rot_bwd(long long n, const float* scales, const float* rots, float mod,
+                                                                const float* dcov6, float* dscales, float* drots) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float q[4] = {rots[4 * i], rots[4 * i + 1], rots[4 * i + 2], rots[4 * i + 3]};
+  const float r = q[0], x = q[1], y = q[2], z = q[3];
+  float Rm[9];
+  quat_to_rm(q, Rm);
+  const float* dc = dcov6 + 6 * i;
+  // symmetric dSigma with halved off-diagonals (dcov6 carries the doubled off-diagonal convention of the rasterizer backward)
+  const float dS[9] = {dc[0], 0.5f * dc[1], 0.5f * dc[2], 0.5f * dc[1], dc[3], 0.5f * dc[4], 0.5f * dc[2], 0.5f * dc[4], dc[5]};
+  const float sc[3] = {mod * scales[3 * i], mod * scales[3 * i + 1], mod * scales[3 * i + 2]};
+  float dRm[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float col[3] = {Rm[k], Rm[3 + k], Rm[6 + k]};
+    float dSc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dSc[a] = dS[3 * a] * col[0] + dS[3 * a + 1] * col[1] + dS[3 * a + 2] * col[2];
+    const float quad = col[0] * dSc[0] + col[1] * dSc[1] + col[2] * dSc[2];
+    if (dscales) dscales[3 * i + k] = 2.f * sc[k] * quad * mod;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dRm[3 * a + k] = 2.f * sc[k] * sc[k] * dSc[a];
+  }
+  if (drots) {
+    float* dq = drots + 4 * i;
+    dq[0] = 2.f * (-z * dRm[1] + y * dRm[2] + z * dRm[3] - x * dRm[5] - y * dRm[6] + x * dRm[7]);
+    dq[1] = 2.f * (y * dRm[1] + z * dRm[2] + y * dRm[3] - 2.f * x * dRm[4] - r * dRm[5] + z * dRm[6] + r * dRm[7] - 2.f * x * dRm[8]);
+    dq[2] = 2.f * (-2.f * y * dRm[0] + x * dRm[1] + r * dRm[2] + x * dRm[3] + z * dRm[5] - r * dRm[6] + z * dRm[7] - 2.f * y * dRm[8]);
+    dq[3] = 2.f * (-2.f * z * dRm[0] - r * dRm[1] + x * dRm[2] + r * dRm[3] - 2.f * z * dRm[4] + y * dRm[5] + x * dRm[6] + y * dRm[7]);
+  }
+}
+
 // Per host thread: one non-blocking side stream and a fork/join event pair (created on first use, kept for the life of
 // the thread - the only persistent state the library holds).  Event records are ordered by the calling stream, so the
 // pair can be reused call after call, and the fork/join pattern is capturable into a HIP graph.
@@ -2578,6 +2641,27 @@ int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* mea
   p.d = *dims; p.g = make_grid(dims->width, dims->height); p.views = views; p.means = means;
   hipLaunchKernelGGL(k_mark_visible, dim3((unsigned)((dims->num_gaussians + 255) / 256), (unsigned)dims->num_sets),
                      dim3(256), 0, static_cast<hipStream_t>(stream_), p, present);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_cov_from_scale_rot(int64_t n, const float* scales, const float* rotations, float scale_modifier, float* cov6, void* stream_) {
+  if (n < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GSR_OK;
+  if (!scales || !rotations || !cov6) return GSR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_cov_from_scale_rot, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     (long long)n, scales, rotations, scale_modifier, cov6);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float* rotations, float scale_modifier,
+                                    const float* dL_dcov6, float* dL_dscales, float* dL_drotations, void* stream_) {
+  if (n < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (n == 0) return GSR_OK;
+  if (!scales || !rotations || !dL_dcov6) return GSR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_cov_from_scale_rot_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
+                     (long long)n, scales, rotations, scale_modifier, dL_dcov6, dL_dscales, dL_drotations);
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
 }

@@ -116,6 +116,25 @@ class HipBackend:
             raise RuntimeError(f"gsr_workspace_sizes rejected the call (code {rc}): {cfg_repr(dims)}")
         return g.value, b.value, i.value
 
+    def cov_from_scale_rot(self, scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+        n = scales.shape[0]
+        out = torch.empty((n, 6), dtype=torch.float32, device=scales.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
+        rc = self.lib.gsr_cov_from_scale_rot(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(out), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_cov_from_scale_rot failed with code {rc}")
+        return out
+
+    def cov_from_scale_rot_backward(self, scales: Tensor, rotations: Tensor, scale_modifier: float, d_cov6: Tensor):
+        n = scales.shape[0]
+        d_s, d_r = torch.empty_like(scales), torch.empty_like(rotations)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
+        rc = self.lib.gsr_cov_from_scale_rot_backward(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(d_cov6),
+                                                      _ptr(d_s), _ptr(d_r), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_cov_from_scale_rot_backward failed with code {rc}")
+        return d_s, d_r
+
     def workspace_layout(self, dims: _lib.GsrDims):
         offs = (ctypes.c_int64 * 8)()
         rc = self.lib.gsr_workspace_layout(ctypes.byref(dims), offs)
@@ -427,8 +446,35 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     return color, (extra_img if has_extra else None), radii
 
 
+class _CovFromScaleRot(torch.autograd.Function):
+    """[EXT] forward.cu / backward.cu computeCov3D through the C ABI (gsr_cov_from_scale_rot[_backward]): covariances (n, 6) from
+    scales (n, 3) and quaternions (n, 4; r, x, y, z; not normalised), with gradients for both."""
+
+    @staticmethod
+    def forward(ctx, scales: Tensor, rotations: Tensor, scale_modifier: float, backend):
+        if not (scales.is_cuda and rotations.is_cuda):
+            raise RuntimeError("pf3plat_amd rasterizer: tensors must be on a ROCm device (there is no CPU fallback path)")
+        scales, rotations = scales.contiguous().float(), rotations.contiguous().float()
+        ctx.save_for_backward(scales, rotations)
+        ctx.mod, ctx.backend = float(scale_modifier), backend
+        return backend.cov_from_scale_rot(scales, rotations, ctx.mod)
+
+    @staticmethod
+    def backward(ctx, d_cov6):
+        scales, rotations = ctx.saved_tensors
+        d_s, d_r = ctx.backend.cov_from_scale_rot_backward(scales, rotations, ctx.mod, d_cov6.contiguous().float())
+        return d_s, d_r, None, None
+
+
 def _cov3d_from_scale_rotation(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
-    """[EXT] forward.cu computeCov3D as differentiable torch ops: quaternion (r,x,y,z), not normalised."""
+    backend = get_backend()
+    if hasattr(backend, "cov_from_scale_rot"):
+        return _CovFromScaleRot.apply(scales, rotations, scale_modifier, backend)
+    return _cov3d_from_scale_rotation_torch(scales, rotations, scale_modifier)
+
+
+def _cov3d_from_scale_rotation_torch(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+    """The same arithmetic as differentiable torch ops (used by the CPU-side tests, which drive the wrappers with the oracle)."""
     r, x, y, z = rotations.unbind(-1)
     rm = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
                       2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),

@@ -158,10 +158,19 @@ def test_per_view_rasterizer_upstream_signature():
             rast(means3D=means, means2D=means2d, opacities=t(sc["opac"]), cov3D_precomp=t(sc["cov6"]))
         with pytest.raises(Exception, match="exactly one"):
             rast(means3D=means, means2D=means2d, shs=shs, opacities=t(sc["opac"]))
-        # scales/rotations instead of cov3D_precomp
-        img2, _ = rast(means3D=means, means2D=means2d, shs=shs, opacities=t(sc["opac"]), scales=t(sc["scales"]), rotations=t(sc["rots"]))
+        # scales/rotations instead of cov3D_precomp (HIP: gsr_cov_from_scale_rot[_backward]; CPU side of the comparison:
+        # the same arithmetic as torch ops in front of the oracle)
+        scales = t(sc["scales"]).requires_grad_(True)
+        rots = t(sc["rots"]).requires_grad_(True)
+        img2, _ = rast(means3D=means, means2D=means2d, shs=shs, opacities=t(sc["opac"]), scales=scales, rotations=rots)
+        wimg = torch.linspace(0.2, 1.0, img2.numel(), device=device).reshape(img2.shape)
+        (img2 * wimg).sum().backward()
+        settings15 = settings._replace(scale_modifier=1.5)
+        img3, _ = GaussianRasterizer(settings15)(means3D=means, means2D=means2d, shs=shs, opacities=t(sc["opac"]), scales=scales,
+                                                 rotations=rots)
         return (img.detach().cpu().numpy(), radii.cpu().numpy(), means.grad.cpu().numpy(), means2d.grad.cpu().numpy(),
-                shs.grad.cpu().numpy(), vis.cpu().numpy(), img2.detach().cpu().numpy())
+                shs.grad.cpu().numpy(), vis.cpu().numpy(), img2.detach().cpu().numpy(), scales.grad.cpu().numpy(),
+                rots.grad.cpu().numpy(), img3.detach().cpu().numpy())
 
     g = run(DEV)
     o = _with_oracle(lambda: run("cpu"))
@@ -170,6 +179,9 @@ def test_per_view_rasterizer_upstream_signature():
         assert rel_l2(g[i], o[i]) < 1e-4, i
     assert np.array_equal(g[5], o[5]) and g[5].all()
     assert rel_l2(g[6], g[0]) < 1e-4  # scale/rotation path reproduces the precomputed covariance image
+    assert rel_l2(g[7], o[7]) < 1e-4 and rel_l2(g[8], o[8]) < 1e-4  # dL/dscales, dL/drotations
+    assert np.abs(o[7]).max() > 0 and np.abs(o[8]).max() > 0
+    assert rel_l2(g[9], o[9]) < 1e-4 and rel_l2(g[9], g[6]) > 1e-2  # scale_modifier reaches the covariance
 
 
 def test_setup_views_kernel_matches_reference_camera_arithmetic():
