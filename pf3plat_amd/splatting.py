@@ -24,15 +24,6 @@ from .geometry import depth_to_relative_disparity, get_fov, get_projection_matri
 from .rasterizer import get_backend, pack_views, rasterize_views
 from .types import DepthRenderingMode
 
-_TRIU = ((0, 0, 0, 1, 1, 2), (0, 1, 2, 1, 2, 2))  # torch.triu_indices(3, 3)
-
-
-def _cov6(covariances: Tensor) -> Tensor:
-    """(..., 3, 3) -> (..., 6) upper triangle xx,xy,xz,yy,yz,zz (reference :115,123); gradients land on the
-    upper-triangle entries only, as with the reference's fancy-index gather."""
-    return covariances[..., _TRIU[0], _TRIU[1]]
-
-
 def _cameras(extrinsics, intrinsics, near, far, scale_invariant: bool):
     """Shared camera set-up of render_cuda (reference :64-71, :80-87): returns per-view
     (view_matrix^T, full_projection^T, campos, tan_fov_x, tan_fov_y, scale)."""
@@ -136,11 +127,11 @@ def render_cuda_orthographic(
         full_projection = view_matrix @ projection_matrix
         viewbuf = pack_views(view_matrix, full_projection, extrinsics[:, :3, 3], tan_fov_x.expand(b),
                              tan_fov_y.expand(b) if tan_fov_y.dim() == 0 else tan_fov_y, background_color, None)
-    shs = gaussian_sh_coefficients.permute(0, 1, 3, 2)
-    colors = shs if use_sh else shs[:, :, 0, :]
+    # harmonics (b, g, 3, d_sh) and covariances (b, g, 3, 3) go to the operator as they are (as in render_cuda)
+    colors = gaussian_sh_coefficients if use_sh else gaussian_sh_coefficients[:, :, :, 0]
     color, _, _ = rasterize_views(
-        gaussian_means, _cov6(gaussian_covariances), gaussian_opacities, colors, viewbuf,
-        image_shape=image_shape, sh_degree=degree, use_sh=use_sh, views_per_set=1)
+        gaussian_means, gaussian_covariances, gaussian_opacities, colors, viewbuf,
+        image_shape=image_shape, sh_degree=degree, use_sh=use_sh, views_per_set=1, sh_planar=True, cov_3x3=True)
     return color
 
 
