@@ -150,7 +150,8 @@ struct Params {
   uint32_t stride;       // index-list entries owned by every (view, tile)
   uint32_t tail_off, tail_cap;  // the rest of the index list: lists longer than `stride`, bump-allocated
   uint32_t* tail_counter;
-  uint32_t* page_counter;  // in the status block: pages of the key buffer handed out so far
+  unsigned long long* page_counter;  // in the status block: (call tag << 32) | pages of the key pool handed out so far
+  uint32_t call_tag;       // unique per gsr_forward call of this process: a counter left by another call reads as zero
   uint32_t* tile_total;
   uint2* ranges;
   unsigned long long* keys;
@@ -626,6 +627,20 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
 // Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the `chunk` Gaussians of
 // one row of the count matrix, histograms their pairs in LDS while it projects them and stores the row at the end -
 // k_count's result without a second pass over the records and without its launch.
+// Pages of the key pool come from a bump counter in the status block.  The counter carries the tag of the call that last
+// touched it in its upper half: a value left by any other call (or never initialised) counts as zero, so the workspace
+// needs no zeroing and nothing has to clean up.  Only the rare workgroup that outgrows its fixed slot comes here.
+__device__ __forceinline__ uint32_t take_pages(const Params& p, uint32_t n) {
+  const unsigned long long tag = (unsigned long long)p.call_tag << 32;
+  unsigned long long cur = __hip_atomic_load(p.page_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    const unsigned long long base = (cur >> 32) == (tag >> 32) ? cur : tag;
+    const unsigned long long seen = atomicCAS(p.page_counter, cur, base + n);
+    if (seen == cur) return (uint32_t)base;
+    cur = seen;
+  }
+}
+
 // Measurement aid: eight 64-bit stamps per slot at the very end of the key buffer (pages handed out last, so unused in
 // any run that does not overflow).
 __device__ __forceinline__ unsigned long long* dbg_stamps(const Params& p, size_t slot) {
@@ -655,8 +670,7 @@ __device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
 //      stored pair by pair are 64 separate 8-byte requests per instruction and were the longest phase of the old emit.
 // Nothing here depends on another workgroup: no count matrix prefix, no tile scan, no second pass over the records.
 // k_sort_tiles<true> later collects a tile's list from the <= rows regions (column (v, :, t) of the pair matrix).
-// The bump counter is left at zero by the blend kernel of the previous call; a dirty counter can only cause a (reported)
-// overflow, never an out-of-range store.  (Same-address device atomics cost ~17 ns each on this chip, one after the other:
+// (Same-address device atomics cost ~17 ns each on this chip, one after the other:
 // a counter hit by every workgroup of a launch is a serial section, hence the fixed slots here and in the sort.)
 __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) {
   extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     uint32_t base = (uint32_t)(blk * kSlotStride);
     if (total > (uint32_t)kStagePairs) {
       const uint32_t npages = (total + kPage - 1) / kPage;
-      const uint32_t first = atomicAdd(p.page_counter, npages);
+      const uint32_t first = take_pages(p, npages);
       base = (first <= p.key_pages && npages <= p.key_pages - first) ? p.pool_off + first * (uint32_t)kPage : 0xffffffffu;
     }
     sBase = base;
@@ -1282,7 +1296,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       }
       if (ok && n > kLds) {  // contiguous scratch for the in-place global sort, from the page pool
         const uint32_t np = ((uint32_t)n + kPage - 1) / kPage;
-        const uint32_t first = atomicAdd(p.page_counter, np);
+        const uint32_t first = take_pages(p, np);
         if (first <= p.key_pages && np <= p.key_pages - first) scratch = p.pool_off + first * (uint32_t)kPage;
         else ok = 0;
       }
@@ -1527,7 +1541,6 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
   const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
 
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.page_counter = 0u;  // leave the bump counter clean for the next call
   if (p.status->overflow) {  // pair workspace too small: nothing was binned.  Poison the outputs so the condition cannot go
     if (wave == 0 && inside) {  // unnoticed even when the caller defers reading the status block.
       const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
@@ -2295,7 +2308,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
     p.tail_cap = (uint32_t)(capq > VTs ? (capq - VTs > 0xffffffffull ? 0xffffffffull : capq - VTs) : 0ull);
   }
   p.tail_counter = reinterpret_cast<uint32_t*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[1]);
-  p.page_counter = reinterpret_cast<uint32_t*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[0]);
+  p.page_counter = reinterpret_cast<unsigned long long*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[0]);
   p.tile_total = reinterpret_cast<uint32_t*>(b + L.o_total);
   p.ranges = reinterpret_cast<uint2*>(b + L.o_ranges);
   p.keys = reinterpret_cast<unsigned long long*>(b + L.o_keys);
@@ -2450,6 +2463,8 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   if (d.has_extra && ((!extra && ((d.flags >> 4) & 7) == 0) || !out_extra)) return GSR_ERR_INVALID_ARGUMENT;
   Params p = base_params(dims, views, means, cov6, opacities, colors, extra, geom, bin, img);
   p.out_color = out_color; p.out_extra = out_extra; p.radii = radii;
+  static std::atomic<uint32_t> call_counter{1u};
+  p.call_tag = call_counter.fetch_add(1u, std::memory_order_relaxed);
   const Layout L = make_layout(d);
   if (N == 0) {  // upstream returns an all-zero image when there is nothing to rasterize
     GSR_CHECK(hipMemsetAsync(out_color, 0, V * 3 * HW * sizeof(float), st));

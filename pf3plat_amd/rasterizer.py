@@ -180,9 +180,6 @@ class HipBackend:
             geom=torch.empty(gb, dtype=u8, device=device), bin=torch.empty(bb, dtype=u8, device=device),
             img=torch.empty(ib, dtype=u8, device=device),
         )
-        # the status block holds the bump counter of the key pages: the library leaves it at zero after every forward, the
-        # owner of a fresh workspace zeroes it once (a dirty counter is safe but can cause a spurious, reported, overflow)
-        plan["bin"][:64].zero_()
         if backward:
             if colors_shape is None:
                 if cfg.sh_coeffs > 0:
