@@ -344,3 +344,11 @@ def test_non_finite_inputs_are_culled_and_do_not_disturb_the_rest():
         assert np.isfinite(g).all(), k
         assert np.all(g[0, :6] == 0), k
         np.testing.assert_allclose(g[0, 6:], hip_r["grads"][k][0], rtol=1e-4, atol=1e-5)  # fp32 atomics: order-dependent sums
+
+
+def test_one_million_gaussians_512x512_forward_and_backward():
+    """Scale check beyond BASELINE's configs: 1 M Gaussians (489 binning rows > the 256 a sort workgroup reads in one stride),
+    512 x 512 (4096 tiles), colour + extra channel, gradients."""
+    cfg, res = _scene_case(31, 1_000_000, (512, 512))
+    _all_checks(cfg, res, max_tiles=48)
+    assert res["hip"]["status"]["num_pairs"] > 3_000_000
