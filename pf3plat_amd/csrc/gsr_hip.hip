@@ -2278,6 +2278,8 @@ static bool dims_ok(const GsrDims* d) {
   if (d->num_views > 65535 || d->pair_capacity < 0 || d->pair_capacity > 0xfffffff0ll) return false;
   const Grid g = make_grid(d->width, d->height);
   if ((int64_t)d->num_views * g.T > 0x7fffffffll) return false;
+  const Layout L = make_layout(*d);  // key offsets are 32-bit: slots + page pool must stay below 2^32 keys
+  if (L.key_slots + L.key_pages * (size_t)kPage > 0xfffffff0ull) return false;
   return true;
 }
 
