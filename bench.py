@@ -7,8 +7,11 @@ HBM.  W untimed warm-up steps, then EXACTLY K timed steps bracketed by barrier +
 MAX over ranks; rank 0 prints ONE JSON line.  `value` = views rendered by all ranks / that time.
 
 N > 1: one process per GPU (torch.distributed, backend "nccl" = RCCL).  Views shard one scene per rank with no
-data-path collective; the rendered views of the K steps are all-gathered ONCE at the end of the timed region
-(one fused RCCL collective over xGMI, north_star), so scaling is "weak".
+data-path collective; every view is rendered straight into its slot of the exchange buffer and the K views are
+all-gathered (RCCL over xGMI) in up to 8 batches of consecutive steps, each issued asynchronously when its last
+view has been enqueued so that it overlaps the rendering of the next batch - only the last batch's gather is
+exposed, inside the timed region (north_star: gather of rendered views at the end, never per tile or per view).
+Scaling is "weak".
 
 After the timed region (never inside it): fwd+bwd timing (configs[2]), per-stage HIP-event timing of the same
 launch chain for the roofline object, a parity spot check and the CPU baseline (oracle, rank 0, N == 1 only).
@@ -196,16 +199,35 @@ def main():
     # timed region (north_star: "all-gather of rendered tiles ... only at the end").  Eager launches (the per-step
     # destination slot is not capturable in a static graph).
     views = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev) if world > 1 else None
+    # The exchange is cut into up to 8 chunks of consecutive steps; a chunk's all-gather is issued (async, RCCL's own
+    # stream) as soon as its last view is enqueued and overlaps the rendering of the next chunk - only the last chunk's
+    # gather is exposed.  Every view is rendered straight into its slot of `views` (no copy).
+    n_chunks = min(8, max(1, K // 8)) if world > 1 else 0
+    bounds = [round(c * K / n_chunks) for c in range(n_chunks + 1)] if n_chunks else []
+    all_views = torch.empty((world, K, 3, H, W), dtype=torch.float32, device=dev) if (world > 1 and backend == "nccl") else None
 
     def timed(fn, k, keep_views):
         barrier()
         t0 = time.perf_counter()
+        handles = []
+        nxt = 1
         for i in range(k):
-            fn()
             if keep_views:
-                views[i].copy_(plan["color"][0], non_blocking=True)
+                be.run_forward(plan, viewbuf, means, cov6, opac, shs, out_color=views[i:i + 1])
+                if all_views is not None and i + 1 == bounds[nxt]:
+                    i0, i1 = bounds[nxt - 1], bounds[nxt]
+                    outs = [all_views[r, i0:i1] for r in range(world)]
+                    handles.append(dist.all_gather(outs, views[i0:i1], async_op=True))
+                    nxt += 1
+            else:
+                fn()
         if keep_views:
-            gathered.append(gather_views(views))  # (world * K, 3, H, W) on every rank
+            if all_views is not None:
+                for h in handles:
+                    h.wait()
+                gathered.append(all_views.reshape(world * K, 3, H, W))
+            else:
+                gathered.append(gather_views(views))  # functional path (gloo): one gather of (world * K, 3, H, W)
         barrier()
         return time.perf_counter() - t0
 
@@ -243,7 +265,7 @@ def main():
         "config": {"workload": f"configs[1]: {n} Gaussians (SH degree 4, 25 coeffs), 1 view {H}x{W}, fwd-only raster, "
                                "one scene per GPU (seed 2+rank), inputs resident in HBM",
                    "launch": launch_mode,
-                   "parallelism": f"views sharded 1 scene/GPU x{world}" + (f", one fused RCCL all-gather of the {K} x {world} rendered views at the end" if world > 1 else ""),
+                   "parallelism": f"views sharded 1 scene/GPU x{world}" + (f", RCCL all-gather of the {K} x {world} rendered views in {n_chunks} batches overlapped with rendering, the last one at the end" if world > 1 else ""),
                    "num_pairs_8x8": status["num_pairs"], "max_tile_list": status["max_list"]},
     }
     if eager_dt is not None:

@@ -197,11 +197,16 @@ class HipBackend:
             )
         return plan
 
-    def run_forward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra=None, profile: bool = False):
-        """Enqueue one forward launch chain on the current stream.  profile=True returns per-stage ms (synchronises)."""
+    def run_forward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra=None, profile: bool = False, out_color=None):
+        """Enqueue one forward launch chain on the current stream.  profile=True returns per-stage ms (synchronises).
+        out_color: render into this contiguous (V, 3, H, W) fp32 tensor instead of the plan's own image (e.g. a slot of a
+        buffer that is all-gathered later: no copy)."""
         stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
+        color = plan["color"] if out_color is None else out_color
+        if color.shape != plan["color"].shape or color.dtype != torch.float32 or not color.is_contiguous():
+            raise ValueError("out_color must be a contiguous fp32 tensor of the plan's image shape")
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
-                _ptr(plan["color"]), _ptr(plan["extra_img"]), _ptr(plan["radii"]), _ptr(plan["geom"]), _ptr(plan["bin"]),
+                _ptr(color), _ptr(plan["extra_img"]), _ptr(plan["radii"]), _ptr(plan["geom"]), _ptr(plan["bin"]),
                 _ptr(plan["img"]), stream)
         if profile:
             ms = (ctypes.c_float * len(_lib.FWD_STAGES))()
