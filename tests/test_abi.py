@@ -89,3 +89,23 @@ def test_rasterizer_argument_errors_match_upstream_messages(oracle_backend):
         r(means3D=m, means2D=m, opacities=torch.ones(2, 1), colors_precomp=torch.zeros(2, 3))
     with pytest.raises(RuntimeError, match=r"means3D must have dimensions \(num_points, 3\)"):
         r(means3D=torch.zeros(2, 4), means2D=m, opacities=torch.ones(2, 1), colors_precomp=torch.zeros(2, 3), cov3D_precomp=torch.zeros(2, 6))
+
+
+def test_capacity_for_is_host_arithmetic():
+    """gsr_capacity_for: 2 x max(num_pairs, views x tiles x max_list) - half the index list is per-(view, tile) slots, half a
+    shared region for longer lists (include/gsr.h)."""
+    lib = _lib.load()
+    be = rasterizer.HipBackend()
+    cfg = rasterizer.RasterConfig(3, 1, 3, 1000, 256, 256, 4, 25, 4, False)
+    dims = be._dims(cfg, 0)
+    tiles = 4 * 16 * 16  # 8x8 tiles of a 256 x 256 image
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 5_000_000, 100) == 2 * 5_000_000
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 1000, 2000) == 2 * 3 * tiles * 2000
+    assert be.capacity_for(cfg, {"num_pairs": 1000, "max_list": 2000}, headroom=1.0) == 2 * 3 * tiles * (2000 + 16)
+    dims.abi_version = 99
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 1, 1) == -1
+    # covariance helpers: bad sizes / null pointers are error codes, n == 0 is a no-op
+    assert lib.gsr_cov_from_scale_rot(-1, None, None, ctypes.c_float(1.0), None, None) == -1
+    assert lib.gsr_cov_from_scale_rot(0, None, None, ctypes.c_float(1.0), None, None) == 0
+    assert lib.gsr_cov_from_scale_rot(4, None, None, ctypes.c_float(1.0), None, None) == -1
+    assert lib.gsr_cov_from_scale_rot_backward(4, None, None, ctypes.c_float(1.0), None, None, None, None) == -1
