@@ -1256,6 +1256,13 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     // range of tiles
     const int tg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
     const int v = tg / T, t = tg - v * T;
+    // De-phase the first resident round.  All its workgroups start together and would gather together (memory-bound, CUs
+    // idle: 250 k small reads take 11 us when issued at once, 2-4 us per workgroup when spread out), then sort together
+    // (LDS-bound, memory idle).  Four groups 2 us apart let one group's gather overlap another's bucket sort (measured:
+    // forward 81.2 -> 77.0 us).  Later rounds start whenever a slot frees up and are out of phase by themselves.
+    if (blockIdx.x < 1024u) {
+      for (int q = 0; q < (int)((blockIdx.x >> 3) & 3); ++q) __builtin_amdgcn_s_sleep(64);
+    }
     const uint2* col = p.pair_mat + (size_t)v * R * (T + 8) + t;
     const size_t cstride = (size_t)T + 8;
     const uint32_t* bb = p.blk_base + (size_t)v * R;
