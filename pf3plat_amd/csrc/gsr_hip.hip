@@ -2469,7 +2469,8 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const size_t V = d.num_views, N = d.num_gaussians, HW = (size_t)d.height * d.width;
   if (V == 0) return GSR_OK;
   if (!views || !out_color || !bin || !img) return GSR_ERR_INVALID_ARGUMENT;
-  if (d.has_extra && ((!extra && ((d.flags >> 4) & 7) == 0) || !out_extra)) return GSR_ERR_INVALID_ARGUMENT;
+  if (d.has_extra && !out_extra) return GSR_ERR_INVALID_ARGUMENT;
+  if (d.has_extra && N > 0 && !extra && ((d.flags >> 4) & 7) == 0) return GSR_ERR_INVALID_ARGUMENT;  // (an empty array has no address)
   Params p = base_params(dims, views, means, cov6, opacities, colors, extra, geom, bin, img);
   p.out_color = out_color; p.out_extra = out_extra; p.radii = radii;
   static std::atomic<uint32_t> call_counter{1u};

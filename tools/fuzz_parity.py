@@ -1,0 +1,73 @@
+"""Randomised HIP-vs-oracle parity sweep (MI355X box): random Gaussian counts, image sizes, view / set structure, SH degrees,
+extra channel, scale factors and pair capacities, every case through the same checks as tests/test_gpu_parity.py.
+usage: python tools/fuzz_parity.py [seconds=60] [seed=0]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pf3plat_amd import _lib, synthetic  # noqa: E402
+from pf3plat_amd.rasterizer import RasterConfig  # noqa: E402
+from tests import gpu_util, parity_checks  # noqa: E402
+
+
+def one_case(rng):
+    n = int(rng.choice([0, 1, 7, 63, 64, 65, 500, 1023, 1024, 1025, 3000, 9000, 20000]))
+    h, w = int(rng.integers(1, 161)), int(rng.integers(1, 161))
+    if rng.random() < 0.15:
+        h, w = int(rng.choice([8, 16, 64, 128])), int(rng.choice([8, 16, 64, 128]))
+    sets = int(rng.choice([1, 1, 2]))
+    vps = int(rng.choice([1, 1, 2, 3]))
+    views = sets * vps
+    d_sh = int(rng.choice([1, 4, 9, 16, 25]))
+    use_sh = bool(rng.random() < 0.8)
+    with_extra = bool(rng.random() < 0.5)
+    windowed = bool(rng.random() < 0.2)
+    seed = int(rng.integers(0, 1 << 30))
+    scs = [synthetic.make_scene(seed + s, n, (h, w), num_views=vps, d_sh=d_sh, near=float(rng.choice([1.0, 0.5, 2.0]))) for s in range(sets)]
+    parts = [gpu_util.scene_tensors(sc, use_sh) for sc in scs]
+    means, cov6, opac, colors = (torch.cat([p[k] for p in parts], 0) for k in range(4))
+    vb = torch.cat([gpu_util.scene_viewbuf(sc, bool(rng.random() < 0.7)) for sc in scs], 0)
+    extra = torch.tensor(rng.uniform(0.5, 2.0, (views, n)).astype(np.float32)) if with_extra else None
+    deg = int(round(d_sh ** 0.5)) - 1
+    flags = _lib.FLAG_WINDOWED_BINNING if windowed else 0
+    cfg = RasterConfig(views, sets, vps, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, flags)
+    gc = torch.tensor(rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32))
+    ge = torch.tensor(rng.uniform(0, 1, (views, h, w)).astype(np.float32)) if with_extra else None
+    cap = None if rng.random() < 0.7 else int(rng.integers(1, 5000))
+    desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap)
+    one_case.last = desc
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
+    if n:
+        for v in range(views):
+            parity_checks.check_preprocess(res, cfg, v)
+            parity_checks.check_tile_lists(res, cfg, v, max_tiles=16)
+            parity_checks.check_image_state(res, cfg, v)
+    parity_checks.check_image(res, cfg)
+    if n:
+        parity_checks.check_grads(res, cfg)
+    return desc
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    t0, k = time.time(), 0
+    while time.time() - t0 < budget:
+        state = rng.bit_generator.state
+        try:
+            desc = one_case(rng)
+        except Exception as e:
+            print("FAILED case", k, getattr(one_case, "last", None), "rng state", state["state"], "->", type(e).__name__, str(e)[:2000], flush=True)
+            raise
+        k += 1
+        if k % 20 == 0:
+            print(k, "cases ok, last:", desc, flush=True)
+    print(f"{k} random cases passed in {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
