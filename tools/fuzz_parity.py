@@ -40,6 +40,7 @@ def one_case(rng):
     cap = None if rng.random() < 0.7 else int(rng.integers(1, 5000))
     desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap)
     one_case.last = desc
+    one_case.inputs = (cfg, vb, means, cov6, opac, colors, extra, gc, ge)
     res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
     if n:
         for v in range(views):
@@ -61,6 +62,21 @@ def main():
         try:
             desc = one_case(rng)
         except Exception as e:
+            try:  # which side is off?  fp32 oracle and HIP against the fp64 oracle
+                r64 = gpu_util.run_both(*one_case.inputs, oracle_dtype=np.float64)
+                from tests.oracle_backend import OracleBackend
+                cfg, vb, *args = one_case.inputs
+                ob = OracleBackend(dtype=np.float32, threads=8)
+                oc, oe, orad, osaved = ob.forward(cfg, vb, *args[:5])
+                og = ob.backward(cfg, osaved, vb, *args[:5], args[5], args[6], True)
+                names = ("means", "cov6", "opac", "colors", "extra", "means2d")
+                for nm, t in zip(names, og):
+                    if t is None or r64["oracle"]["grads"][nm] is None:
+                        continue
+                    ref = r64["oracle"]["grads"][nm]
+                    print(f"  {nm}: hip vs f64 {parity_checks.rel_l2(r64['hip']['grads'][nm], ref):.3e} | f32 oracle vs f64 {parity_checks.rel_l2(t.numpy(), ref):.3e}", flush=True)
+            except Exception as e2:
+                print("  (fp64 diagnosis failed:", type(e2).__name__, e2, ")")
             print("FAILED case", k, getattr(one_case, "last", None), "rng state", state["state"], "->", type(e).__name__, str(e)[:2000], flush=True)
             raise
         k += 1
