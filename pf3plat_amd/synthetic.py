@@ -125,4 +125,5 @@ def scene_viewbuf(scene: Scene, scale_invariant: bool = True) -> Tensor:
     s, v = scene.extrinsics.shape[:2]
     vm, fp, cp, tx, ty, sc = _cameras(scene.extrinsics.reshape(s * v, 4, 4), scene.intrinsics.reshape(s * v, 3, 3),
                                       scene.near.reshape(s * v), scene.far.reshape(s * v), scale_invariant)
-    return pack_views(vm, fp, cp, tx, ty, scene.background.reshape(1, 3).expand(s * v, 3), sc)
+    return pack_views(vm, fp, cp, tx, ty, scene.background.reshape(1, 3).expand(s * v, 3), sc,
+                      near=scene.near.reshape(s * v), far=scene.far.reshape(s * v))

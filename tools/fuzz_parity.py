@@ -34,11 +34,26 @@ def one_case(rng):
     extra = torch.tensor(rng.uniform(0.5, 2.0, (views, n)).astype(np.float32)) if with_extra else None
     deg = int(round(d_sh ** 0.5)) - 1
     flags = _lib.FLAG_WINDOWED_BINNING if windowed else 0
+    # native layouts and built-in extra modes (depth / disparity / relative disparity / log from the camera-space depth)
+    planar = bool(use_sh and rng.random() < 0.4)
+    cov33 = bool(rng.random() < 0.4)
+    emode = int(rng.integers(1, 5)) if (with_extra and rng.random() < 0.4) else 0
+    if planar:
+        flags |= _lib.FLAG_SH_PLANAR
+        colors = colors.permute(0, 1, 3, 2).contiguous()
+    if cov33:
+        flags |= _lib.FLAG_COV_3X3
+        c = cov6
+        cov6 = torch.stack((c[..., 0], c[..., 1], c[..., 2], c[..., 1], c[..., 3], c[..., 4], c[..., 2], c[..., 4], c[..., 5]), -1).reshape(*c.shape[:-1], 3, 3).contiguous()
+    if emode:
+        flags |= emode << 4
+        extra = None
     cfg = RasterConfig(views, sets, vps, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, flags)
     gc = torch.tensor(rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32))
     ge = torch.tensor(rng.uniform(0, 1, (views, h, w)).astype(np.float32)) if with_extra else None
     cap = None if rng.random() < 0.7 else int(rng.integers(1, 5000))
-    desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap)
+    desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap,
+                planar=planar, cov33=cov33, emode=emode)
     one_case.last = desc
     one_case.inputs = (cfg, vb, means, cov6, opac, colors, extra, gc, ge)
     res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
