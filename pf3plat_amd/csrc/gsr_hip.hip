@@ -1606,9 +1606,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
       CG = __builtin_elementwise_fma(f2{rg.z, rg.w}, w, CG);
       CB = __builtin_elementwise_fma(f2{be.x, be.y}, w, CB);
       if (kExtra) CE = __builtin_elementwise_fma(f2{be.z, be.w}, w, CE);
-      const uint32_t idx = b * kFB + e0 + u;
-      last = (w.x > 0.f) ? idx + 1 : last;
-      last = (w.y > 0.f) ? idx + 2 : last;
+      last += (uint32_t)alive0 + (uint32_t)alive1;  // entries this pixel's loop went through (a prefix of the list)
     }
   };
   auto put_records = [&](int sb, const float4& q, const float2& q2, const float4& c) {  // lane = entry of the batch
@@ -1681,12 +1679,14 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
         C0 += sPart[h][0][lane]; C1 += sPart[h][1][lane]; C2 += sPart[h][2][lane];
         if (kExtra) E += sPart[h][3][lane];
         T = fminf(T, sPart[h][4][lane]);
-        last = max(last, sLast[h][lane]);
+        last += sLast[h][lane];
       }
       const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
       const GsrView& cam = p.views[v];
       p.final_T[(size_t)v * HW + pix] = T;
-      p.n_contrib[(size_t)v * HW + pix] = last;
+      // the pixel's loop ran through `last` entries before it stopped (every splat it blended has a smaller index; the reference
+      // stores the index of the last one it blended - the entries in between are skipped by the alpha < 1/255 test either way)
+      p.n_contrib[(size_t)v * HW + pix] = min(last, n);  // (the padding of the last batch counts as alive)
       float* oc = p.out_color + (size_t)v * 3 * HW;
       oc[pix] = C0 + T * cam.bg[0];
       oc[HW + pix] = C1 + T * cam.bg[1];
