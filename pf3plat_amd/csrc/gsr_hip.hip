@@ -1645,8 +1645,9 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
       if (do_stage) stage_batch(geom, rgbc, n, bs * kFB, lane, id_next, kExtra, sg, sg2, sc);  // global gather in flight
       if (wave == (int)((i + 3) & 3) && lane < kFB) id_next = ((i + 3) * kFB + lane < n) ? plist[(i + 3) * kFB + lane] : 0u;
       const float t1 = Tb * P0, t2 = t1 * P1, t3 = t2 * P2, t4 = t3 * P3;  // the same chain in every wave
+      const bool last_batch = __all(t4 < 0.0001f);  // every pixel has stopped by the end of this batch: no need to evaluate the next
       accum(i, wave == 0 ? Tb : wave == 1 ? t1 : wave == 2 ? t2 : t3);
-      if (i + 1 < nbat) eval(i + 1);
+      if (i + 1 < nbat && !last_batch) eval(i + 1);
       if (do_stage) {
         put_records((int)(bs & 3), sg, sg2, sc);
       }
