@@ -134,11 +134,15 @@ def check_image_state(res, cfg, v=0):
     st = o.image_state()
     ht, ot = ws["final_T"][v].astype(np.float64), st["final_T"].astype(np.float64)
     d = np.abs(ht - ot)
-    big = ot >= 1e-3
+    flipped = d > 1e-3 * np.abs(ot) + 1e-7  # a decision fell the other way at this pixel (0.4 % of T, or a factor 1 - alpha)
+    big = (ot >= 1e-3) & ~flipped
     m = {"final_T_rel_above_1e-3": float(np.linalg.norm((ht - ot)[big]) / max(np.linalg.norm(ot[big]), 1e-30)) if big.any() else 0.0,
-         "final_T_median_abs": float(np.median(d)) if d.size else 0.0, "final_T_outliers_1e-4": int((d > 1e-4).sum())}
-    assert m["final_T_median_abs"] < 1e-6 and m["final_T_rel_above_1e-3"] < 1e-3, m
+         "final_T_median_abs": float(np.median(d)) if d.size else 0.0, "final_T_flipped_pixels": int(flipped.sum()),
+         "final_T_outliers_1e-4": int((d > 1e-4).sum())}
+    assert m["final_T_median_abs"] < 1e-6 and m["final_T_rel_above_1e-3"] < 1e-4, m
     assert m["final_T_outliers_1e-4"] <= max(4, int(2e-3 * d.size)), m
+    # pixels that end at the stop threshold (T ~ 1e-4) flip easily: one entry earlier or later; bound the others
+    assert int((flipped & (ot >= 1e-3)).sum()) <= max(4, int(2e-3 * d.size)), m
     return m
 
 
