@@ -12,12 +12,14 @@
 //     pixel's 16x16 parent tile is inside the ceil(3 sigma) rect) and then drops (8x8 tile, splat)
 //     pairs that provably cannot reach alpha >= 1/255 anywhere in the tile (exact min of the conic
 //     quadratic over the tile box) - a result-preserving cull;
-//   * binning is a counting sort by tile (64-way replicated counters -> wave scan -> slot scatter)
-//     followed by a per-tile depth sort in LDS (64-bit key = depth bits : Gaussian index, so ties
-//     break by index as the reference's stable radix sort does); no global 64-bit radix sort and
-//     no device->host read of the pair count;
+//   * binning is a counting sort by tile done inside the preprocess kernel (per-workgroup LDS histogram -> scan over the
+//     tiles -> the workgroup's own region of the key buffer; no cross-workgroup prefix, no global atomics), followed by a
+//     per-tile gather + depth sort in LDS (64-bit key = depth bits : Gaussian index, so ties break by index as the
+//     reference's stable radix sort does); no global 64-bit radix sort and no device->host read of the pair count;
+//   * the blend kernels cut a tile's list into segments, one per wave: transmittance and the backward's accumulators are
+//     linear recurrences, so a segment needs from its predecessors only a product (and a sum);
 //   * SH coefficients (300 of the ~350 input bytes per Gaussian) are staged wave-cooperatively
-//     through LDS with 16-byte coalesced loads and read once per set for all of its views in backward.
+//     through LDS with 16-byte coalesced loads and read once per set for all of its views, forward and backward.
 //
 // Built with -ffp-contract=off: projection / EWA / SH arithmetic then evaluates the same expression
 // trees as the fp32 oracle (IEEE +,-,*,/ and sqrt are correctly rounded on both sides).
@@ -34,7 +36,6 @@ constexpr int kChunkMin = 1024;
 constexpr int kCUs = 256;
 constexpr int kBinThreads = 1024; // threads of a binning workgroup (count / emit)
 constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup (32 KiB)
-constexpr int kSortLds = 4096;    // per-tile list length sorted in LDS (32 KiB); longer lists sort in global memory
 constexpr int kSortThreads = 256; // threads cooperating on one tile's sort
 constexpr int kPage = 1024;        // pairs per page of the key buffer: a binning workgroup's private region is whole pages
 constexpr int kSlotStride = 8192 + 136;  // keys between the fixed slots of consecutive binning workgroups: NOT a multiple of the memory
@@ -882,14 +883,16 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Binning = counting sort of (8x8 tile, splat) pairs by tile WITHOUT global atomics (device-scope atomics
-// measured ~25 G/s on MI355X: 50 us per pass at 1.25 M pairs).  A workgroup owns a chunk of `chunk` Gaussians
-// of one view and histograms its pairs per tile in LDS:
-//   K2 count : counts[v][chunk][tile] = pairs of this chunk in this tile        (LDS atomics, coalesced row store)
-//   K3a      : per (v, tile) exclusive scan down the chunk rows, tile totals     (column scan)
-//   K3b      : exclusive scan over all (v, tile) totals -> list ranges, pair total, overflow flag
-//   K4 emit  : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
-// Count and emit walk the same footprints with the same code, so slots match counts exactly.
+// WINDOWED binning path (images of more than kTileWindow tiles, or GSR_FLAG_WINDOWED_BINNING): counting sort of (8x8 tile,
+// splat) pairs by tile with exact global offsets and WITHOUT global atomics (device-scope atomics measured ~25 G/s on
+// MI355X: 50 us per pass at 1.25 M pairs).  A workgroup owns a chunk of `chunk` Gaussians of one view and histograms its
+// pairs per tile in LDS, one window of kTileWindow tiles at a time:
+//   k_count       : counts[v][chunk][tile] = pairs of this chunk in this tile     (LDS atomics, coalesced row store)
+//   k_tile_prefix : per (v, tile) exclusive scan down the chunk rows, tile totals  (column scan)
+//   k_tile_scan   : exclusive scan over all (v, tile) totals -> list ranges, pair total, overflow flag (or inside k_emit)
+//   k_emit        : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
+// Count and emit walk the same footprints with the same code, so slots match counts exactly.  Images of up to kTileWindow
+// tiles take k_preprocess_bin + k_sort_tiles<gather> instead (above / below).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
   __shared__ uint32_t hist[kTileWindow];
@@ -1146,7 +1149,7 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
 
 // ------------------------------------------------------------------------------------------------
 // K5: per-tile depth sort, kSortThreads threads per tile.  Bitonic network in its all-ascending (mirror)
-// form so that a list of any length sorts with virtual +inf padding; <= kSortLds keys sort in LDS, longer
+// form so that a list of any length sorts with virtual +inf padding; <= kLds keys sort in LDS, longer
 // lists in place in global memory.  Within a substep all compare-exchanges are disjoint, so each thread
 // loads a batch of pairs before storing any (LDS latency paid once per batch, not once per pair).
 // Writes the sorted Gaussian indices (the reference's point_list).
@@ -1189,8 +1192,7 @@ __device__ __forceinline__ void bitonic_block(KeyPtr a, int n, int lgnp, int tid
   }
 }
 
-constexpr int kBuckets = 1024;    // per-tile depth buckets of the bucket sort
-constexpr int kSpanMax = 48;      // longest per-thread span the insertion-sort finish accepts (else bitonic fallback)
+constexpr int kSpanMax = 48;      // most keys in one depth bucket the rank finish accepts (else bitonic fallback)
 
 // Exclusive scan over the kSortThreads per-thread values of a workgroup (wave scan + 4 wave totals through LDS).
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot /*[4] LDS*/, int tid, uint32_t& total) {
@@ -1214,13 +1216,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
   return basew + s - v;
 }
 
-// K5: per-tile depth sort, kSortThreads threads per tile; writes the sorted Gaussian indices (the reference's
-// point_list).  Lists of up to kSortLds keys: LDS bucket sort - keys stay in registers, one LDS-atomic histogram
-// over kBuckets buckets of the tile's own depth range (float bits are monotonic for positive depths), exclusive
-// scan, LDS-atomic scatter, then every thread insertion-sorts the few keys of its 4 adjacent buckets with the full
-// 64-bit (depth, index) compare.  ~40 B of LDS traffic per key instead of ~800 B for an in-LDS bitonic network.
-// Degenerate depth distributions (a span longer than kSpanMax) fall back to the bitonic network on the same LDS
-// array; lists longer than kSortLds sort in place in global memory with the same network.
+// Per-tile depth sort, kSortThreads threads per tile; writes the sorted Gaussian indices (the reference's point_list).
+// Lists of up to kLds keys: LDS bucket sort - keys stay in registers, one LDS-atomic histogram over kLds / 4 buckets of the
+// tile's own depth range (float bits are monotonic for positive depths), exclusive scan, LDS-atomic scatter into bucket
+// order, then every key ranks itself among the few keys of its own bucket with the full 64-bit (depth, index) compare and
+// goes to its final place.  ~40 B of LDS traffic per key instead of ~800 B for an in-LDS bitonic network.  Degenerate depth
+// distributions (a bucket of more than kSpanMax keys) fall back to the bitonic network on the same LDS array; lists longer
+// than kLds sort in place in global memory with the same network.
 // kGather = false: the tile's keys are a contiguous range (ranges[]) written by k_emit.
 // kGather = true : the tile's keys sit in up to `rows` runs, one per binning workgroup (k_preprocess_bin): column
 //   (view, :, tile) of the pair matrix says where and how many.  The workgroup sums the column, copies the runs into LDS in
