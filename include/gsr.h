@@ -165,8 +165,9 @@ int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float*
 
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
- * Forward stages: 0 preprocess (geometry + hit masks) 1 colour (SH; on the product path this one overlaps stages 0-4 on a
- * side stream) 2 count + tile scans 3 emit 4 per-tile sort 5 blend.
+ * Forward stages: 0 preprocess (geometry, hit masks and - images of up to 8192 tiles - the whole binning) 1 colour (SH; on
+ * the product path this one overlaps stages 0-4 on a side stream) 2 count + tile scans and 3 emit (windowed binning path
+ * only: empty, i.e. one event gap each, otherwise) 4 per-tile gather + sort 5 blend.
  * Backward stages: 0 blend backward 1 preprocess backward. */
 #define GSR_FWD_STAGES 6
 #define GSR_BWD_STAGES 2
