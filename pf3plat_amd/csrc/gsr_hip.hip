@@ -2434,7 +2434,7 @@ extern "C" {
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 const char* gsr_build_info(void) {
-  return "gsr_hip gfx950 wave64 tile8x8 chunk1024 sortlds4096 abi1";
+  return "gsr_hip gfx950 wave64 tile8x8 fused-binning segment-blend abi1";
 }
 
 int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes) {
