@@ -135,3 +135,21 @@ def test_builtin_depth_channel_equals_explicit_fake_colour(oracle_backend, mode)
         outs.append((d.detach().numpy(), m.grad.numpy(), c.grad.numpy(), o.grad.numpy()))
     for a, b, name in zip(outs[0], outs[1], ("depth", "d_means", "d_cov", "d_opac")):
         assert rel_l2(a, b) < 5e-5, (mode, name, rel_l2(a, b))
+
+
+def test_gaussians_container_helpers():
+    import pytest
+    import torch
+
+    from pf3plat_amd.types import Gaussians
+
+    g = Gaussians(torch.zeros(2, 5, 3), torch.zeros(2, 5, 3, 3), torch.zeros(2, 5, 3, 25), torch.ones(2, 5))
+    assert (g.num_scenes, g.num_gaussians, g.d_sh, g.sh_degree) == (2, 5, 25, 4)
+    c = g.check().clone()
+    c.means += 1
+    assert float(g.means.sum()) == 0 and float(c.means.sum()) == 30
+    assert g.to(torch.float64).harmonics.dtype == torch.float64 and not g.detach().means.requires_grad
+    with pytest.raises(ValueError, match="covariances"):
+        Gaussians(g.means, torch.zeros(2, 5, 6), g.harmonics, g.opacities).check()
+    with pytest.raises(ValueError, match="harmonics"):
+        Gaussians(g.means, g.covariances, torch.zeros(2, 5, 3, 24), g.opacities).check()
