@@ -15,9 +15,9 @@
  *     pass instead of a second raster pass.
  *
  * Conventions (all pointers are DEVICE pointers owned by the caller unless noted; the library
- * allocates nothing persistent, enqueues all work on `stream`, never synchronises the host, never
- * throws; every entry point returns GSR_OK or a negative error code.  gsr_forward forks its SH->colour kernel onto a
- * per-thread internal side stream and joins it before the blend - a HIP-graph-capturable pattern):
+ * allocates nothing and keeps no state between calls, enqueues all work on `stream` as a plain chain of kernel launches
+ * (capturable into a HIP graph), never synchronises the host (except in GSR_FLAG_DEBUG mode and in the *_profile aids), never
+ * throws; every entry point returns GSR_OK or a negative error code):
  *   means     (num_sets, N, 3)   fp32 world-space centres                     (means3D)
  *   cov6      (num_sets, N, 6)   fp32 xx,xy,xz,yy,yz,zz                       (cov3D_precomp)
  *   opacities (num_sets, N)      fp32 in (0,1)
@@ -56,17 +56,34 @@ extern "C" {
 #define GSR_EXTRA_RELATIVE_DISPARITY 3
 #define GSR_EXTRA_LOG 4
 #define GSR_FLAG_EXTRA_MODE(m) ((m) << 4)
-/* GsrDims.flags bits >= 8 are measurement-only ablation switches (tools/ablate.py): they make results WRONG on purpose
- * to time a kernel without one of its parts.  Never set on the product path. */
+/* GsrDims.flags bit 0: upstream's `prefiltered` (accepted and ignored: nothing is pre-filtered, exactly as upstream behaves
+ * with prefiltered = False); bit 1: upstream's `debug` (cuda_splatting.py:111) - the library synchronises the stream after
+ * every stage of the call and checks for errors; on failure the entry point returns GSR_ERR_LAUNCH and
+ * gsr_last_failed_stage() names the stage. */
+#define GSR_FLAG_PREFILTERED 0x1
+#define GSR_FLAG_DEBUG 0x2
+/* Deterministic backward: the per-(view, Gaussian) screen-space gradients are accumulated as 64-bit fixed-point integers
+ * (2^-32 resolution, integer atomics commute), so two runs on the same inputs return bit-identical gradients whatever
+ * order the tiles finish in.  The scratch buffer is then twice as large (gsr_backward_scratch_bytes). */
+#define GSR_FLAG_DETERMINISTIC 0x80
+/* Test aid: take the windowed binning path (preprocess, count, prefix, scan, emit, sort) even when the image has few enough
+ * tiles for the fused one (k_preprocess_bin + gathering sort). */
+#define GSR_FLAG_WINDOWED_BINNING 0x4000
+/* Every other bit is rejected (GSR_ERR_INVALID_ARGUMENT). */
+#define GSR_FLAG_VALID_MASK (GSR_FLAG_PREFILTERED | GSR_FLAG_DEBUG | GSR_FLAG_SH_PLANAR | GSR_FLAG_COV_3X3 | 0x70 | \
+                             GSR_FLAG_DETERMINISTIC | GSR_FLAG_WINDOWED_BINNING)
+#ifdef GSR_ABLATE
+/* Measurement-only build (tools/ablate.py compiles its own copy of the library with -DGSR_ABLATE; the product library does
+ * not contain these branches and rejects the bits): switches that make results WRONG on purpose to time a kernel without
+ * one of its parts, and device-side phase stamps written into unused workspace. */
 #define GSR_FLAG_ABLATE_NO_COUNT 0x100       /* preprocess: skip the per-tile pair counting atomics */
-#define GSR_FLAG_ABLATE_NO_SH 0x200          /* preprocess: skip SH staging + evaluation */
+#define GSR_FLAG_ABLATE_NO_SH 0x200          /* skip the colour pass */
 #define GSR_FLAG_ABLATE_EMIT_NO_STORE 0x400  /* emit: skip the key stores */
 #define GSR_FLAG_ABLATE_EMIT_NO_ATOMIC 0x800 /* emit: skip the slot atomics */
 #define GSR_FLAG_ABLATE_NO_GEOM_STORE 0x1000 /* preprocess: skip the projected-record store */
-#define GSR_FLAG_DEBUG_TIMING 0x2000
-/* Test aid: take the windowed binning path (preprocess, count, prefix, scan, emit, sort) even when the image has few enough
- * tiles for the fused one (k_preprocess_bin + gathering sort). */
-#define GSR_FLAG_WINDOWED_BINNING 0x4000         /* forward blend: per-tile cycle stamps into the (then unused) key buffer */
+#define GSR_FLAG_DEBUG_TIMING 0x2000         /* phase stamps (100 MHz counter) into the tail of the key buffer */
+#define GSR_FLAG_ABLATE_MASK 0x3f00
+#endif
 
 /* One camera = the non-tensor fields of upstream's GaussianRasterizationSettings
  * (constructed at cuda_splatting.py:99-112), 48 floats = 192 bytes. */
@@ -93,7 +110,7 @@ typedef struct GsrDims {
   int32_t sh_coeffs;      /* M coefficients in memory; 0 => colours are precomputed RGB */
   int32_t max_sh_eval;    /* highest SH band evaluated (4; 3 = vanilla upstream) */
   int32_t has_extra;      /* 1 => `extra`/`out_extra` are used */
-  int32_t flags;          /* bit0: prefiltered (ignored, as upstream without debug); bit1: debug */
+  int32_t flags;          /* GSR_FLAG_* | GSR_FLAG_EXTRA_MODE(m); unknown bits are rejected */
   int64_t pair_capacity;  /* capacity of the (tile,splat) pair workspaces, in pairs; see gsr_capacity_for */
 } GsrDims;
 
@@ -140,6 +157,14 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
                  const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
                  void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
                  float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream);
+
+/* GSR_FLAG_DEBUG: the stage of the last failed call of this host thread (forward: 0 preprocess/binning, 1 count + scans,
+ * 2 emit, 3 sort + colour, 4 blend; backward: 0 blend backward, 1 preprocess backward), or -1. */
+int gsr_last_failed_stage(void);
+
+/* Bytes of the `scratch` buffer gsr_backward needs for these dims (V * N * 12 floats; twice that with
+ * GSR_FLAG_DETERMINISTIC). */
+size_t gsr_backward_scratch_bytes(const GsrDims* dims);
 
 /* Camera set-up in one launch: fills views[0..num_views) from camera-to-world extrinsics (V,4,4), normalised intrinsics
  * (V,3,3), near/far (V) and a background colour (background_stride 3: one per view; 0: one shared) - the arithmetic of the

@@ -15,11 +15,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "gsr_hip.hip")
 HEADER = os.path.join(REPO_ROOT, "include", "gsr.h")
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")  # (override: tools/ablate.py's measurement build)
 GSR_ABI_VERSION = 1
 SCREEN_GRAD_FLOATS = 12
+FLAG_PREFILTERED = 0x1  # accepted and ignored, as upstream with prefiltered = False
+FLAG_DEBUG = 0x2  # upstream's `debug`: synchronise + check after every stage
 FLAG_SH_PLANAR = 0x4
 FLAG_COV_3X3 = 0x8
+FLAG_DETERMINISTIC = 0x80  # backward accumulates in 64-bit fixed point: bit-identical from run to run
 FLAG_WINDOWED_BINNING = 0x4000  # test aid: the windowed binning path on an image small enough for the fused one
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
@@ -49,17 +52,20 @@ def is_stale() -> bool:
     return any(os.path.getmtime(s) > t for s in (SRC, HEADER))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/gsr_hip.hip -> libgsr_hip.so for gfx950 (seconds; no GPU needed)."""
-    if force or is_stale():
-        cmd = [find_hipcc(), *HIPCC_FLAGS, "-o", LIB_PATH + ".tmp", SRC]
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
+    """Compile csrc/gsr_hip.hip -> libgsr_hip.so for gfx950 (seconds; no GPU needed).  `extra_flags` / `out`: measurement
+    builds (tools/ablate.py: -DGSR_ABLATE into its own file)."""
+    out = out or LIB_PATH
+    stale = is_stale() if out == LIB_PATH else (not os.path.exists(out) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in (SRC, HEADER)))
+    if force or stale:
+        cmd = [find_hipcc(), *HIPCC_FLAGS, *extra_flags, "-o", out + ".tmp", SRC]
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
-        os.replace(LIB_PATH + ".tmp", LIB_PATH)
+        os.replace(out + ".tmp", out)
         if verbose:
-            print("built", LIB_PATH)
-    return LIB_PATH
+            print("built", out)
+    return out
 
 
 _lib = None
@@ -89,6 +95,10 @@ def load():
     lib.gsr_workspace_sizes.argtypes = [dp, szp, szp, szp]
     lib.gsr_workspace_layout.restype = ctypes.c_int
     lib.gsr_workspace_layout.argtypes = [dp, i64p]
+    lib.gsr_last_failed_stage.restype = ctypes.c_int
+    lib.gsr_last_failed_stage.argtypes = []
+    lib.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
+    lib.gsr_backward_scratch_bytes.argtypes = [dp]
     lib.gsr_cov_from_scale_rot.restype = ctypes.c_int
     lib.gsr_cov_from_scale_rot.argtypes = [ctypes.c_int64, vp, vp, ctypes.c_float, vp, vp]
     lib.gsr_cov_from_scale_rot_backward.restype = ctypes.c_int
@@ -117,7 +127,11 @@ def load():
 EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
-    "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward",
+    "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
+    "gsr_backward_scratch_bytes",
 )
-FWD_STAGES = ("preprocess", "color", "tile_scan", "emit", "sort", "blend")
+# gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning
+# kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).
+FWD_STAGES = ("preprocess", "color", "count_scan", "emit", "sort", "blend")
+FWD_DEBUG_STAGES = ("preprocess/binning", "count + scans", "emit", "sort + colour", "blend")
 BWD_STAGES = ("blend_bwd", "preprocess_bwd")

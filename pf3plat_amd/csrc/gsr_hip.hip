@@ -29,6 +29,15 @@
 
 #include "../../include/gsr.h"
 
+// Measurement-only switches (tools/ablate.py builds its own library with -DGSR_ABLATE): ablation bits that make results
+// WRONG on purpose and device-side phase stamps.  The product library is compiled without them - the branches do not
+// exist in it, and dims_ok() rejects the bits.
+#ifdef GSR_ABLATE
+#define GSR_ABL(flags, bit) (((flags) & (bit)) != 0)
+#else
+#define GSR_ABL(flags, bit) false
+#endif
+
 namespace gsr {
 
 constexpr int kChunkMax = 2048;   // most Gaussians per binning workgroup (= one row of the per-view count matrix)
@@ -51,7 +60,7 @@ struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one
   float4 q3;  // bits: hit mask lo, hit mask hi, window origin (sx0 | sy0 << 12 | big << 31), depth
 };
 // The view-dependent colour lives in its own array (float4 per (view, Gaussian): r, g, b, bits(clamp mask)) because it is
-// produced by a separate kernel (k_color) that runs on a second stream concurrently with the geometry/binning chain.
+// produced by the colour workgroups that ride in the sort launch (color_unit), not by the geometry/binning kernel.
 // q3: the 8x8 tiles this splat must be listed in, as a 64-bit mask over the 8x8-tile window whose top-left tile is
 // (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); computed once in preprocess, consumed by count and emit.
 // Footprints wider than 8 tiles set `big` and are re-derived from q0/q1 by the binning kernels.
@@ -153,6 +162,8 @@ struct Params {
   uint32_t* tail_counter;
   unsigned long long* page_counter;  // in the status block: (call tag << 32) | pages of the key pool handed out so far
   uint32_t call_tag;       // unique per gsr_forward call of this process: a counter left by another call reads as zero
+  uint32_t sort_blocks;    // k_sort_tiles: workgroups [0, sort_blocks) sort a tile each, the rest evaluate one 64-Gaussian colour unit
+  uint32_t color_units;    // colour units per set = ceil(N / 64)
   uint32_t* tile_total;
   uint2* ranges;
   unsigned long long* keys;
@@ -499,14 +510,12 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1: preprocess ([EXT] forward.cu preprocessCUDA; oracle preprocess()), split in two kernels that run CONCURRENTLY on
-// two streams because they have nothing in common but the means:
-//   k_preprocess (this stream, feeds the binning chain): projection, EWA covariance, conic, radius, reference rect and the
-//       64-bit 8x8-tile hit mask - 40 B in, 64 B out per (view, Gaussian), VALU-bound on the hit tests;
-//   k_color (side stream, joined before the blend): SH -> RGB (+0.5, clamp mask) for every view of a set - 300 of the 352
-//       input bytes per Gaussian, HBM-bound.  The wave's 64 x 3M SH floats (19 200 B at M = 25) are requested first, as
-//       16-byte coalesced loads into registers, then transposed through LDS (row stride 3M floats, odd => conflict-free)
-//       and evaluated once per view of the set (the SH of a set is read ONCE however many views it has).
+// K1: preprocess ([EXT] forward.cu preprocessCUDA; oracle preprocess()), split in two parts that have nothing in common
+// but the means:
+//   geometry (k_preprocess / k_preprocess_bin, feeds the binning chain): projection, EWA covariance, conic, radius,
+//       reference rect and the 64-bit 8x8-tile hit mask - 40 B in, 64 B out per (view, Gaussian), VALU-bound;
+//   colour (color_unit, further down: workgroups riding in the sort launch): SH -> RGB (+0.5, clamp mask) for every view
+//       of a set - 300 of the 352 input bytes per Gaussian, HBM-bound.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPreThreads = 256;
 
@@ -567,7 +576,7 @@ __device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i,
   rec.q2 = make_float4(0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius));
   unsigned long long mask = 0ull;
   uint32_t origin = 0u;
-  if (vis && !(p.d.flags & GSR_FLAG_ABLATE_NO_COUNT)) {
+  if (vis && !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_COUNT)) {
     const Foot f = make_foot(px, py, conA, conB, conC, op, my_radius, g);
     if (f.sx1 > f.sx0 && f.sy1 > f.sy0) {
       origin = (uint32_t)f.sx0 | ((uint32_t)f.sy0 << 12);
@@ -621,7 +630,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   if (first >= N) return;
   GeomRec rec{};
   if (i < N) rec = preprocess_one(p, v, i, [](int) {}, [](int, const Foot&, float) {});
-  if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
+  if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
     store_records_wave(p.geom + (size_t)v * N + first, N - first, rec, stage[threadIdx.x >> 6], lane);
 }
 
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T, N = p.d.num_gaussians;
-  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
   unsigned long long* stamp = dbg_stamps(p, (size_t)(blockIdx.y * gridDim.x + blockIdx.x));
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
@@ -720,7 +729,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
       });
       q3s[it] = rec.q3;
     }
-    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_GEOM_STORE))
+    if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
       store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
   }
   __syncthreads();
@@ -815,20 +824,28 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
 #undef GSR_STAMP
 }
 
-constexpr int kShPre = 19;  // float4 registers per lane that hold a full wave's SH rows (64 * 75 / 4 / 64 = 18.75)
+// Colour role of the sort kernel: SH -> RGB (+0.5, clamp mask) of one 64-Gaussian unit for every view of its set, by a
+// workgroup of kSortThreads threads.  All threads request the unit's 64 x 3M SH floats (19 200 B at M = 25) as 16-byte
+// coalesced loads, park them in LDS (row stride 3M floats, odd => conflict-free) and wave w evaluates views w, w + 4, ... with
+// lane = Gaussian (the SH of a set is read ONCE however many views it has).  These workgroups ride in the same launch as the
+// per-tile sorts (k_sort_tiles: blockIdx >= sort_blocks): the sort is latency-bound and leaves HBM idle, the colour pass is
+// HBM-bound (300 of the 352 input bytes per Gaussian) - one stream, no second queue, no events.
+constexpr int kColorThreads = 256;
+constexpr int kShPre = 5;  // float4 registers per thread that hold the unit's SH rows (64 * 75 / 4 / 256 = 4.7)
+constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 75: odd)
 
-__global__ __launch_bounds__(64) void k_color(const Params p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, float* lds) {
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-  const int lane = threadIdx.x, set = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int set = (int)(cu / p.color_units), unit = (int)(cu - (uint32_t)set * p.color_units);
   const int N = p.d.num_gaussians, Vs = p.d.views_per_set;
-  const int g0 = blockIdx.x * 64;
+  const int g0 = unit * 64;
   const int i = g0 + lane;
   const bool in_range = i < N;
   const size_t gi = (size_t)set * N + (in_range ? i : 0);
   const int M = p.d.sh_coeffs;
   if (M == 0) {  // precomputed colours: copy through (no clamp)
-    if (in_range)
+    if (in_range && wave == 0)
       for (int vv = 0; vv < Vs; ++vv)
         p.rgbc[(size_t)(set * Vs + vv) * N + i] = make_float4(p.colors[3 * gi], p.colors[3 * gi + 1], p.colors[3 * gi + 2], 0.f);
     return;
@@ -842,29 +859,32 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
     float4 pre[kShPre];
 #pragma unroll
     for (int q = 0; q < kShPre; ++q) {
-      const int k = lane + 64 * q;
+      const int k = tid + kColorThreads * q;
       pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int q = 0; q < kShPre; ++q) {
-      const int k = lane + 64 * q;
+      const int k = tid + kColorThreads * q;
       if (k < sh_n4) reinterpret_cast<float4*>(lds)[k] = pre[q];
     }
-    for (int k = (sh_n4 << 2) + lane; k < sh_total; k += 64) lds[k] = sh_src[k];
+    for (int k = (sh_n4 << 2) + tid; k < sh_total; k += kColorThreads) lds[k] = sh_src[k];
   } else {
-    stage_rows(lds, sh_src, cnt, rowf, ldstride, lane);
+    for (int k = tid; k < sh_total; k += kColorThreads) {
+      const int row = k / rowf;
+      lds[row * ldstride + (k - row * rowf)] = sh_src[k];
+    }
   }
   float rmx = 0, rmy = 0, rmz = 0;
-  if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
+  if (in_range && wave < Vs) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
   __syncthreads();
   if (!in_range) return;
   const float* sh = lds + lane * ldstride;
   const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
   const int ks = planar ? 1 : 3, cs = planar ? M : 1;  // coefficient k of channel c sits at k * ks + c * cs
   const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
-  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0 && set == 0 && lane == 0;
-  if (dbg) dbg_stamps(p, 16384 + blockIdx.x)[0] = t_start;
-  for (int vv = 0; vv < Vs; ++vv) {
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
+  if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
+  for (int vv = wave; vv < Vs; vv += kColorThreads / 64) {
     const int v = set * Vs + vv;
     const GsrView& cam = p.views[v];
     const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
@@ -879,7 +899,7 @@ __global__ __launch_bounds__(64) void k_color(const Params p) {
     const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
     p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
   }
-  if (dbg) dbg_stamps(p, 16384 + blockIdx.x)[1] = __builtin_amdgcn_s_memrealtime();
+  if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -903,7 +923,7 @@ __global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
     const int t1 = min(T, t0 + kTileWindow);
     for (int k = tid; k < t1 - t0; k += kBinThreads) hist[k] = 0;
     __syncthreads();
-    if (!(p.d.flags & GSR_FLAG_ABLATE_NO_COUNT))
+    if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_COUNT))
       for_each_pair(p, v, row, tid, t0, t1, [&](int, int t, float) { atomicAdd(&hist[t - t0], 1u); });
     __syncthreads();
     for (int k = tid; k < t1 - t0; k += kBinThreads) out[t0 + k] = hist[k];
@@ -1022,7 +1042,7 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
   const int T = p.g.T;
   const uint32_t* rowp = p.counts + ((size_t)v * p.rows + row) * T;
   const uint32_t cap = (uint32_t)p.d.pair_capacity;
-  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
   unsigned long long* stamp = p.keys + (size_t)cap - (size_t)(blockIdx.x + 1) * 8;
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
@@ -1099,8 +1119,8 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
     if (overflow) return;
     GSR_STAMP(3);
     auto put = [&](int gi, int t, float depth) {
-      const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
-      if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
+      const uint32_t slot = GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t] : atomicAdd(&cursor[t], 1u);
+      if (slot < cap && !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_EMIT_NO_STORE))
         p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
     };
 #pragma unroll
@@ -1138,8 +1158,8 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
     for (int k = tid; k < t1 - t0; k += kBinThreads) cursor[k] = rng[t0 + k].x + rowp[t0 + k];
     __syncthreads();
     for_each_pair(p, v, row, tid, t0, t1, [&](int i, int t, float depth) {
-      const uint32_t slot = (p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t - t0] : atomicAdd(&cursor[t - t0], 1u);
-      if (slot < cap && !(p.d.flags & GSR_FLAG_ABLATE_EMIT_NO_STORE))
+      const uint32_t slot = GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_EMIT_NO_ATOMIC) ? cursor[t - t0] : atomicAdd(&cursor[t - t0], 1u);
+      if (slot < cap && !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_EMIT_NO_STORE))
         p.keys[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)i;
     });
     __syncthreads();
@@ -1232,20 +1252,27 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 //   shared counters when pair_capacity >= 2 x views x tiles x longest list).
 template <bool kGather, int kLds>
 __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
-  // kLds keys sort in LDS, over kLds / 4 depth buckets.  The 2048-key variant fits the LDS one k_color workgroup frees
-  // (18.2 KB < 19.2 KB): in the eager chain the sort starts while the colour kernel is still draining, and a 36 KB
-  // workgroup had to wait for two neighbouring colour workgroups to retire.
+  // kLds keys sort in LDS, over kLds / 4 depth buckets.  The 2048-key variant needs no more LDS than a colour unit
+  // (18.4 KB vs 19.2 KB), so eight workgroups of either role share a CU.
   constexpr int kBk = kLds / 4, kBkBits = kLds == 4096 ? 10 : 9, kBpt = kBk / kSortThreads;
   static_assert(kLds == 4096 || kLds == 2048, "bucket geometry");
-  __shared__ unsigned long long sk[kLds];
-  __shared__ uint32_t hist[kBk];  // counts, then (same storage) scatter cursors
+  static_assert(kColorThreads == kSortThreads, "the colour role shares the sort kernel's workgroup shape");
+  // one block: keys (kLds x 8 B), then the bucket counters (kBk x 4 B) - or, in a colour workgroup, the unit's SH rows
+  constexpr int kSortWords = kLds + kBk / 2, kColorWords = kColorLdsFloats / 2;
+  __shared__ __attribute__((aligned(16))) unsigned long long smem[kSortWords > kColorWords ? kSortWords : kColorWords];
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
+  if (blockIdx.x >= p.sort_blocks) {  // workgroup-uniform: the colour pass rides in this launch (see color_unit)
+    color_unit(p, blockIdx.x - p.sort_blocks, reinterpret_cast<float*>(smem));
+    return;
+  }
+  unsigned long long* sk = smem;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kLds);  // counts, then (same storage) scatter cursors
   uint32_t* cur = hist;
   const int tid = threadIdx.x;
-  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
   unsigned long long* stamp = dbg_stamps(p, 8192 + blockIdx.x);
-  unsigned long long* stamp2 = dbg_stamps(p, 8192 + gridDim.x + blockIdx.x);
+  unsigned long long* stamp2 = dbg_stamps(p, 8192 + p.sort_blocks + blockIdx.x);
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define GSR_STAMP2(k) do { if (dbg && tid == 0) stamp2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
@@ -1256,7 +1283,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     const int T = p.g.T, R = p.rows;
     // XCD-aware order: neighbouring tiles' runs share cache lines in every region, so give each XCD (= each L2) a contiguous
     // range of tiles
-    const int tg = xcd_remap((int)blockIdx.x, (int)gridDim.x);
+    const int tg = xcd_remap((int)blockIdx.x, (int)p.sort_blocks);
     const int v = tg / T, t = tg - v * T;
     // De-phase the first resident round.  All its workgroups start together and would gather together (memory-bound, CUs
     // idle: 250 k small reads take 11 us when issued at once, 2-4 us per workgroup when spread out), then sort together
@@ -1566,7 +1593,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
   float Tmin = 1.f;                             // smallest transmittance that passed the test in this wave's segments
   f2 al[kFS / 2];                               // alphas of this wave's segment of the batch about to be accumulated
   uint32_t last = 0, consumed = 0;
-  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
   unsigned long long tm0 = 0, tm1 = 0, rt0 = 0;
   if (dbg) { tm0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
   const int e0 = wave * kFS;
@@ -1673,6 +1700,8 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
     o[0] = tm0; o[1] = ((unsigned long long)hw << 32) | (unsigned)(tm1 - tm0); o[2] = __builtin_readcyclecounter();
     o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
   }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)  // every taker of key-pool pages (binning, sort) has finished: leave the
+    *p.page_counter = (unsigned long long)p.call_tag << 32;     // counter at zero for a replay of this very call (HIP graph: same tag)
   if (wave == 0) {
     if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
     if (inside) {
@@ -1746,7 +1775,16 @@ __device__ __forceinline__ float oct_allreduce(float v) {
   return v;
 }
 
-template <bool kExtra>
+// Fixed-point form of a gradient contribution (GSR_FLAG_DETERMINISTIC): 2^-32 resolution, clamped to +-2^30 so that the
+// 64-bit sum of any realistic number of contributions cannot wrap.  Integer adds commute: the sum does not depend on order.
+constexpr float kFixScale = 4294967296.f, kFixInv = 1.f / 4294967296.f;
+__device__ __forceinline__ unsigned long long to_fixed(float v) {
+  v = fminf(fmaxf(v, -1073741824.f), 1073741824.f);
+  return (unsigned long long)(long long)__float2ll_rn(v * kFixScale);
+}
+__device__ __forceinline__ float from_fixed(long long x) { return (float)x * kFixInv; }
+
+template <bool kExtra, bool kDet>
 __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   __shared__ __attribute__((aligned(16))) float sW[kBwdWaves][kBS][64];  // A -> R, per wave: blend weight w
   __shared__ __attribute__((aligned(16))) float sQ[kBwdWaves][kBS][64];  // A -> R, per wave: G dL/dalpha
@@ -1902,9 +1940,16 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     float val = v0;
     val = pr == 1 ? v1 : val; val = pr == 2 ? mh * Sxx : val; val = pr == 3 ? mh * Sxy : val; val = pr == 4 ? mh * Syy : val;
     val = pr == 5 ? S0 : val; val = pr == 6 ? v6 : val; val = pr == 7 ? v7 : val;
-    float* dst = scratch + (size_t)__float_as_uint(a2.z) * GSR_SCREEN_GRAD_FLOATS;
-    unsafeAtomicAdd(dst + pr, val);
-    if (pr < (kExtra ? 2 : 1)) unsafeAtomicAdd(dst + 8 + pr, pr == 0 ? v8 : v9);
+    if (kDet) {
+      unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) +
+                                ((size_t)v * p.d.num_gaussians + __float_as_uint(a2.z)) * GSR_SCREEN_GRAD_FLOATS;
+      atomicAdd(dst + pr, to_fixed(val));
+      if (pr < (kExtra ? 2 : 1)) atomicAdd(dst + 8 + pr, to_fixed(pr == 0 ? v8 : v9));
+    } else {
+      float* dst = scratch + (size_t)__float_as_uint(a2.z) * GSR_SCREEN_GRAD_FLOATS;
+      unsafeAtomicAdd(dst + pr, val);
+      if (pr < (kExtra ? 2 : 1)) unsafeAtomicAdd(dst + 8 + pr, pr == 0 ? v8 : v9);
+    }
   };
 
   // ---- prologue: waves 0 / 1 stage iterations 0 / 1, wave 2 fetches the list ids of iteration 2; everyone evaluates 0
@@ -1968,12 +2013,20 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   // private to their lane, so no barrier is needed in between) before the cooperative store.  Half the LDS of an
   // in + out pair => twice the resident waves for this latency-bound kernel.
   float* sh_in = lds;
-  const bool dbg = (p.d.flags & GSR_FLAG_DEBUG_TIMING) != 0 && p.dL_dmeans2D != nullptr;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && p.dL_dmeans2D != nullptr;
   unsigned long long stamps[5] = {0, 0, 0, 0, 0};
   if (dbg) stamps[0] = __builtin_amdgcn_s_memrealtime();
   // this lane's own inputs are requested before the (long) SH staging so that one memory latency covers both
   float rmx = 0, rmy = 0, rmz = 0, rcov[6] = {0, 0, 0, 0, 0, 0};
+  const bool det = (p.d.flags & GSR_FLAG_DETERMINISTIC) != 0;
   auto load_row = [&](int vv, float (&sg)[12]) {  // screen-space gradient row of (view, Gaussian): 48 B, three 16-byte loads
+    if (det) {  // 12 fixed-point sums of 8 bytes
+      const longlong2* s = reinterpret_cast<const longlong2*>(reinterpret_cast<const long long*>(p.scratch) +
+                                                              ((size_t)(set * Vs + vv) * N + i) * GSR_SCREEN_GRAD_FLOATS);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const longlong2 x = s[k]; sg[2 * k] = from_fixed(x.x); sg[2 * k + 1] = from_fixed(x.y); }
+      return;
+    }
     const float4* s = reinterpret_cast<const float4*>(p.scratch + ((size_t)(set * Vs + vv) * N + i) * GSR_SCREEN_GRAD_FLOATS);
     const float4 s0 = s[0], s1 = s[1], s2 = s[2];
     sg[0] = s0.x; sg[1] = s0.y; sg[2] = s0.z; sg[3] = s0.w; sg[4] = s1.x; sg[5] = s1.y; sg[6] = s1.z; sg[7] = s1.w;
@@ -2153,8 +2206,14 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const int v = set * Vs + vv;
       const GsrView& cam = p.views[v];
       const size_t oi = (size_t)v * N + i;
-      const float* sgp = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
-      const float c0 = sgp[6], c1 = sgp[7], c2 = sgp[8];
+      float c0, c1, c2;
+      if (det) {
+        const long long* sgi = reinterpret_cast<const long long*>(p.scratch) + oi * GSR_SCREEN_GRAD_FLOATS;
+        c0 = from_fixed(sgi[6]); c1 = from_fixed(sgi[7]); c2 = from_fixed(sgi[8]);
+      } else {
+        const float* sgp = p.scratch + oi * GSR_SCREEN_GRAD_FLOATS;
+        c0 = sgp[6]; c1 = sgp[7]; c2 = sgp[8];
+      }
       if (c0 == 0.f && c1 == 0.f && c2 == 0.f) continue;
       const uint32_t cl = __float_as_uint(p.rgbc[oi].w);
       const float d0 = (cl & 1u) ? 0.f : c0, d1 = (cl & 2u) ? 0.f : c1, d2 = (cl & 4u) ? 0.f : c2;
@@ -2286,6 +2345,13 @@ static bool dims_ok(const GsrDims* d) {
   if (d->height <= 0 || d->width <= 0 || d->height > 32768 || d->width > 32768) return false;
   if (d->sh_coeffs < 0 || d->sh_coeffs > 25 || d->sh_degree < 0 || d->sh_degree > 4) return false;
   if (d->num_views > 65535 || d->pair_capacity < 0 || d->pair_capacity > 0xfffffff0ll) return false;
+  {
+    int valid = GSR_FLAG_VALID_MASK;
+#ifdef GSR_ABLATE
+    valid |= GSR_FLAG_ABLATE_MASK;
+#endif
+    if ((d->flags & ~valid) != 0 || ((d->flags >> 4) & 7) > GSR_EXTRA_LOG) return false;
+  }
   const Grid g = make_grid(d->width, d->height);
   if ((int64_t)d->num_views * g.T > 0x7fffffffll) return false;
   const Layout L = make_layout(*d);  // key offsets are 32-bit: slots + page pool must stay below 2^32 keys
@@ -2341,6 +2407,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
 using namespace gsr;
 
 static hipEvent_t* g_bwd_events = nullptr;
+static thread_local int g_failed_stage = -1;  // debug mode: stage whose check failed (gsr_last_failed_stage)
 
 // ------------------------------------------------------------------------------------------------
 // Covariance from scale + rotation ([EXT] forward.cu computeCov3D, backward.cu computeCov3D; oracle cov3d_from_scale_rot and the
@@ -2405,36 +2472,20 @@ __global__ __launch_bounds__(256) void k_cov_from_scale_rot_bwd(long long n, con
   }
 }
 
-// Per host thread: one non-blocking side stream and a fork/join event pair (created on first use, kept for the life of
-// the thread - the only persistent state the library holds).  Event records are ordered by the calling stream, so the
-// pair can be reused call after call, and the fork/join pattern is capturable into a HIP graph.
-struct SideStream {
-  hipStream_t stream = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
-};
-static SideStream* side_stream() {
-  static thread_local SideStream s;
-  static thread_local int dev = -1;
-  int cur = 0;
-  if (hipGetDevice(&cur) != hipSuccess) return nullptr;
-  if (!s.ok || dev != cur) {
-    if (s.ok) { (void)hipStreamDestroy(s.stream); (void)hipEventDestroy(s.fork); (void)hipEventDestroy(s.join); s.ok = false; }
-    if (hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.fork, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&s.join, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return nullptr;
-    s.ok = true;
-    dev = cur;
-  }
-  return &s;
-}
-
 extern "C" {
 
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 const char* gsr_build_info(void) {
-  return "gsr_hip gfx950 wave64 tile8x8 fused-binning segment-blend abi1";
+  return "gsr_hip gfx950 wave64 tile8x8 fused-binning sort+colour segment-blend single-stream abi1";
+}
+
+int gsr_last_failed_stage(void) { return g_failed_stage; }
+
+size_t gsr_backward_scratch_bytes(const GsrDims* dims) {
+  if (!dims_ok(dims)) return 0;
+  const size_t rows = (size_t)dims->num_views * (size_t)dims->num_gaussians;
+  return rows * GSR_SCREEN_GRAD_FLOATS * ((dims->flags & GSR_FLAG_DETERMINISTIC) ? sizeof(long long) : sizeof(float));
 }
 
 int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_bytes, size_t* img_bytes) {
@@ -2489,30 +2540,34 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   if (!means || !cov6 || !opacities || !colors || !radii || !geom) return GSR_ERR_INVALID_ARGUMENT;
   const size_t VT = V * (size_t)p.g.T;
   int e = 0;
+  // debug (flags bit 1, upstream's `debug`): synchronise and check after every stage, report the stage that failed
+#define GSR_STAGE_DONE(idx)                                                            \
+  do {                                                                                  \
+    if (d.flags & GSR_FLAG_DEBUG) {                                                     \
+      if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {  \
+        g_failed_stage = (idx);                                                         \
+        return GSR_ERR_LAUNCH;                                                          \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
 #define GSR_MARK() do { if (ev) GSR_CHECK(hipEventRecord(ev[e++], st)); } while (0)
-  const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
-  const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
-  const bool do_color = !(d.flags & GSR_FLAG_ABLATE_NO_SH);
-  const dim3 cgrid((unsigned)((N + 63) / 64), (unsigned)d.num_sets);
-  // Fork: the colour kernel (HBM-bound, 85 % of the input bytes) runs on a side stream while this stream goes through
-  // geometry -> binning -> sort; joined before the blend.  In profile mode (ev != null) everything stays on one
-  // stream so each stage is timed alone.
-  SideStream* ss = ev ? nullptr : side_stream();
+  const bool do_color = !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH);
+  p.color_units = (uint32_t)((N + 63) / 64);
+  const unsigned color_blocks = do_color ? p.color_units * (unsigned)d.num_sets : 0u;
+  // One stream, three launches: binning -> per-tile sorts + the colour pass riding in the same grid -> blend.  In profile
+  // mode (ev != null) the colour pass gets a launch of its own so that each stage is timed alone; it goes FIRST (it streams
+  // 90 MB through the caches; between binning and sort it would evict the keys the sort gathers).  gsr_forward_profile
+  // swaps the two durations back into stage order.
   GSR_MARK();
-  // profile mode: the colour kernel goes FIRST (it streams 90 MB through the caches; between binning and sort it would
-  // evict the keys the sort gathers, which the concurrent eager order does not do).  gsr_forward_profile swaps the two
-  // durations back into stage order.
-  if (do_color && !ss) hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, st, p);
-  if (ev) GSR_MARK();
-  if (do_color && ss) {
-    GSR_CHECK(hipEventRecord(ss->fork, st));
-    GSR_CHECK(hipStreamWaitEvent(ss->stream, ss->fork, 0));
-    hipLaunchKernelGGL(k_color, cgrid, dim3(64), shmem, ss->stream, p);
-    GSR_CHECK(hipEventRecord(ss->join, ss->stream));
+  if (ev && color_blocks) {
+    Params pc = p;
+    pc.sort_blocks = 0;
+    hipLaunchKernelGGL((k_sort_tiles<true, 2048>), dim3(color_blocks), dim3(kSortThreads), 0, st, pc);
   }
+  if (ev) GSR_MARK();
   // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin + gathering sort: 2 launches);
   // larger ones the windowed path (preprocess, count, prefix, scan, emit, sort: 5-6 launches).
-  const bool fused_bin = p.g.T <= kTileWindow && !(d.flags & (GSR_FLAG_ABLATE_NO_COUNT | GSR_FLAG_WINDOWED_BINNING));
+  const bool fused_bin = p.g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   if (fused_bin) {
     static std::atomic<unsigned long long> lds_set{0ull};  // per device: > 64 KB of dynamic LDS has to be asked for
     int dev = 0;
@@ -2527,6 +2582,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   } else {
     hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   }
+  GSR_STAGE_DONE(0);
   GSR_MARK();
   if (!fused_bin) {
     hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
@@ -2534,25 +2590,30 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   }
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
   if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
+  GSR_STAGE_DONE(1);
   GSR_MARK();
   if (!fused_bin) {
     if (scan_in_emit) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
     else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   }
+  GSR_STAGE_DONE(2);
   GSR_MARK();
+  p.sort_blocks = (uint32_t)VT;
+  const dim3 sgrid((unsigned)VT + (ev ? 0u : color_blocks));
   if (fused_bin) {
     // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
-    if (p.stride <= 2048u) hipLaunchKernelGGL((k_sort_tiles<true, 2048>), dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
-    else hipLaunchKernelGGL((k_sort_tiles<true, 4096>), dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+    if (p.stride <= 2048u) hipLaunchKernelGGL((k_sort_tiles<true, 2048>), sgrid, dim3(kSortThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_sort_tiles<true, 4096>), sgrid, dim3(kSortThreads), 0, st, p);
   } else {
-    hipLaunchKernelGGL((k_sort_tiles<false, 4096>), dim3((unsigned)VT), dim3(kSortThreads), 0, st, p);
+    hipLaunchKernelGGL((k_sort_tiles<false, 4096>), sgrid, dim3(kSortThreads), 0, st, p);
   }
+  GSR_STAGE_DONE(3);
   GSR_MARK();
-  // join: the colour kernel (~22 us alone at 300k x 25 coefficients) has had the whole binning chain to finish
-  if (do_color && ss) GSR_CHECK(hipStreamWaitEvent(st, ss->join, 0));
   if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
   else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
+  GSR_STAGE_DONE(4);
   GSR_MARK();
+#undef GSR_STAGE_DONE
 #undef GSR_MARK
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
@@ -2612,14 +2673,33 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   p.dL_dextra = d.has_extra ? dL_dextra : nullptr; p.dL_dmeans2D = dL_dmeans2D;
   hipEvent_t* ev = g_bwd_events;
   int e = 0;
+#define GSR_STAGE_DONE(idx)                                                            \
+  do {                                                                                  \
+    if (d.flags & GSR_FLAG_DEBUG) {                                                     \
+      if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess) {  \
+        g_failed_stage = (idx);                                                         \
+        return GSR_ERR_LAUNCH;                                                          \
+      }                                                                                 \
+    }                                                                                   \
+  } while (0)
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
-  GSR_CHECK(hipMemsetAsync(scratch, 0, V * N * GSR_SCREEN_GRAD_FLOATS * sizeof(float), st));
-  if (p.dL_dextra_img) hipLaunchKernelGGL(k_blend_bwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
-  else hipLaunchKernelGGL(k_blend_bwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kBwdThreads), 0, st, p);
+  const bool det = (d.flags & GSR_FLAG_DETERMINISTIC) != 0;
+  GSR_CHECK(hipMemsetAsync(scratch, 0, gsr_backward_scratch_bytes(dims), st));
+  const dim3 bgrid((unsigned)p.g.T, (unsigned)V);
+  if (p.dL_dextra_img) {
+    if (det) hipLaunchKernelGGL((k_blend_bwd<true, true>), bgrid, dim3(kBwdThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_blend_bwd<true, false>), bgrid, dim3(kBwdThreads), 0, st, p);
+  } else {
+    if (det) hipLaunchKernelGGL((k_blend_bwd<false, true>), bgrid, dim3(kBwdThreads), 0, st, p);
+    else hipLaunchKernelGGL((k_blend_bwd<false, false>), bgrid, dim3(kBwdThreads), 0, st, p);
+  }
+  GSR_STAGE_DONE(0);
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
   hipLaunchKernelGGL(k_preprocess_bwd, dim3((unsigned)((N + 63) / 64), (unsigned)d.num_sets), dim3(64), shmem, st, p);
+  GSR_STAGE_DONE(1);
+#undef GSR_STAGE_DONE
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipGetLastError());
   return GSR_OK;

@@ -97,11 +97,21 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.load()
-        self.capacity_hint = {}  # (V, N, H, W) -> pair_capacity that suits what was seen last time (headroom included)
-        self.sync_policy = "lazy"  # or "sync": see forward()
+        self.capacity_hint = {}  # (V, N, H, W) -> largest pair_capacity any call of that shape has needed (headroom included)
+        self.sync_policy = "sync"  # or "lazy" (opt-in, inference / benchmarks): see forward()
         self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
-        self.pending = []  # (pinned status copy, event, shape key) of lazy forwards not yet verified
+        self.pending = []  # (pinned status copy, event, shape key, cfg, workspace id) of lazy forwards not yet verified
         self.last_status = None
+
+    def _rc(self, rc: int, what: str, stages=None):
+        if rc == 0:
+            return
+        msg = f"{what} failed with code {rc}"
+        if rc == -2:  # GSR_ERR_LAUNCH
+            st = self.lib.gsr_last_failed_stage()
+            if stages is not None and 0 <= st < len(stages):
+                msg += f" (debug mode: stage '{stages[st]}' did not complete)"
+        raise RuntimeError(msg)
 
     @staticmethod
     def _dims(cfg: RasterConfig, capacity: int) -> _lib.GsrDims:
@@ -120,7 +130,8 @@ class HipBackend:
         n = scales.shape[0]
         out = torch.empty((n, 6), dtype=torch.float32, device=scales.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
-        rc = self.lib.gsr_cov_from_scale_rot(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(out), stream)
+        with torch.cuda.device(scales.device):
+            rc = self.lib.gsr_cov_from_scale_rot(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(out), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_cov_from_scale_rot failed with code {rc}")
         return out
@@ -129,8 +140,9 @@ class HipBackend:
         n = scales.shape[0]
         d_s, d_r = torch.empty_like(scales), torch.empty_like(rotations)
         stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
-        rc = self.lib.gsr_cov_from_scale_rot_backward(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(d_cov6),
-                                                      _ptr(d_s), _ptr(d_r), stream)
+        with torch.cuda.device(scales.device):
+            rc = self.lib.gsr_cov_from_scale_rot_backward(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(d_cov6),
+                                                          _ptr(d_s), _ptr(d_r), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_cov_from_scale_rot_backward failed with code {rc}")
         return d_s, d_r
@@ -187,7 +199,7 @@ class HipBackend:
                 else:
                     colors_shape = (s, n, 3)
             plan.update(
-                scratch=torch.empty(max(1, v * n * _lib.SCREEN_GRAD_FLOATS), dtype=f32, device=device),
+                scratch=torch.empty(max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=u8, device=device),
                 d_means=torch.empty((s, n, 3), dtype=f32, device=device),
                 d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=device),
                 d_opac=torch.empty((s, n), dtype=f32, device=device),
@@ -208,14 +220,14 @@ class HipBackend:
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
                 _ptr(color), _ptr(plan["extra_img"]), _ptr(plan["radii"]), _ptr(plan["geom"]), _ptr(plan["bin"]),
                 _ptr(plan["img"]), stream)
-        if profile:
-            ms = (ctypes.c_float * len(_lib.FWD_STAGES))()
-            rc = self.lib.gsr_forward_profile(*args, ms)
-        else:
-            ms = None
-            rc = self.lib.gsr_forward(*args)
-        if rc != 0:
-            raise RuntimeError(f"gsr_forward failed with code {rc}")
+        with torch.cuda.device(plan["device"]):  # kernels launch on the process's current device: make it the tensors' device
+            if profile:
+                ms = (ctypes.c_float * len(_lib.FWD_STAGES))()
+                rc = self.lib.gsr_forward_profile(*args, ms)
+            else:
+                ms = None
+                rc = self.lib.gsr_forward(*args)
+        self._rc(rc, "gsr_forward", _lib.FWD_DEBUG_STAGES)
         return None if ms is None else dict(zip(_lib.FWD_STAGES, [float(x) for x in ms]))
 
     def run_backward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img=None,
@@ -227,14 +239,14 @@ class HipBackend:
                 _ptr(g_extra_img if cfg.has_extra else None), _ptr(plan["scratch"]), _ptr(plan["d_means"]),
                 _ptr(plan["d_cov6"]), _ptr(plan["d_opac"]), _ptr(plan["d_colors"]), _ptr(plan["d_extra"]),
                 _ptr(plan["d_means2d"] if want_means2d else None), stream)
-        if profile:
-            ms = (ctypes.c_float * len(_lib.BWD_STAGES))()
-            rc = self.lib.gsr_backward_profile(*args, ms)
-        else:
-            ms = None
-            rc = self.lib.gsr_backward(*args)
-        if rc != 0:
-            raise RuntimeError(f"gsr_backward failed with code {rc}")
+        with torch.cuda.device(plan["device"]):
+            if profile:
+                ms = (ctypes.c_float * len(_lib.BWD_STAGES))()
+                rc = self.lib.gsr_backward_profile(*args, ms)
+            else:
+                ms = None
+                rc = self.lib.gsr_backward(*args)
+        self._rc(rc, "gsr_backward", _lib.BWD_STAGES)
         return None if ms is None else dict(zip(_lib.BWD_STAGES, [float(x) for x in ms]))
 
     @staticmethod
@@ -247,11 +259,13 @@ class HipBackend:
     # ---- autograd-facing calls: fresh outputs/workspaces per call, kept alive for backward
     def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None):
         """Pair-count policy (`self.sync_policy`):
-        "sync"  - read the 16-byte status block back after every call (one host sync, as the reference extension does) and
-                  retry with the exact size on overflow;
-        "lazy"  - (default) do that only the first time a (views, N, H, W) shape is seen; afterwards size the workspace at
-                  1.25x the last known pair count, copy the status block asynchronously and verify it at the next call
-                  (or `check_pending()`).  A workspace that turns out too small poisons that call's image with NaN
+        "sync"  - (default) read the 16-byte status block back after every call (one host sync, as the reference extension
+                  does with its num_rendered) and retry with the exact size on overflow: a jump in the pair count from one
+                  scene to the next costs one retry, never a wrong image;
+        "lazy"  - opt-in (inference loops, benchmarks): do that only the first time a (views, N, H, W) shape is seen;
+                  afterwards size the workspace at 1.25x the largest pair count seen, copy the status block asynchronously
+                  and verify it at the next call, at `check_pending()`, and - for a call that is differentiated - at the
+                  start of its backward.  A workspace that turns out too small poisons that call's image with NaN
                   (k_blend_fwd) and raises at verification - it cannot pass silently."""
         self._check_device(viewbuf, means, cov6, opac, colors, extra)
         self.check_pending()
@@ -272,34 +286,50 @@ class HipBackend:
                 host.copy_(plan["bin"][:16], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream(dev))
-                self.pending.append((host, ev, key, cfg))
+                self.pending.append((host, ev, key, cfg, plan["bin"].data_ptr()))
                 return out
             self.last_status = st = self.read_status(plan)
-            self.capacity_hint[key] = self.capacity_for(cfg, st)
+            self._raise_hint(key, self.capacity_for(cfg, st))
             if not st["overflow"]:
                 return out
             cap = self.capacity_for(cfg, st, headroom=1.05)
         raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
 
-    def check_pending(self, wait: bool = False):
-        """Verify the status blocks of earlier lazy/deferred forwards (those whose async copy has landed; all if `wait`)."""
-        keep = []
-        for host, ev, key, cfg in self.pending:
-            if wait:
+    def _raise_hint(self, key, need: int):
+        self.capacity_hint[key] = max(int(need), int(self.capacity_hint.get(key, 0)))  # a running maximum: it never shrinks
+
+    def check_pending(self, wait: bool = False, only_ws: Optional[int] = None):
+        """Verify the status blocks of earlier lazy/deferred forwards (those whose async copy has landed; all if `wait`;
+        `only_ws`: just the forward that owns that workspace, waiting for it)."""
+        keep, failed = [], None
+        for item in self.pending:
+            host, ev, key, cfg, ws = item
+            mine = only_ws is not None and ws == only_ws
+            if only_ws is not None and not mine:
+                keep.append(item)
+                continue
+            if wait or mine:
                 ev.synchronize()
             elif not ev.query():
-                keep.append((host, ev, key, cfg))
+                keep.append(item)
                 continue
             num_pairs = int(host[:8].view(torch.int64).item())
             overflow = int(host[8:12].view(torch.int32).item())
             self.last_status = {"num_pairs": num_pairs, "overflow": overflow, "max_list": int(host[12:16].view(torch.int32).item())}
-            self.capacity_hint[key] = self.capacity_for(cfg, self.last_status)
-            if overflow:
-                self.pending = [p for p in self.pending if p[0] is not host]
-                raise RuntimeError(
-                    f"an earlier gsr_forward needed {num_pairs} pairs but its workspace was smaller; that call's image was "
-                    "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync').")
+            self._raise_hint(key, self.capacity_for(cfg, self.last_status))
+            if overflow and failed is None:
+                failed = num_pairs
         self.pending = keep
+        if failed is not None:
+            raise RuntimeError(
+                f"an earlier gsr_forward needed {failed} pairs but its workspace was smaller; that call's image was "
+                "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync').")
+
+    def _verify_own_forward(self, binb):
+        """Backward of a lazily sized forward: its status must be known to be good before gradients are computed from
+        its workspace (an overflowed forward binned nothing)."""
+        if self.pending:
+            self.check_pending(only_ws=binb.data_ptr())
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
                  want_means2d: bool):
@@ -307,8 +337,9 @@ class HipBackend:
         dev = viewbuf.device
         v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         f32 = torch.float32
+        self._verify_own_forward(binb)
         plan = dict(cfg=cfg, dims=dims, device=dev, geom=geom, bin=binb, img=img,
-                    scratch=torch.empty(max(1, v * n * _lib.SCREEN_GRAD_FLOATS), dtype=f32, device=dev),
+                    scratch=torch.empty(max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=torch.uint8, device=dev),
                     d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
                     d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=dev),
                     d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
@@ -331,8 +362,9 @@ class HipBackend:
         nr, fr, bg = near.to(f32).contiguous(), far.to(f32).contiguous(), background.to(f32).contiguous()
         out = torch.empty((v, VIEW_FLOATS), dtype=f32, device=ext.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(ext.device).cuda_stream)
-        rc = self.lib.gsr_setup_views(v, _ptr(ext), _ptr(intr), _ptr(nr), _ptr(fr), _ptr(bg), 3 if bg.dim() == 2 else 0,
-                                      int(bool(scale_invariant)), _ptr(out), stream)
+        with torch.cuda.device(ext.device):
+            rc = self.lib.gsr_setup_views(v, _ptr(ext), _ptr(intr), _ptr(nr), _ptr(fr), _ptr(bg), 3 if bg.dim() == 2 else 0,
+                                          int(bool(scale_invariant)), _ptr(out), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_setup_views failed with code {rc}")
         return out
@@ -342,7 +374,8 @@ class HipBackend:
         present = torch.empty((cfg.num_sets, cfg.num_gaussians), dtype=torch.uint8, device=means.device)
         dims = self._dims(cfg, 0)
         stream = ctypes.c_void_p(torch.cuda.current_stream(means.device).cuda_stream)
-        rc = self.lib.gsr_mark_visible(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(present), stream)
+        with torch.cuda.device(means.device):
+            rc = self.lib.gsr_mark_visible(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(present), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_mark_visible failed with code {rc}")
         return present.bool()
@@ -402,14 +435,16 @@ class _RasterizeViews(torch.autograd.Function):
             g_color = torch.zeros((cfg.num_views, 3, cfg.height, cfg.width), dtype=torch.float32, device=means.device)
         d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
             cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d)
-        ctx.saved_ws = None
+        # the workspaces stay with ctx (freed with the graph): a second backward (retain_graph=True, several autograd.grad
+        # calls over one render) runs on them again, as upstream's Function can
         return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, None, None
 
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
                     image_shape, sh_degree: int, use_sh: bool, views_per_set: int, extra: Optional[Tensor] = None,
                     means2d: Optional[Tensor] = None, max_sh_eval: int = 4, sh_planar: bool = False, cov_3x3: bool = False,
-                    extra_mode: Optional[str] = None):
+                    extra_mode: Optional[str] = None, debug: bool = False, prefiltered: bool = False,
+                    deterministic: Optional[bool] = None):
     """Render V = num_sets * views_per_set views in one launch chain.
 
     means (S,N,3); cov6 (S,N,6) or, with cov_3x3, the full symmetric (S,N,3,3); opacities (S,N); colors (S,N,M,3) or, with
@@ -419,6 +454,9 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     Returns (color (V,3,H,W), extra_img (V,H,W) | None, radii (V,N) int32).  Differentiable w.r.t. means, cov6, opacities,
     colors, extra (gradients come back in the layouts given; means2d receives the screen-space gradient); cameras get none,
     like the reference operator.
+    debug: upstream's `settings.debug` - the library synchronises and checks for errors after every stage and names the
+    stage that failed.  deterministic: the backward accumulates per-Gaussian gradients in 64-bit fixed point (bit-identical
+    from run to run); None = follow `torch.are_deterministic_algorithms_enabled()`.
     """
     s, n = means.shape[0], means.shape[1]
     v = viewbuf.shape[0]
@@ -438,6 +476,10 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
         raise ValueError(f"covariances have shape {tuple(cov6.shape)}; expected (sets, N, {'3, 3' if cov_3x3 else '6'})")
     m = (colors.shape[3] if sh_planar else colors.shape[2]) if use_sh else 0
     flags = (_lib.FLAG_SH_PLANAR if (sh_planar and use_sh) else 0) | (_lib.FLAG_COV_3X3 if cov_3x3 else 0)
+    if deterministic is None:
+        deterministic = torch.are_deterministic_algorithms_enabled()
+    flags |= (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_PREFILTERED if prefiltered else 0)
+    flags |= _lib.FLAG_DETERMINISTIC if deterministic else 0
     if extra_mode is not None:
         if extra is not None:
             raise ValueError("give either `extra` or `extra_mode`")
@@ -529,5 +571,5 @@ class GaussianRasterizer(nn.Module):
             means3D[None], cov3D_precomp.reshape(n, 6)[None], opacities.reshape(n)[None], colors[None],
             self._viewbuf(means3D.device), image_shape=(int(rs.image_height), int(rs.image_width)),
             sh_degree=int(rs.sh_degree), use_sh=use_sh, views_per_set=1,
-            means2d=means2D[None] if means2D is not None else None)
+            means2d=means2D[None] if means2D is not None else None, debug=bool(rs.debug), prefiltered=bool(rs.prefiltered))
         return color[0], radii[0]

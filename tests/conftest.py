@@ -29,3 +29,29 @@ def oracle_backend():
     old = rasterizer.set_backend(be)
     yield be
     rasterizer.set_backend(old)
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The give in the parity tolerance, made visible: per test, the pixels beyond 1e-4, the threshold flips and the gradient
+    rows set aside (tests/parity_checks.py REPORT).  Also written to gpurun_out/parity_counts.json."""
+    import json
+
+    from tests import parity_checks
+
+    rep = parity_checks.REPORT
+    if not rep:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "parity counts (pixels > 1e-4 | final-T flips | gradient rows set aside | worst rel-L2 over ALL rows)")
+    for test, row in rep.items():
+        aside = sum(v for k, v in row.items() if k.endswith("_set_aside"))
+        tr.write_line(f"{test.split('::')[-1][:70]:70s} outlier_px {row.get('outlier_pixels_1e-4', 0):5d}  T_flips {row.get('final_T_flipped_pixels', 0):5d}  "
+                      f"flipped_px {row.get('flipped_pixels', 0):5d}  set_aside {aside:5d}  img {row.get('color_rel_l2_all', 0.0):.2e}  "
+                      f"grad {row.get('grad_rel_l2_all_max', 0.0):.2e}")
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_counts.json"), "w") as f:
+            json.dump(rep, f, indent=1)
+    except OSError:
+        pass

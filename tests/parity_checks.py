@@ -8,6 +8,35 @@ from tests.util import psnr, rel_l2
 
 TOL = 1e-4  # north_star: "within 1e-4 relative fp32"
 
+# Audit trail of the give in the tolerance: every check_image / check_image_state / check_grads call files its counts
+# (pixels whose colour differs by more than 1e-4, pixels whose threshold decision fell the other way, gradient rows set
+# aside) under the running test's id.  tests/conftest.py prints the table at the end of the pytest run and writes it to
+# gpurun_out/parity_counts.json; __graft_entry__.smoke() prints that file.
+REPORT = {}
+_COUNT_KEYS = ("outlier_pixels_1e-4", "final_T_flipped_pixels", "final_T_outliers_1e-4", "flipped_pixels")
+
+
+def _file_counts(kind, m):
+    import os
+
+    test = os.environ.get("PYTEST_CURRENT_TEST", "direct").split(" ")[0]
+    row = REPORT.setdefault(test, {})
+    for k, v in m.items():
+        if k in _COUNT_KEYS or k.endswith("_set_aside"):
+            row[k] = row.get(k, 0) + int(v)
+    for k in ("color_rel_l2_all", "extra_rel_l2_all"):
+        if k in m:
+            row[k] = max(row.get(k, 0.0), float(m[k]))
+    worst = max([float(v) for k, v in m.items() if k.endswith("_rel_l2_all") and kind == "grads"] or [0.0])
+    if kind == "grads":
+        row["grad_rel_l2_all_max"] = max(row.get("grad_rel_l2_all_max", 0.0), worst)
+
+
+def assert_nothing_set_aside(m):
+    """Strict form used by the BASELINE-config tests: the tolerance is met by ALL rows (no gradient row was set aside)."""
+    aside = {k: v for k, v in m.items() if k.endswith("_set_aside")}
+    assert not aside, (aside, m)
+
 
 def check_preprocess(res, cfg, v=0):
     """Projected records vs oracle geometry for view v."""
@@ -120,6 +149,7 @@ def check_image(res, cfg, tol=TOL):
         assert m["extra_rel_l2"] < tol, m
     npx = hc.shape[0] * hc.shape[2] * hc.shape[3]
     assert m["outlier_pixels_1e-4"] <= max(4, int(2e-3 * npx)), m
+    _file_counts("image", m)
     return m
 
 
@@ -143,6 +173,7 @@ def check_image_state(res, cfg, v=0):
     assert m["final_T_outliers_1e-4"] <= max(4, int(2e-3 * d.size)), m
     # pixels that end at the stop threshold (T ~ 1e-4) flip easily: one entry earlier or later; bound the others
     assert int((flipped & (ot >= 1e-3)).sum()) <= max(4, int(2e-3 * d.size)), m
+    _file_counts("state", m)
     return m
 
 
@@ -190,4 +221,5 @@ def check_grads(res, cfg, tol=TOL):
     for k, val in list(m.items()):
         if k.endswith("_rel_l2") and m[k.replace("_rel_l2", "_norm")] > 0:
             assert val < tol, (k, m)
+    _file_counts("grads", m)
     return m

@@ -55,6 +55,28 @@ def test_workspace_sizes_and_validation():
     assert lib.gsr_backward(ctypes.byref(bad), *([None] * 19)) == -1
 
 
+def test_flag_bits_are_validated_and_ablation_switches_are_not_in_the_product_library():
+    """Unknown GsrDims.flags bits are rejected; the measurement-only ablation / phase-stamp switches (0x100 .. 0x2000, only in
+    a -DGSR_ABLATE build made by tools/ablate.py) are unknown bits to the shipped library; extra modes above 4 do not exist."""
+    lib = _lib.load()
+    be = rasterizer.HipBackend()
+    z = ctypes.c_size_t()
+    sizes = lambda d: lib.gsr_workspace_sizes(ctypes.byref(d), ctypes.byref(z), ctypes.byref(z), ctypes.byref(z))
+    ok = _lib.FLAG_PREFILTERED | _lib.FLAG_DEBUG | _lib.FLAG_SH_PLANAR | _lib.FLAG_COV_3X3 | _lib.FLAG_DETERMINISTIC | (4 << 4)
+    assert sizes(be._dims(rasterizer.RasterConfig(1, 1, 1, 100, 16, 16, 4, 25, 4, True, ok), 1000)) == 0
+    for bad in (0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x8000, 0x10000, 1 << 30, 5 << 4, 7 << 4):
+        assert sizes(be._dims(rasterizer.RasterConfig(1, 1, 1, 100, 16, 16, 4, 25, 4, True, bad), 1000)) == -1, hex(bad)
+    hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    product, _, _ = hdr.partition("#ifdef GSR_ABLATE")
+    assert "GSR_FLAG_ABLATE" not in product and "GSR_FLAG_DEBUG_TIMING" not in product
+    # scratch sizing of the backward: 12 floats per (view, Gaussian); 12 x 8 bytes in deterministic mode
+    d = be._dims(rasterizer.RasterConfig(2, 1, 2, 100, 16, 16, 4, 25, 4, False), 1000)
+    assert lib.gsr_backward_scratch_bytes(ctypes.byref(d)) == 2 * 100 * 12 * 4
+    d = be._dims(rasterizer.RasterConfig(2, 1, 2, 100, 16, 16, 4, 25, 4, False, _lib.FLAG_DETERMINISTIC), 1000)
+    assert lib.gsr_backward_scratch_bytes(ctypes.byref(d)) == 2 * 100 * 12 * 8
+    assert lib.gsr_last_failed_stage() == -1
+
+
 def test_no_cpu_fallback_path():
     """The product path must fail loudly off-device (there is no CPU fallback and it never reaches for the oracle)."""
     import pf3plat_amd

@@ -132,6 +132,61 @@ def test_decoder_forward_fused_colour_and_depth_config4_shape():
     assert rel_l2(d2.cpu().numpy(), gd) < 1e-5
 
 
+def test_decoder_forward_config4_full_size_colour_and_depth_fwd_bwd():
+    """BASELINE configs[3] as the reference runs it: `DecoderSplattingCUDA.forward` on B = 1, G = 131 072, K = 25, V = 3 target
+    views, 256 x 256, colour + depth, forward and backward, against the same decoder code driven by the oracle on CPU
+    (reference src/model/decoder/decoder_splatting_cuda.py:35-67).  Bounds hold over ALL elements (nothing set aside)."""
+    sc = synthetic.make_scene(50, 131072, (256, 256), num_views=3)
+    dec_gpu = pf3plat_amd.DecoderSplattingCUDA().to(DEV)
+    dec_cpu = pf3plat_amd.DecoderSplattingCUDA()
+    w = torch.rand((1, 3, 3, 256, 256), generator=torch.Generator().manual_seed(2))
+    wd = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(3)) * 0.1
+
+    def run(dec, device):
+        m, c, h, o = _leafs(sc, device)
+        out = dec.forward(Gaussians(m, c, h, o), sc.extrinsics.to(device), sc.intrinsics.to(device), sc.near.to(device),
+                          sc.far.to(device), (256, 256), depth_mode="depth")
+        ((out.color * w.to(device)).sum() + (out.depth * wd.to(device)).sum()).backward()
+        return out.color.detach().cpu().numpy(), out.depth.detach().cpu().numpy(), (m, c, h, o)
+
+    gc, gd, gl = run(dec_gpu, DEV)
+    oc, od, ol = _with_oracle(lambda: run(dec_cpu, "cpu"))
+    assert gc.shape == (1, 3, 3, 256, 256) and gd.shape == (1, 3, 256, 256)
+    assert rel_l2(gc, oc) < 1e-4 and rel_l2(gd, od) < 1e-4
+    assert int((np.abs(gc - oc).max(axis=2) > 1e-4).sum()) <= 4  # pixels whose colour differs by more than 1e-4
+    _cmp_grads(gl, ol)
+
+
+def test_backward_twice_with_retain_graph_and_settings_debug():
+    """Upstream's Function can be differentiated repeatedly (retain_graph=True / several autograd.grad calls over one render);
+    `settings.debug=True` reaches the library (per-stage synchronise + check) and changes no result."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from tests.util import make_camera, random_small_scene
+
+    sc = random_small_scene(5, 400, sh_coeffs=25, dtype=np.float32)
+    cam = make_camera(dtype=np.float32)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    means = t(sc["means"]).requires_grad_(True)
+    shs = t(sc["colors"]).requires_grad_(True)
+    imgs = []
+    for debug in (False, True):
+        settings = GaussianRasterizationSettings(
+            image_height=40, image_width=48, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t([0.1, 0.1, 0.1]),
+            scale_modifier=1.0, viewmatrix=t(cam["viewmatrix"]).reshape(4, 4), projmatrix=t(cam["projmatrix"]).reshape(4, 4),
+            sh_degree=4, campos=t(cam["campos"]), prefiltered=False, debug=debug)
+        img, _ = GaussianRasterizer(settings)(means3D=means, means2D=None, shs=shs, opacities=t(sc["opac"])[:, None],
+                                              cov3D_precomp=t(sc["cov6"]))
+        imgs.append(img)
+    assert torch.equal(imgs[0], imgs[1])
+    loss = imgs[0].sum()
+    g1 = torch.autograd.grad(loss, [means, shs], retain_graph=True)
+    g2 = torch.autograd.grad(loss, [means, shs], retain_graph=True)
+    g3 = torch.autograd.grad(imgs[0][0].sum(), [means], retain_graph=False)
+    for a, b in zip(g1, g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6)
+    assert torch.isfinite(g3[0]).all() and g3[0].abs().sum() > 0
+
+
 def test_per_view_rasterizer_upstream_signature():
     from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
     from tests.util import make_camera, random_small_scene

@@ -7,6 +7,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the ablation switches and the phase stamps exist only in a -DGSR_ABLATE build of the library: make one next to this file
+ABLATE_LIB = os.path.join(ROOT, "tools", "libgsr_hip_ablate.so")
+os.environ["GSR_LIB_PATH"] = ABLATE_LIB
+from pf3plat_amd import _lib  # noqa: E402
+
+_lib.build(extra_flags=["-DGSR_ABLATE"], out=ABLATE_LIB)
 from pf3plat_amd import synthetic  # noqa: E402
 from pf3plat_amd.rasterizer import HipBackend, RasterConfig  # noqa: E402
 

@@ -21,8 +21,9 @@ def main():
             cur = []
             passes.append(cur)
         if cur is not None:
-            cur.append((short, st, en))
-    passes = [p for p in passes if len(p) in (4, 6) and p[-1][0].startswith("k_blend_fwd")]
+            k = sum(1 for x in cur if x[0].split("#")[0] == short)
+            cur.append((short if k == 0 else f"{short}#{k}", st, en))
+    passes = [p for p in passes if 3 <= len(p) <= 8 and any(x[0].startswith(("k_blend_fwd", "k_tile_fwd")) for x in p)]
     passes = passes[len(passes) // 2: len(passes) // 2 + npass]
     acc = defaultdict(lambda: [0.0, 0.0, 0])
     period = []
