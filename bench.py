@@ -14,7 +14,9 @@ exposed, inside the timed region (north_star: gather of rendered views at the en
 Scaling is "weak".
 
 After the timed region (never inside it): fwd+bwd timing (configs[2]), per-stage HIP-event timing of the same
-launch chain for the roofline object, a parity spot check and the CPU baseline (oracle, rank 0, N == 1 only).
+launch chain for the roofline objects (every kernel of the forward and backward chains, with its HBM traffic from
+rocprofv3 PMC passes), a parity spot check and the CPU baseline (oracle, rank 0, N == 1 only).
+Camera set-up (gsr_setup_views, one ~4 us launch per batch of views) happens once before the loop and is not part of a step.
 """
 from __future__ import annotations
 
@@ -67,12 +69,30 @@ def backward_bytes(n, nv, r16, hw, k_sh):
     return hw * (12 + 8) + r16 * (8 + 36) + nv * 80 + nv * (12 + 24 + kc) + n * (12 + 24 + 4 + kc)
 
 
-def pmc_traffic(kernel, n):
-    """HBM bytes per launch of `kernel` from the TCC counters, one rocprofv3 pass per counter (FETCH_SIZE and WRITE_SIZE do
-    not fit one pass), each profiling a child run of this file (--traffic-child).  Units and the gfx950 correction are those
-    of /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB, and FETCH_SIZE reports half the bytes of
-    a wide coalesced read, so traffic = 2 * FETCH + WRITE (an upper bound for the gather-type kernels).  None if rocprofv3 is
-    unavailable or a pass fails."""
+# kernel of every stage of the two chains (images of up to 8192 tiles: the fused binning path), and SURVEY.md 8d's algorithmic
+# bytes split over them: the terms of FWD_BYTES / BWD_BYTES, each attributed to the kernel that has to move it
+KERNELS = {"preprocess": "gsr::k_preprocess_bin", "sort": "gsr::k_sort_tiles", "blend": "gsr::k_blend_fwd",
+           "blend_bwd": "gsr::k_blend_bwd", "preprocess_bwd": "gsr::k_preprocess_bwd"}
+
+
+def kernel_bytes(n, nv, r16, hw, k_sh):
+    kc = 12 * k_sh
+    return {
+        "preprocess": 12 * n + nv * (24 + 4) + nv * 28 + 8 * r16,      # means, cov6 + opacity in; xy, depth, conic + opacity out; (depth, id) keys out
+        "sort": 8 * r16 + nv * kc + nv * 12,                           # keys in; and the colour pass riding in this launch: SH in, rgb out
+        "blend": 36 * r16 + hw * (12 + 8),                             # gather of xy / conic-opacity / rgb; image + saved state out
+        "blend_bwd": hw * (12 + 8) + r16 * (8 + 36) + nv * 40,         # dL/dpixel + state in; list + gather; screen-space gradients out
+        "preprocess_bwd": nv * 40 + nv * (12 + 24 + kc) + n * (12 + 24 + 4 + kc),  # screen-space grads + inputs in; dense gradients out
+    }
+
+
+def pmc_traffic(kernels, n):
+    """HBM bytes per launch of every kernel in `kernels` (name fragments) from the TCC counters, one rocprofv3 pass per
+    counter (FETCH_SIZE and WRITE_SIZE do not fit one pass), each profiling a child run of this file (--traffic-child:
+    a dozen eager forward + backward passes of the headline workload).  Units and the gfx950 correction are those of
+    /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB, and FETCH_SIZE reports half the bytes of
+    a wide coalesced read, so traffic = 2 * FETCH + WRITE (an upper bound for the gather-type kernels).  None if rocprofv3
+    is unavailable or a pass fails."""
     import csv
     import glob
     import shutil
@@ -82,7 +102,7 @@ def pmc_traffic(kernel, n):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None
-    raw = {}
+    raw = {k: {} for k in kernels}
     here = os.path.abspath(__file__)
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -91,23 +111,25 @@ def pmc_traffic(kernel, n):
             subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
                             sys.executable, here, "--traffic-child", "--gaussians", str(n)],
                            cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
-            vals = []
+            vals = {k: [] for k in kernels}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == ctr and kernel.split("::")[-1] in r["Kernel_Name"]:
-                        vals.append(float(r["Counter_Value"]))
+                    if r["Counter_Name"] != ctr:
+                        continue
+                    for k in kernels:
+                        if k.split("::")[-1] in r["Kernel_Name"]:
+                            vals[k].append(float(r["Counter_Value"]))
             shutil.rmtree(d, ignore_errors=True)
-            if not vals:
-                return None
-            vals = vals[len(vals) // 3:]  # steady state
-            raw[ctr] = 1024.0 * sum(vals) / len(vals)
+            for k in kernels:
+                if not vals[k]:
+                    return None
+                v = vals[k][len(vals[k]) // 3:]  # steady state
+                raw[k][ctr] = 1024.0 * sum(v) / len(v)
     except Exception as e:  # pragma: no cover - measurement aid
-        print(f"[bench] PMC traffic pass failed ({type(e).__name__}: {e}); roofline.traffic stays null", file=sys.stderr)
+        print(f"[bench] PMC traffic pass failed ({type(e).__name__}: {e}); traffic stays null", file=sys.stderr)
         return None
-    return {"traffic": 2.0 * raw["FETCH_SIZE"] + raw["WRITE_SIZE"], "fetch_size_raw_bytes": raw["FETCH_SIZE"],
-            "write_size_raw_bytes": raw["WRITE_SIZE"],
-            "note": "per launch; rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the "
-                    "guide's gfx950 correction (exact for coalesced streams, an upper bound for gathers); WRITE uncalibrated"}
+    return {k: {"traffic": 2.0 * raw[k]["FETCH_SIZE"] + raw[k]["WRITE_SIZE"], "fetch_size_raw_bytes": raw[k]["FETCH_SIZE"],
+                "write_size_raw_bytes": raw[k]["WRITE_SIZE"]} for k in kernels}
 
 
 def main():
@@ -161,9 +183,11 @@ def main():
     def step():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
 
-    if args.traffic_child:  # profiled by pmc_traffic(): a handful of eager passes of the headline chain, nothing else
+    if args.traffic_child:  # profiled by pmc_traffic(): a dozen eager forward + backward passes of the headline workload
+        g_child = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(3)).to(dev)
         for _ in range(12):
             step()
+            be.run_backward(plan, viewbuf, means, cov6, opac, shs, None, g_child)  # (plain plan: own scratch + zero-fill)
         torch.cuda.synchronize()
         return
 
@@ -173,7 +197,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- optional HIP-graph capture of one step (launch-bound chain of 6 kernels + 1 memset)
+    # ---- optional HIP-graph capture of one step (a plain chain of three kernel launches on one stream)
     graph = None
     if not args.no_graph:
         try:
@@ -246,10 +270,14 @@ def main():
         for _ in range(min(Wm, 5)):
             step()
         eager_dt = timed(step, K, False)
+    ranks_seen = 1
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # how many ranks the collective itself saw
+        ranks_seen = int(round(float(ones.item())))
     status = be.read_status(plan)
     assert not status["overflow"], status
     # both launch modes ran the same W + K protocol; the headline is the faster one and says which it is
@@ -269,8 +297,12 @@ def main():
                                "one scene per GPU (seed 2+rank), inputs resident in HBM",
                    "launch": launch_mode,
                    "parallelism": f"views sharded 1 scene/GPU x{world}" + (f", RCCL all-gather of the {K} x {world} rendered views in {n_chunks} batches overlapped with rendering, the last one at the end" if world > 1 else ""),
+                   "camera_setup": "excluded (gsr_setup_views runs once before the loop; ~4 us per batch of views)",
                    "num_pairs_8x8": status["num_pairs"], "max_tile_list": status["max_list"]},
     }
+    if world > 1:
+        result["rccl_ranks"] = ranks_seen
+        result["dist_backend"] = backend
     if eager_dt is not None:
         result["eager_ms_per_step"] = 1e3 * eager_dt / K
         result["graph_ms_per_step"] = 1e3 * graph_dt / K
@@ -285,22 +317,22 @@ def main():
                 acc[k_] = acc.get(k_, 0.0) + v_ / reps
         nv, r16 = reference_rect_stats(plan, cfg)
         ab = algorithmic_bytes(n, nv, r16, H * W, D_SH)
-        kc = 12 * D_SH
-        stage_bytes = {"preprocess": 12 * n + nv * 28 + nv * 28, "color": nv * kc + nv * 12, "tile_scan": 0,
-                       "emit": ab["binning"] // 2, "sort": ab["binning"] // 2, "blend": ab["blend"]}
-        dom = max(acc, key=acc.get)
-        chain_ms = sum(acc.values())
-        ach = stage_bytes[dom] / (acc[dom] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": {"preprocess": "gsr::k_preprocess_count", "color": "gsr::k_color", "tile_scan": "gsr::k_tile_scan",
-                                                         "emit": "gsr::k_emit", "sort": "gsr::k_sort_tiles",
-                                                         "blend": "gsr::k_blend_fwd"}[dom],
-                              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": None, "algorithmic_bytes": stage_bytes[dom], "avg_ms": acc[dom]}
+        kb = kernel_bytes(n, nv, r16, H * W, D_SH)
+        assert kb["preprocess"] + kb["sort"] + kb["blend"] == ab["total"]
+        # the product chain on this image size is three launches: stages preprocess, sort (+ colour riding), blend
+        chain_stages = ("preprocess", "sort", "blend")
+        dom = max(chain_stages, key=lambda k_: acc[k_])
+        ach = kb[dom] / (acc[dom] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "kernel": KERNELS[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": kb[dom], "avg_ms": acc[dom]}
         result["roofline_chain"] = {"bound": "hbm", "achieved": ab["total"] / (dt / K) / 1e9,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab["total"] / (dt / K) / 1e9 / HBM_PEAK_GBS,
                                     "algorithmic_bytes": ab["total"], "N": n, "N_v": nv, "R16": r16}
-        result["stage_ms"] = {k_: round(v_, 5) for k_, v_ in acc.items()}
-        result["stage_ms"]["sum_with_event_gaps"] = round(chain_ms, 5)
+        result["stage_ms"] = {k_: round(acc[k_], 5) for k_ in chain_stages}
+        result["stage_ms"]["color_alone"] = round(acc["color"], 5)
+        result["stage_ms"]["note"] = ("HIP events on the launch stream around each launch of the product chain (preprocess_bin, sort_tiles "
+                                      "with the colour workgroups riding, blend_fwd), serialised by the events (~1 us each); color_alone is an "
+                                      "extra launch of the colour workgroups only and is not part of the chain")
         # ---- on-box HBM ceilings ("fraction against both"): device copy and triad over 1 GiB arrays
         try:
             nel = 256 << 20
@@ -329,32 +361,42 @@ def main():
             result["roofline_chain"]["frac_of_measured"] = result["roofline_chain"]["achieved"] / ceil_gbs
         except Exception as e:  # pragma: no cover - measurement aid
             result["roofline"]["measured_ceiling"] = f"{type(e).__name__}: {e}"
+        traffic = None
         if not args.no_traffic and world == 1:
-            tr = pmc_traffic(result["roofline"]["kernel"], n)
-            if tr is not None:
-                result["roofline"]["traffic"] = tr["traffic"]
-                result["roofline"]["traffic_detail"] = tr
+            traffic = pmc_traffic(list(KERNELS.values()), n)
+            if traffic is not None:
+                result["roofline"]["traffic"] = traffic[KERNELS[dom]]["traffic"]
+                result["roofline"]["traffic_detail"] = dict(traffic[KERNELS[dom]], note=(
+                    "per launch; rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the guide's "
+                    "gfx950 correction (exact for coalesced streams, an upper bound for gathers); WRITE uncalibrated"))
 
         # ---- fwd + bwd (configs[2]): dense seeded dL/dcolor
         gen = torch.Generator().manual_seed(3)
         g_color = torch.rand((1, 3, H, W), generator=gen).to(dev)
 
+        # configs[2]: the forward is told a backward follows (it zero-fills the accumulator rows on its way) - as autograd does
+        from pf3plat_amd import _lib as _gl
+
+        cfg_b = RasterConfig(1, 1, 1, n, H, W, 4, D_SH, 4, False, _gl.FLAG_BACKWARD_FOLLOWS)
+        plan_b = be.make_plan(cfg_b, dev, capacity=int(plan["dims"].pair_capacity), backward=True)
+
         def fb():
-            be.run_forward(plan, viewbuf, means, cov6, opac, shs)
-            be.run_backward(plan, viewbuf, means, cov6, opac, shs, None, g_color)
+            be.run_forward(plan_b, viewbuf, means, cov6, opac, shs)
+            be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color)
 
         for _ in range(5):
             fb()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        kb = max(10, K // 4)
-        for _ in range(kb):
+        n_fb = max(10, K // 4)
+        for _ in range(n_fb):
             fb()
         torch.cuda.synchronize()
-        fb_ms = 1e3 * (time.perf_counter() - t0) / kb
+        fb_ms = 1e3 * (time.perf_counter() - t0) / n_fb
         bacc = {}
         for _ in range(20):
-            ms = be.run_backward(plan, viewbuf, means, cov6, opac, shs, None, g_color, profile=True)
+            be.run_forward(plan_b, viewbuf, means, cov6, opac, shs)  # (the rows are good for one backward)
+            ms = be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color, profile=True)
             for k_, v_ in ms.items():
                 bacc[k_] = bacc.get(k_, 0.0) + v_ / 20
         bwd_ms = sum(bacc.values())
@@ -364,6 +406,16 @@ def main():
         result["bwd_stage_ms"] = {k_: round(v_, 5) for k_, v_ in bacc.items()}
         result["roofline_bwd"] = {"bound": "hbm", "achieved": bb / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": bb / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": bb}
+        assert kb["blend_bwd"] + kb["preprocess_bwd"] == bb
+        # every kernel of both chains: SURVEY 8d's bytes attributed to it, its measured time (HIP events), the HBM traffic the
+        # TCC counters saw per launch, the fraction of the 8 TB/s roofline and traffic / algorithmic bytes
+        times = dict(acc, **bacc)
+        result["roofline_per_kernel"] = [
+            {"kernel": KERNELS[k_], "stage": k_, "algorithmic_bytes": kb[k_], "avg_us": round(1e3 * times[k_], 3),
+             "achieved_GBps": round(kb[k_] / (times[k_] * 1e-3) / 1e9, 1), "frac": round(kb[k_] / (times[k_] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "traffic": None if traffic is None else traffic[KERNELS[k_]]["traffic"],
+             "traffic_over_algorithmic": None if traffic is None else round(traffic[KERNELS[k_]]["traffic"] / kb[k_], 3)}
+            for k_ in ("preprocess", "sort", "blend", "blend_bwd", "preprocess_bwd")]
 
         # ---- CPU baseline (the oracle = "port"; the reference has no CPU splatting path) + parity spot check
         if world == 1 and not args.no_cpu_baseline:
@@ -425,6 +477,7 @@ def main():
                 assert not be.read_status(plan8)["overflow"]
                 result["batched_8_views"] = {"views_per_s": 8 / t8, "ms_per_launch_chain": 1e3 * t8}
                 sc4 = synthetic.make_scene(50, 131072, (H, W), d_sh=D_SH, num_views=3).to(dev)
+                pf3plat_amd.get_backend().sync_policy = "lazy"  # inference loop: pair-count status verified asynchronously
                 dec = pf3plat_amd.DecoderSplattingCUDA().to(dev)
                 g4 = sc4.gaussians
                 a4 = (sc4.extrinsics, sc4.intrinsics, sc4.near, sc4.far, (H, W))
@@ -438,7 +491,7 @@ def main():
                     torch.cuda.synchronize()
                     t4 = (time.perf_counter() - t0) / 40
                 pf3plat_amd.get_backend().check_pending(wait=True)
-                result["decoder_config4"] = {"workload": "DecoderSplattingCUDA.forward, B=1, G=131072, K=25, V=3, colour+depth",
+                result["decoder_config4"] = {"workload": "DecoderSplattingCUDA.forward, B=1, G=131072, K=25, V=3, colour+depth (sync_policy lazy)",
                                              "ms_per_call": 1e3 * t4, "views_per_s": 3 / t4}
             except Exception as e:  # extras must never take the headline line down
                 result["extras_error"] = f"{type(e).__name__}: {e}"

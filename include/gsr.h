@@ -66,12 +66,17 @@ extern "C" {
  * (2^-32 resolution, integer atomics commute), so two runs on the same inputs return bit-identical gradients whatever
  * order the tiles finish in.  The scratch buffer is then twice as large (gsr_backward_scratch_bytes). */
 #define GSR_FLAG_DETERMINISTIC 0x80
+/* The caller will run gsr_backward on this forward's workspaces: the forward then also zero-fills the per-(view, Gaussian)
+ * screen-space gradient rows (inside `geom`, which is that much larger) while it streams the SH coefficients, and
+ * gsr_backward called with the same dims and scratch == NULL accumulates into them - no separate zero-fill pass and no
+ * extra launch in the backward.  A second backward over the same forward must bring its own `scratch` (the rows are used). */
+#define GSR_FLAG_BACKWARD_FOLLOWS 0x10000
 /* Test aid: take the windowed binning path (preprocess, count, prefix, scan, emit, sort) even when the image has few enough
  * tiles for the fused one (k_preprocess_bin + gathering sort). */
 #define GSR_FLAG_WINDOWED_BINNING 0x4000
 /* Every other bit is rejected (GSR_ERR_INVALID_ARGUMENT). */
 #define GSR_FLAG_VALID_MASK (GSR_FLAG_PREFILTERED | GSR_FLAG_DEBUG | GSR_FLAG_SH_PLANAR | GSR_FLAG_COV_3X3 | 0x70 | \
-                             GSR_FLAG_DETERMINISTIC | GSR_FLAG_WINDOWED_BINNING)
+                             GSR_FLAG_DETERMINISTIC | GSR_FLAG_WINDOWED_BINNING | GSR_FLAG_BACKWARD_FOLLOWS)
 #ifdef GSR_ABLATE
 /* Measurement-only build (tools/ablate.py compiles its own copy of the library with -DGSR_ABLATE; the product library does
  * not contain these branches and rejects the bits): switches that make results WRONG on purpose to time a kernel without
@@ -82,7 +87,8 @@ extern "C" {
 #define GSR_FLAG_ABLATE_EMIT_NO_ATOMIC 0x800 /* emit: skip the slot atomics */
 #define GSR_FLAG_ABLATE_NO_GEOM_STORE 0x1000 /* preprocess: skip the projected-record store */
 #define GSR_FLAG_DEBUG_TIMING 0x2000         /* phase stamps (100 MHz counter) into the tail of the key buffer */
-#define GSR_FLAG_ABLATE_MASK 0x3f00
+#define GSR_FLAG_ABLATE_BWD_NO_ATOMIC 0x8000 /* backward blend: skip the per-splat atomic adds */
+#define GSR_FLAG_ABLATE_MASK 0xbf00
 #endif
 
 /* One camera = the non-tensor fields of upstream's GaussianRasterizationSettings
@@ -150,7 +156,8 @@ int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, c
  * Gaussians): dL_dmeans (num_sets,N,3), dL_dcov6 (num_sets,N,6), dL_dopacities (num_sets,N),
  * dL_dcolors (same shape as colors), dL_dextra (V,N) or NULL, dL_dmeans2D (V,N,3) or NULL.
  * Gradients of views sharing a set are summed, including the scale / scale2 chain factors.
- * `scratch` holds V*N*GSR_SCREEN_GRAD_FLOATS floats of screen-space accumulators. */
+ * `scratch` holds gsr_backward_scratch_bytes(dims) bytes of screen-space accumulators (zero-filled by the call); it may be
+ * NULL when the forward ran with GSR_FLAG_BACKWARD_FOLLOWS (the rows inside `geom` are used, once). */
 #define GSR_SCREEN_GRAD_FLOATS 12
 int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
                  const float* opacities, const float* colors, const float* extra, const void* geom,
@@ -173,6 +180,15 @@ size_t gsr_backward_scratch_bytes(const GsrDims* dims);
 int gsr_setup_views(int num_views, const float* extrinsics, const float* intrinsics, const float* near, const float* far,
                     const float* background, int background_stride, int scale_invariant, GsrView* views, void* stream);
 
+/* The same for the reference's fake orthographic camera (render_cuda_orthographic, cuda_splatting.py:153-181): per view the
+ * extent (width, height) of the orthographic window in world units; the camera is moved back along its own -z by
+ * (width / 2) / tan(fov_degrees / 2) and near / far move with it; no scale-invariant step.  The reference's quirk is kept:
+ * the projection's y scale uses fov_y = atan(2 tan_fov_y) (:160) while tanfovy holds tan_fov_y.  `dump` (nullable,
+ * num_views x 20 floats): moved extrinsics (16), fov_x, fov_y, near, far - the values of the wrapper's `dump` dict. */
+int gsr_setup_views_orthographic(int num_views, const float* extrinsics, const float* width, const float* height,
+                                 const float* near, const float* far, const float* background, int background_stride,
+                                 float fov_degrees, GsrView* views, float* dump, void* stream);
+
 /* Replaces upstream `_C.mark_visible` (GaussianRasterizer.markVisible): present[i] = 1 iff the
  * Gaussian passes the near-plane test of view 0 of its set (p_view.z > 0.2). */
 int gsr_mark_visible(const GsrDims* dims, const GsrView* views, const float* means, uint8_t* present,
@@ -190,9 +206,11 @@ int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float*
 
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
- * Forward stages: 0 preprocess (geometry, hit masks and - images of up to 8192 tiles - the whole binning) 1 colour (SH; on
- * the product path this one overlaps stages 0-4 on a side stream) 2 count + tile scans and 3 emit (windowed binning path
- * only: empty, i.e. one event gap each, otherwise) 4 per-tile gather + sort 5 blend.
+ * Forward stages: 0 preprocess (geometry, hit masks and - images of up to 8192 tiles - the whole binning) 1 the colour pass
+ * launched ALONE (an extra launch, measurement only: on the product path its workgroups ride in the sort launch) 2 count +
+ * tile scans and 3 emit (windowed binning path only: empty, i.e. one event gap each, otherwise) 4 the sort launch as the
+ * product issues it (per-tile gather + sort, with the colour workgroups riding along) 5 blend.  The product chain is
+ * 0 + 2 + 3 + 4 + 5.
  * Backward stages: 0 blend backward 1 preprocess backward. */
 #define GSR_FWD_STAGES 6
 #define GSR_BWD_STAGES 2

@@ -23,6 +23,7 @@ FLAG_DEBUG = 0x2  # upstream's `debug`: synchronise + check after every stage
 FLAG_SH_PLANAR = 0x4
 FLAG_COV_3X3 = 0x8
 FLAG_DETERMINISTIC = 0x80  # backward accumulates in 64-bit fixed point: bit-identical from run to run
+FLAG_BACKWARD_FOLLOWS = 0x10000  # forward zero-fills the backward's accumulator rows (inside geom); backward scratch may be None
 FLAG_WINDOWED_BINNING = 0x4000  # test aid: the windowed binning path on an image small enough for the fused one
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
@@ -113,6 +114,8 @@ def load():
     lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
     lib.gsr_setup_views.restype = ctypes.c_int
     lib.gsr_setup_views.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.gsr_setup_views_orthographic.restype = ctypes.c_int
+    lib.gsr_setup_views_orthographic.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_float, vp, vp, vp]
     fp = ctypes.POINTER(ctypes.c_float)
     lib.gsr_forward_profile.restype = ctypes.c_int
     lib.gsr_forward_profile.argtypes = [dp] + [vp] * 13 + [fp]
@@ -128,7 +131,7 @@ EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
-    "gsr_backward_scratch_bytes",
+    "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic",
 )
 # gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).

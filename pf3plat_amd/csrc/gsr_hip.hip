@@ -83,7 +83,7 @@ __host__ __device__ inline Grid make_grid(int W, int H) {
 
 struct Layout {
   size_t geom_bytes, bin_bytes, img_bytes;
-  size_t o_rgbc;  // in geom
+  size_t o_rgbc, o_rows;  // in geom (o_rows: screen-space gradient rows, only with GSR_FLAG_BACKWARD_FOLLOWS)
   size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list, o_blk, o_blktot;  // in bin
   size_t key_slots;  // keys: one fixed slot of kStagePairs keys per binning workgroup, then ...
   size_t key_pages;  // ... a pool of pages of kPage keys (regions / scratch too long for a slot)
@@ -113,7 +113,9 @@ static Layout make_layout(const GsrDims& d) {
   const size_t V = d.num_views, N = d.num_gaussians, VT = V * (size_t)g.T;
   const size_t cap = d.pair_capacity > 0 ? (size_t)d.pair_capacity : 0;
   L.o_rgbc = align_up(V * N * sizeof(GeomRec), 256);
-  L.geom_bytes = L.o_rgbc + align_up(V * N * sizeof(float4), 256);
+  L.o_rows = L.o_rgbc + align_up(V * N * sizeof(float4), 256);
+  L.geom_bytes = L.o_rows + ((d.flags & GSR_FLAG_BACKWARD_FOLLOWS)
+                                 ? align_up(V * N * GSR_SCREEN_GRAD_FLOATS * ((d.flags & GSR_FLAG_DETERMINISTIC) ? 8 : 4), 256) : 0);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
   const size_t rows = (N + choose_chunk(d) - 1) / choose_chunk(d);
@@ -150,6 +152,7 @@ struct Params {
   int32_t* radii;
   GeomRec* geom;
   float4* rgbc;
+  float4* grad_rows;  // forward with GSR_FLAG_BACKWARD_FOLLOWS: the rows the colour workgroups zero-fill (else null)
   GsrStatus* status;
   uint32_t* counts;      // windowed path: u32 count matrix; fused path: the same storage as uint2 (offset, count)
   uint2* pair_mat;
@@ -669,6 +672,110 @@ __device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
   return f;
 }
 
+// Colour role: SH -> RGB (+0.5, clamp mask) of one 64-Gaussian unit for every view of its set, by a group of kColorThreads
+// threads.  All of them request the unit's 64 x 3M SH floats (19 200 B at M = 25) as 16-byte coalesced loads, park them in
+// LDS (row stride 3M floats, odd => conflict-free) and wave w evaluates views w, w + 4, ... with lane = Gaussian (the SH of a
+// set is read ONCE however many views it has).  The colour pass is HBM-bound (300 of the 352 input bytes per Gaussian) and
+// has no launch of its own: its workgroups ride in the sort launch (k_sort_tiles: blockIdx >= sort_blocks), BEHIND the
+// per-tile sorts - they take the CU slots the sorts free as they finish.  One stream, no second queue, no events.
+// (Measured alternatives, all slower: colour beside the sorts at 6 or 8 workgroups per CU - the sorts' scattered gathers
+// queue behind the colour stream; colour workgroups beside the binning workgroups - with 19 KB of LDS per unit in flight
+// a CU holds too few units to cover their latency once their waves share SIMDs with VALU-bound ones; a second stream.)
+constexpr int kColorThreads = 256;
+constexpr int kShPre = 5;  // float4 registers per thread that hold the unit's SH rows (64 * 75 / 4 / 256 = 4.7)
+constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 75: odd)
+
+// `tid` = thread within the group (0 .. kColorThreads - 1), `lds` = the group's 19 200 B; the one barrier inside is the
+// workgroup's, so every group of a workgroup must come here together - a group without a unit passes valid = false.
+__device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool valid, float* lds, int tid) {
+  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+  const int lane = tid & 63, wave = tid >> 6;
+  // Few waves, little arithmetic, but every cycle a unit waits keeps 19 KB of LDS from the next one: issue ahead of the
+  // VALU-bound waves this workgroup shares its SIMDs with
+  __builtin_amdgcn_s_setprio(3);
+  if (!valid) cu = 0;
+  const int set = (int)(cu / p.color_units), unit = (int)(cu - (uint32_t)set * p.color_units);
+  const int N = p.d.num_gaussians, Vs = p.d.views_per_set;
+  const int g0 = unit * 64;
+  const int i = g0 + lane;
+  const bool in_range = i < N;
+  const size_t gi = (size_t)set * N + (in_range ? i : 0);
+  const int M = p.d.sh_coeffs;
+  if (p.grad_rows && valid) {  // a backward follows: its accumulator rows of this unit, all views of the set, start at zero
+    const int row4 = (p.d.flags & GSR_FLAG_DETERMINISTIC) ? 2 * GSR_SCREEN_GRAD_FLOATS / 4 : GSR_SCREEN_GRAD_FLOATS / 4;
+    const int n4 = min(64, N - g0) * row4;
+    for (int vv = 0; vv < Vs; ++vv) {
+      float4* rows = p.grad_rows + ((size_t)(set * Vs + vv) * N + g0) * row4;
+      for (int k = tid; k < n4; k += kColorThreads) rows[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  if (M == 0) {  // precomputed colours: copy through (no clamp)
+    if (in_range && wave == 0 && valid)
+      for (int vv = 0; vv < Vs; ++vv)
+        p.rgbc[(size_t)(set * Vs + vv) * N + i] = make_float4(p.colors[3 * gi], p.colors[3 * gi + 1], p.colors[3 * gi + 2], 0.f);
+    return;
+  }
+  const int rowf = 3 * M, ldstride = rowf | 1;
+  const int cnt = min(64, N - g0);
+  const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
+  const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
+  const bool sh_fast = (ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0);
+  if (!valid) {
+  } else if (sh_fast) {
+    float4 pre[kShPre];
+#pragma unroll
+    for (int q = 0; q < kShPre; ++q) {
+      const int k = tid + kColorThreads * q;
+      pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < kShPre; ++q) {
+      const int k = tid + kColorThreads * q;
+      if (k < sh_n4) reinterpret_cast<float4*>(lds)[k] = pre[q];
+    }
+    for (int k = (sh_n4 << 2) + tid; k < sh_total; k += kColorThreads) lds[k] = sh_src[k];
+  } else {
+    for (int k = tid; k < sh_total; k += kColorThreads) {
+      const int row = k / rowf;
+      lds[row * ldstride + (k - row * rowf)] = sh_src[k];
+    }
+  }
+  float rmx = 0, rmy = 0, rmz = 0;
+  if (valid && in_range && wave < Vs) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
+  __syncthreads();
+  if (!in_range || !valid) return;
+  const float* sh = lds + lane * ldstride;
+  const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
+  if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
+  // coefficient k of channel c sits at k * ks + c * cs: (3, 1) for (N, M, 3), (1, M) for the planar (N, 3, M) layout.  The
+  // common layouts get compile-time strides (one base register + immediate offsets); computed per coefficient at run time
+  // the 75 LDS addresses occupied 75 registers.
+  auto eval_views = [&](auto ks_c, auto cs_c) {
+    const int ks = ks_c(), cs = cs_c();
+    for (int vv = wave; vv < Vs; vv += kColorThreads / 64) {
+      const int v = set * Vs + vv;
+      const GsrView& cam = p.views[v];
+      const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
+      float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float cr = 0, cg = 0, cb = 0;
+      sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
+        if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
+      });
+      cr += 0.5f; cg += 0.5f; cb += 0.5f;
+      const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
+      p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
+    }
+  };
+  const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
+  if (!planar) eval_views([] { return 3; }, [] { return 1; });
+  else if (M == 25) eval_views([] { return 1; }, [] { return 25; });
+  else eval_views([] { return 1; }, [&] { return M; });
+  if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
+}
+
 // K1 (images of up to kTileWindow tiles): preprocess AND the whole binning of this workgroup's `chunk` Gaussians.
 //   1. preprocess the Gaussians; histogram their (tile, splat) pairs per tile in LDS; records leave through the transpose;
 //   2. exclusive scan of the histogram over the tiles = where each tile's pairs start INSIDE this workgroup's own region
@@ -822,84 +929,6 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   }
   GSR_STAMP(4);
 #undef GSR_STAMP
-}
-
-// Colour role of the sort kernel: SH -> RGB (+0.5, clamp mask) of one 64-Gaussian unit for every view of its set, by a
-// workgroup of kSortThreads threads.  All threads request the unit's 64 x 3M SH floats (19 200 B at M = 25) as 16-byte
-// coalesced loads, park them in LDS (row stride 3M floats, odd => conflict-free) and wave w evaluates views w, w + 4, ... with
-// lane = Gaussian (the SH of a set is read ONCE however many views it has).  These workgroups ride in the same launch as the
-// per-tile sorts (k_sort_tiles: blockIdx >= sort_blocks): the sort is latency-bound and leaves HBM idle, the colour pass is
-// HBM-bound (300 of the 352 input bytes per Gaussian) - one stream, no second queue, no events.
-constexpr int kColorThreads = 256;
-constexpr int kShPre = 5;  // float4 registers per thread that hold the unit's SH rows (64 * 75 / 4 / 256 = 4.7)
-constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 75: odd)
-
-__device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, float* lds) {
-  const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int set = (int)(cu / p.color_units), unit = (int)(cu - (uint32_t)set * p.color_units);
-  const int N = p.d.num_gaussians, Vs = p.d.views_per_set;
-  const int g0 = unit * 64;
-  const int i = g0 + lane;
-  const bool in_range = i < N;
-  const size_t gi = (size_t)set * N + (in_range ? i : 0);
-  const int M = p.d.sh_coeffs;
-  if (M == 0) {  // precomputed colours: copy through (no clamp)
-    if (in_range && wave == 0)
-      for (int vv = 0; vv < Vs; ++vv)
-        p.rgbc[(size_t)(set * Vs + vv) * N + i] = make_float4(p.colors[3 * gi], p.colors[3 * gi + 1], p.colors[3 * gi + 2], 0.f);
-    return;
-  }
-  const int rowf = 3 * M, ldstride = rowf | 1;
-  const int cnt = min(64, N - g0);
-  const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
-  const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
-  const bool sh_fast = (ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0);
-  if (sh_fast) {
-    float4 pre[kShPre];
-#pragma unroll
-    for (int q = 0; q < kShPre; ++q) {
-      const int k = tid + kColorThreads * q;
-      pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int q = 0; q < kShPre; ++q) {
-      const int k = tid + kColorThreads * q;
-      if (k < sh_n4) reinterpret_cast<float4*>(lds)[k] = pre[q];
-    }
-    for (int k = (sh_n4 << 2) + tid; k < sh_total; k += kColorThreads) lds[k] = sh_src[k];
-  } else {
-    for (int k = tid; k < sh_total; k += kColorThreads) {
-      const int row = k / rowf;
-      lds[row * ldstride + (k - row * rowf)] = sh_src[k];
-    }
-  }
-  float rmx = 0, rmy = 0, rmz = 0;
-  if (in_range && wave < Vs) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
-  __syncthreads();
-  if (!in_range) return;
-  const float* sh = lds + lane * ldstride;
-  const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
-  const int ks = planar ? 1 : 3, cs = planar ? M : 1;  // coefficient k of channel c sits at k * ks + c * cs
-  const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
-  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
-  if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
-  for (int vv = wave; vv < Vs; vv += kColorThreads / 64) {
-    const int v = set * Vs + vv;
-    const GsrView& cam = p.views[v];
-    const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
-    float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
-    const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-    dx = dx / len; dy = dy / len; dz = dz / len;
-    float cr = 0, cg = 0, cb = 0;
-    sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
-      if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
-    });
-    cr += 0.5f; cg += 0.5f; cb += 0.5f;
-    const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
-    p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
-  }
-  if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1250,8 +1279,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 //   fixed slot of the index list (`stride` = pair_capacity / (2 x views x tiles) entries; a longer list takes a run of the
 //   shared second half from a bump counter: correct for any distribution as long as pair_capacity >= 2 x pairs, and free of
 //   shared counters when pair_capacity >= 2 x views x tiles x longest list).
+#ifndef GSR_SORT_OCC
+#define GSR_SORT_OCC 4
+#endif
 template <bool kGather, int kLds>
-__global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
+__global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GSR_SORT_OCC, GSR_SORT_OCC))) void k_sort_tiles(const Params p) {
   // kLds keys sort in LDS, over kLds / 4 depth buckets.  The 2048-key variant needs no more LDS than a colour unit
   // (18.4 KB vs 19.2 KB), so eight workgroups of either role share a CU.
   constexpr int kBk = kLds / 4, kBkBits = kLds == 4096 ? 10 : 9, kBpt = kBk / kSortThreads;
@@ -1262,17 +1294,23 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
   __shared__ __attribute__((aligned(16))) unsigned long long smem[kSortWords > kColorWords ? kSortWords : kColorWords];
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
-  if (blockIdx.x >= p.sort_blocks) {  // workgroup-uniform: the colour pass rides in this launch (see color_unit)
-    color_unit(p, blockIdx.x - p.sort_blocks, reinterpret_cast<float*>(smem));
-    return;
+  uint32_t bid = blockIdx.x;
+  {
+    const uint32_t S = p.sort_blocks;
+    const bool colour = bid >= S;
+    if (colour) bid -= S;
+    if (colour) {  // workgroup-uniform: the colour pass rides in this launch (see color_unit)
+      color_unit(p, bid, true, reinterpret_cast<float*>(smem), (int)threadIdx.x);
+      return;
+    }
   }
   unsigned long long* sk = smem;
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kLds);  // counts, then (same storage) scatter cursors
   uint32_t* cur = hist;
   const int tid = threadIdx.x;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
-  unsigned long long* stamp = dbg_stamps(p, 8192 + blockIdx.x);
-  unsigned long long* stamp2 = dbg_stamps(p, 8192 + p.sort_blocks + blockIdx.x);
+  unsigned long long* stamp = dbg_stamps(p, 8192 + bid);
+  unsigned long long* stamp2 = dbg_stamps(p, 8192 + p.sort_blocks + bid);
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define GSR_STAMP2(k) do { if (dbg && tid == 0) stamp2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
@@ -1283,14 +1321,14 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
     const int T = p.g.T, R = p.rows;
     // XCD-aware order: neighbouring tiles' runs share cache lines in every region, so give each XCD (= each L2) a contiguous
     // range of tiles
-    const int tg = xcd_remap((int)blockIdx.x, (int)p.sort_blocks);
+    const int tg = xcd_remap((int)bid, (int)p.sort_blocks);
     const int v = tg / T, t = tg - v * T;
     // De-phase the first resident round.  All its workgroups start together and would gather together (memory-bound, CUs
     // idle: 250 k small reads take 11 us when issued at once, 2-4 us per workgroup when spread out), then sort together
     // (LDS-bound, memory idle).  Four groups 2 us apart let one group's gather overlap another's bucket sort (measured:
     // forward 81.2 -> 77.0 us).  Later rounds start whenever a slot frees up and are out of phase by themselves.
-    if (blockIdx.x < 1024u) {
-      for (int q = 0; q < (int)((blockIdx.x >> 3) & 3); ++q) __builtin_amdgcn_s_sleep(64);
+    if (bid < 1024u) {
+      for (int q = 0; q < (int)((bid >> 3) & 3); ++q) __builtin_amdgcn_s_sleep(64);
     }
     const uint2* col = p.pair_mat + (size_t)v * R * (T + 8) + t;
     const size_t cstride = (size_t)T + 8;
@@ -1340,7 +1378,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       p.ranges[tg] = ok ? make_uint2(rbase, rbase + (uint32_t)n) : make_uint2(0u, 0u);
       sInfo[0] = rbase; sInfo[1] = ok; sInfo[2] = scratch;
     }
-    if (blockIdx.x == 0) {  // total pair count = sum of the binning workgroups' totals
+    if (bid == 0) {  // total pair count = sum of the binning workgroups' totals
       unsigned long long part = 0;
       for (int k = tid; k < p.d.num_views * R; k += kSortThreads) part += p.blk_total[k];
       for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
@@ -1399,7 +1437,7 @@ __global__ __launch_bounds__(kSortThreads) void k_sort_tiles(const Params p) {
       return;
     }
   } else {
-    const uint2 rg = p.ranges[blockIdx.x];
+    const uint2 rg = p.ranges[bid];
     n = (int)(rg.y - rg.x);
     if (n == 0) return;
     keys = p.keys + rg.x;
@@ -1931,7 +1969,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     if (kExtra) v9 = oct_allreduce(v9);
     // a splat that no pixel of the tile blended (or whose pixels carry no gradient) adds exact zeros: skip its atomics
     const bool any = (S0 != 0.f) || (Sx != 0.f) || (Sy != 0.f) || (Sxx != 0.f) || (v6 != 0.f) || (v7 != 0.f) || (v8 != 0.f) || (v9 != 0.f);
-    if (!any) return;
+    if (!any || GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_BWD_NO_ATOMIC)) return;
     // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
     const float o = a2.y;
     const float v0 = hW * kLn2 * o * (2.f * a.z * Sx + a.w * Sy);
@@ -2139,20 +2177,25 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const uint32_t cl = bits >> 28;
       const float d0 = (cl & 1u) ? 0.f : sg[6], d1 = (cl & 2u) ? 0.f : sg[7], d2 = (cl & 4u) ? 0.f : sg[8];
       const float* sh = sh_in + lane * ldstride;
-      const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
-      const int ks = planar ? 1 : 3, cs = planar ? M : 1;
       float ddx = 0, ddy = 0, ddz = 0;
       const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
       float* shw = sh_in + lane * ldstride;
-      sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
-        if (k < M) {
-          const float sd = sh[k * ks + 0 * cs] * d0 + sh[k * ks + 1 * cs] * d1 + sh[k * ks + 2 * cs] * d2;
-          ddx += bx * sd; ddy += by * sd; ddz += bz * sd;
-          if (one_walk) { shw[k * ks + 0 * cs] = bk * d0; shw[k * ks + 1 * cs] = bk * d1; shw[k * ks + 2 * cs] = bk * d2; }
-        }
-      });
-      if (one_walk)  // coefficients above the evaluated degree get no gradient
-        for (int k = (deg + 1) * (deg + 1); k < M; ++k) { shw[k * ks + 0 * cs] = 0.f; shw[k * ks + 1 * cs] = 0.f; shw[k * ks + 2 * cs] = 0.f; }
+      // compile-time strides for the common layouts (see color_unit): run-time ones cost a register per LDS address
+      auto sh_block = [&](auto ks_c, auto cs_c) {
+        const int ks = ks_c(), cs = cs_c();
+        sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
+          if (k < M) {
+            const float sd = sh[k * ks + 0 * cs] * d0 + sh[k * ks + 1 * cs] * d1 + sh[k * ks + 2 * cs] * d2;
+            ddx += bx * sd; ddy += by * sd; ddz += bz * sd;
+            if (one_walk) { shw[k * ks + 0 * cs] = bk * d0; shw[k * ks + 1 * cs] = bk * d1; shw[k * ks + 2 * cs] = bk * d2; }
+          }
+        });
+        if (one_walk)  // coefficients above the evaluated degree get no gradient
+          for (int k = (deg + 1) * (deg + 1); k < M; ++k) { shw[k * ks + 0 * cs] = 0.f; shw[k * ks + 1 * cs] = 0.f; shw[k * ks + 2 * cs] = 0.f; }
+      };
+      if (!(p.d.flags & GSR_FLAG_SH_PLANAR)) sh_block([] { return 3; }, [] { return 1; });
+      else if (M == 25) sh_block([] { return 1; }, [] { return 25; });
+      else sh_block([] { return 1; }, [&] { return M; });
       const float sum2 = ox * ox + oy * oy + oz * oz;
       const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
       dm[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
@@ -2199,9 +2242,9 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   } else if (M > 0) {
     float* dsh = sh_in + lane * ldstride;  // this lane's row: the coefficients are no longer needed
     for (int k = 0; k < rowf; ++k) dsh[k] = 0.f;
-    const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
-    const int ks = planar ? 1 : 3, cs = planar ? M : 1;
     const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+    auto second_walk = [&](auto ks_c, auto cs_c) {
+    const int ks = ks_c(), cs = cs_c();
     for (int vv = 0; vv < Vs && in_range; ++vv) {
       const int v = set * Vs + vv;
       const GsrView& cam = p.views[v];
@@ -2223,6 +2266,10 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
         if (k < M) { dsh[k * ks + 0 * cs] += bk * d0; dsh[k * ks + 1 * cs] += bk * d1; dsh[k * ks + 2 * cs] += bk * d2; }
       });
     }
+    };
+    if (!(p.d.flags & GSR_FLAG_SH_PLANAR)) second_walk([] { return 3; }, [] { return 1; });
+    else if (M == 25) second_walk([] { return 1; }, [] { return 25; });
+    else second_walk([] { return 1; }, [&] { return M; });
     __syncthreads();
     unstage_rows(p.dL_dcolors + ((size_t)set * N + g0) * rowf, sh_in, cnt, rowf, ldstride, lane);
   }
@@ -2270,6 +2317,36 @@ __device__ __forceinline__ void inv4(const float* m, float* inv) {  // general 4
   for (int i = 0; i < 16; ++i) inv[i] *= id;
 }
 
+// Camera record from a camera-to-world matrix E (already rescaled / moved), clip distances and the tangents: `tpx, tpy`
+// shape the projection matrix (get_projection_matrix, cuda_splatting.py:17-44), `tx, ty` are what the rasterizer is told.
+__device__ __forceinline__ void finish_view(const float* E, float nr, float fr, float tpx, float tpy, float tx, float ty, float s,
+                                            const float* bg, float near_raw, float far_raw, GsrView& o) {
+  const float top = tpy * nr, right = tpx * nr;
+  float P[16] = {0};
+  P[0] = 2.f * nr / (right + right); P[5] = 2.f * nr / (top + top); P[14] = 1.f;
+  P[10] = fr / (fr - nr); P[11] = -(fr * nr) / (fr - nr);
+  float Ei[16];
+  inv4(E, Ei);
+  // viewmatrix = (E^-1)^T, projmatrix = (E^-1)^T P^T, both stored row-major (cuda_splatting.py:85-87)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o.viewmatrix[4 * i + j] = Ei[4 * j + i];
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += Ei[4 * k + i] * P[4 * j + k];
+      o.projmatrix[4 * i + j] = a;
+    }
+  o.campos[0] = E[3]; o.campos[1] = E[7]; o.campos[2] = E[11];
+  o.tanfovx = tx; o.tanfovy = ty;
+  o.bg[0] = bg[0]; o.bg[1] = bg[1]; o.bg[2] = bg[2];
+  o.scale = s; o.scale2 = s * s; o.scale_modifier = 1.f;
+  o.reserved[0] = near_raw; o.reserved[1] = far_raw;  // un-normalised near / far (built-in relative-disparity / log extra channel)
+#pragma unroll
+  for (int i = 2; i < 5; ++i) o.reserved[i] = 0.f;
+}
+
 __global__ void k_setup_views(int V, const float* ext, const float* intr, const float* near_, const float* far_, const float* bg,
                               int bg_stride, int scale_invariant, GsrView* out) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2293,33 +2370,40 @@ __global__ void k_setup_views(int V, const float* ext, const float* intr, const 
   const float fov_x = acosf(l[0] * r[0] + l[1] * r[1] + l[2] * r[2]);
   const float fov_y = acosf(t[0] * b[0] + t[1] * b[1] + t[2] * b[2]);
   const float tx = tanf(0.5f * fov_x), ty = tanf(0.5f * fov_y);
-  // get_projection_matrix (cuda_splatting.py:17-44)
-  const float top = ty * nr, right = tx * nr;
-  float P[16] = {0};
-  P[0] = 2.f * nr / (right + right); P[5] = 2.f * nr / (top + top); P[14] = 1.f;
-  P[10] = fr / (fr - nr); P[11] = -(fr * nr) / (fr - nr);
-  float Ei[16];
-  inv4(E, Ei);
   GsrView o;
-  // viewmatrix = (E^-1)^T, projmatrix = (E^-1)^T P^T, both stored row-major (cuda_splatting.py:85-87)
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      o.viewmatrix[4 * i + j] = Ei[4 * j + i];
-      float a = 0.f;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a += Ei[4 * k + i] * P[4 * j + k];
-      o.projmatrix[4 * i + j] = a;
-    }
-  o.campos[0] = E[3]; o.campos[1] = E[7]; o.campos[2] = E[11];
-  o.tanfovx = tx; o.tanfovy = ty;
-  o.bg[0] = bg[bg_stride * v + 0]; o.bg[1] = bg[bg_stride * v + 1]; o.bg[2] = bg[bg_stride * v + 2];
-  o.scale = s; o.scale2 = s * s; o.scale_modifier = 1.f;
-  o.reserved[0] = near_[v]; o.reserved[1] = far_[v];  // un-normalised near / far (built-in relative-disparity / log extra channel)
-#pragma unroll
-  for (int i = 2; i < 5; ++i) o.reserved[i] = 0.f;
+  finish_view(E, nr, fr, tx, ty, tx, ty, s, bg + bg_stride * v, near_[v], far_[v], o);
   out[v] = o;
+}
+
+// The reference's fake orthographic camera (render_cuda_orthographic, cuda_splatting.py:153-181): the camera moves back
+// along its own -z by d = (width / 2) / tan(fov_x / 2) with a narrow fov_x, near and far move with it, no scale-invariant
+// step.  Quirk kept (:160): the projection's y scale comes from fov_y = atan(2 tan_fov_y) while the rasterizer is told
+// tan_fov_y itself.  `dump` (optional, 20 floats per view): the moved extrinsics, fov_x, fov_y, near, far - the wrapper's
+// `dump` dict.
+__global__ void k_setup_views_ortho(int V, const float* ext, const float* width, const float* height, const float* near_,
+                                    const float* far_, const float* bg, int bg_stride, float fov_degrees, GsrView* out, float* dump) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const float fov_x = fov_degrees * 0.017453292519943295f;
+  const float tx = tanf(0.5f * fov_x);
+  const float dist = (0.5f * width[v]) / tx;
+  const float ty = 0.5f * height[v] / dist;
+  const float fov_y = atanf(2.f * ty);
+  const float nr = near_[v] + dist, fr = far_[v] + dist;
+  float E[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) E[i] = ext[16 * v + i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) E[4 * i + 3] = E[4 * i + 2] * -dist + E[4 * i + 3];  // E @ [I | (0, 0, -d)]
+  GsrView o;
+  finish_view(E, nr, fr, tx, tanf(0.5f * fov_y), tx, ty, 1.f, bg + bg_stride * v, nr, fr, o);
+  out[v] = o;
+  if (dump) {
+    float* dp = dump + 20 * v;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dp[i] = E[i];
+    dp[16] = fov_x; dp[17] = fov_y; dp[18] = nr; dp[19] = fr;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_mark_visible(const Params p, uint8_t* present) {
@@ -2371,6 +2455,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   char* b = static_cast<char*>(bin);
   p.geom = static_cast<GeomRec*>(geom);
   p.rgbc = geom ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rgbc) : nullptr;
+  p.grad_rows = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS)) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rows) : nullptr;
   p.status = reinterpret_cast<GsrStatus*>(b + L.o_status);
   p.counts = reinterpret_cast<uint32_t*>(b + L.o_counts);
   p.pair_mat = reinterpret_cast<uint2*>(b + L.o_counts);
@@ -2554,10 +2639,9 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const bool do_color = !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH);
   p.color_units = (uint32_t)((N + 63) / 64);
   const unsigned color_blocks = do_color ? p.color_units * (unsigned)d.num_sets : 0u;
-  // One stream, three launches: binning -> per-tile sorts + the colour pass riding in the same grid -> blend.  In profile
-  // mode (ev != null) the colour pass gets a launch of its own so that each stage is timed alone; it goes FIRST (it streams
-  // 90 MB through the caches; between binning and sort it would evict the keys the sort gathers).  gsr_forward_profile
-  // swaps the two durations back into stage order.
+  // One stream, three launches: binning -> per-tile sorts + the colour pass riding in the same grid -> blend.  Profile mode
+  // (ev != null) times exactly that chain, and - first, as an extra - a launch of the colour workgroups alone, so that the
+  // colour pass also has a time of its own (gsr_forward_profile moves it to stage 1; it is not part of the chain).
   GSR_MARK();
   if (ev && color_blocks) {
     Params pc = p;
@@ -2599,7 +2683,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   GSR_STAGE_DONE(2);
   GSR_MARK();
   p.sort_blocks = (uint32_t)VT;
-  const dim3 sgrid((unsigned)VT + (ev ? 0u : color_blocks));
+  const dim3 sgrid((unsigned)VT + color_blocks);
   if (fused_bin) {
     // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
     if (p.stride <= 2048u) hipLaunchKernelGGL((k_sort_tiles<true, 2048>), sgrid, dim3(kSortThreads), 0, st, p);
@@ -2627,8 +2711,8 @@ int gsr_forward(const GsrDims* dims, const GsrView* views, const float* means, c
 }
 
 // Measurement aid (bench.py): the same launch chain with a HIP event recorded on `stream` between its stages;
-// synchronises the stream and returns the GSR_FWD_STAGES stage durations in milliseconds
-// (preprocess+count, tile scan, emit, sort, blend).  Never used on the product path.
+// synchronises the stream and returns the GSR_FWD_STAGES stage durations in milliseconds (see include/gsr.h).
+// Never used on the product path.
 int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
                         const float* opacities, const float* colors, const float* extra, float* out_color,
                         float* out_extra, int32_t* radii, void* geom, void* bin, void* img, void* stream_,
@@ -2662,13 +2746,14 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   const GsrDims& d = *dims;
   const size_t V = d.num_views, N = d.num_gaussians;
   if (V == 0 || N == 0) return GSR_OK;
-  if (!views || !means || !cov6 || !opacities || !colors || !geom || !bin || !img || !dL_dcolor || !scratch ||
+  const bool own_rows = !scratch && (d.flags & GSR_FLAG_BACKWARD_FOLLOWS);  // zero-filled by the forward, inside geom
+  if (!views || !means || !cov6 || !opacities || !colors || !geom || !bin || !img || !dL_dcolor || (!scratch && !own_rows) ||
       !dL_dmeans || !dL_dcov6 || !dL_dopacities || !dL_dcolors)
     return GSR_ERR_INVALID_ARGUMENT;
   Params p = base_params(dims, views, means, cov6, opacities, colors, extra, const_cast<void*>(geom),
                          const_cast<void*>(bin), const_cast<void*>(img));
   p.dL_dcolor = dL_dcolor; p.dL_dextra_img = d.has_extra ? dL_dextra_img : nullptr;
-  p.scratch = static_cast<float*>(scratch);
+  p.scratch = own_rows ? reinterpret_cast<float*>(p.grad_rows) : static_cast<float*>(scratch);
   p.dL_dmeans = dL_dmeans; p.dL_dcov6 = dL_dcov6; p.dL_dopac = dL_dopacities; p.dL_dcolors = dL_dcolors;
   p.dL_dextra = d.has_extra ? dL_dextra : nullptr; p.dL_dmeans2D = dL_dmeans2D;
   hipEvent_t* ev = g_bwd_events;
@@ -2684,7 +2769,7 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   } while (0)
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const bool det = (d.flags & GSR_FLAG_DETERMINISTIC) != 0;
-  GSR_CHECK(hipMemsetAsync(scratch, 0, gsr_backward_scratch_bytes(dims), st));
+  if (!own_rows) GSR_CHECK(hipMemsetAsync(scratch, 0, gsr_backward_scratch_bytes(dims), st));
   const dim3 bgrid((unsigned)p.g.T, (unsigned)V);
   if (p.dL_dextra_img) {
     if (det) hipLaunchKernelGGL((k_blend_bwd<true, true>), bgrid, dim3(kBwdThreads), 0, st, p);
@@ -2737,6 +2822,18 @@ int gsr_setup_views(int num_views, const float* extrinsics, const float* intrins
   if (!extrinsics || !intrinsics || !near_ || !far_ || !background || !views) return GSR_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_setup_views, dim3((unsigned)((num_views + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream_),
                      num_views, extrinsics, intrinsics, near_, far_, background, background_stride, scale_invariant, views);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_setup_views_orthographic(int num_views, const float* extrinsics, const float* width, const float* height, const float* near_,
+                                 const float* far_, const float* background, int background_stride, float fov_degrees,
+                                 GsrView* views, float* dump, void* stream_) {
+  if (num_views < 0 || (background_stride != 0 && background_stride != 3) || !(fov_degrees > 0.f)) return GSR_ERR_INVALID_ARGUMENT;
+  if (num_views == 0) return GSR_OK;
+  if (!extrinsics || !width || !height || !near_ || !far_ || !background || !views) return GSR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_setup_views_ortho, dim3((unsigned)((num_views + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     num_views, extrinsics, width, height, near_, far_, background, background_stride, fov_degrees, views, dump);
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
 }

@@ -80,14 +80,10 @@ class DecoderSplattingCUDA(Decoder):
         mode: DepthRenderingMode = "depth",
     ) -> Tensor:  # (batch, view, height, width)
         b, v, _, _ = extrinsics.shape
-        g = gaussians.means.shape[1]
+        # the v views of a scene share the scene's one copy of the Gaussians (the reference repeats them v times, :79-86)
         result = render_depth_cuda(
             extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(b * v), far.reshape(b * v),
-            image_shape,
-            gaussians.means[:, None].expand(b, v, g, 3).reshape(b * v, g, 3),
-            gaussians.covariances[:, None].expand(b, v, g, 3, 3).reshape(b * v, g, 3, 3),
-            gaussians.opacities[:, None].expand(b, v, g).reshape(b * v, g),
-            mode=mode,
+            image_shape, gaussians.means, gaussians.covariances, gaussians.opacities, mode=mode,
         )
         h, w = image_shape
         return result.reshape(b, v, h, w)

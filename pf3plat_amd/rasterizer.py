@@ -199,7 +199,9 @@ class HipBackend:
                 else:
                     colors_shape = (s, n, 3)
             plan.update(
-                scratch=torch.empty(max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=u8, device=device),
+                # (a forward announced with FLAG_BACKWARD_FOLLOWS keeps the accumulator rows inside geom: no scratch, no zero-fill)
+                scratch=None if cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS else torch.empty(
+                    max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=u8, device=device),
                 d_means=torch.empty((s, n, 3), dtype=f32, device=device),
                 d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=device),
                 d_opac=torch.empty((s, n), dtype=f32, device=device),
@@ -332,14 +334,17 @@ class HipBackend:
             self.check_pending(only_ws=binb.data_ptr())
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
-                 want_means2d: bool):
+                 want_means2d: bool, rows_in_workspace: bool = False):
+        """rows_in_workspace: the forward ran with FLAG_BACKWARD_FOLLOWS and this is the first backward over it - accumulate
+        into the rows it zero-filled inside geom (no scratch, no zero-fill pass)."""
         dims, geom, binb, img = saved
         dev = viewbuf.device
         v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         f32 = torch.float32
         self._verify_own_forward(binb)
         plan = dict(cfg=cfg, dims=dims, device=dev, geom=geom, bin=binb, img=img,
-                    scratch=torch.empty(max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=torch.uint8, device=dev),
+                    scratch=None if (rows_in_workspace and cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) else torch.empty(
+                        max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=torch.uint8, device=dev),
                     d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
                     d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=dev),
                     d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
@@ -368,6 +373,30 @@ class HipBackend:
         if rc != 0:
             raise RuntimeError(f"gsr_setup_views failed with code {rc}")
         return out
+
+    def setup_views_orthographic(self, extrinsics, width, height, near, far, background, fov_degrees: float):
+        """Cameras of the reference's fake orthographic render (cuda_splatting.py:153-181) in one launch
+        (gsr_setup_views_orthographic) -> ((V,48) records, dict(extrinsics, fov_x, fov_y, near, far) after the move)."""
+        self._check_device(extrinsics, width, height, near, far, background)
+        v = extrinsics.shape[0]
+        f32 = torch.float32
+        c = lambda t: t.to(f32).contiguous()
+        ext, wd, ht, nr, fr, bg = c(extrinsics), c(width).reshape(v), c(height).reshape(v), c(near).reshape(v), c(far).reshape(v), c(background)
+        out = torch.empty((v, VIEW_FLOATS), dtype=f32, device=ext.device)
+        dump = torch.empty((v, 20), dtype=f32, device=ext.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(ext.device).cuda_stream)
+        with torch.cuda.device(ext.device):
+            rc = self.lib.gsr_setup_views_orthographic(v, _ptr(ext), _ptr(wd), _ptr(ht), _ptr(nr), _ptr(fr), _ptr(bg),
+                                                       3 if bg.dim() == 2 else 0, float(fov_degrees), _ptr(out), _ptr(dump), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_setup_views_orthographic failed with code {rc}")
+        moved = {"extrinsics": dump[:, :16].reshape(v, 4, 4), "fov_x": dump[0, 16], "fov_y": dump[:, 17], "near": dump[:, 18],
+                 "far": dump[:, 19]}
+        return out, moved
+
+    @property
+    def default_device(self):
+        return torch.device("cuda", torch.cuda.current_device())
 
     def mark_visible(self, cfg: RasterConfig, viewbuf, means):
         self._check_device(viewbuf, means)
@@ -414,6 +443,7 @@ class _RasterizeViews(torch.autograd.Function):
         color, extra_img, radii, saved = backend.forward(cfg, viewbuf, means, cov6, opac, colors, extra)
         ctx.cfg = cfg
         ctx.saved_ws = saved
+        ctx.rows_fresh = bool(cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS)  # accumulator rows zero-filled by the forward, usable once
         ctx.backend = backend
         ctx.want_means2d = means2d is not None
         ctx.save_for_backward(means, cov6, opac, colors, extra if extra is not None else torch.empty(0), viewbuf)
@@ -434,7 +464,9 @@ class _RasterizeViews(torch.autograd.Function):
         if g_color is None:
             g_color = torch.zeros((cfg.num_views, 3, cfg.height, cfg.width), dtype=torch.float32, device=means.device)
         d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
-            cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d)
+            cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d,
+            rows_in_workspace=ctx.rows_fresh)
+        ctx.rows_fresh = False
         # the workspaces stay with ctx (freed with the graph): a second backward (retain_graph=True, several autograd.grad
         # calls over one render) runs on them again, as upstream's Function can
         return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, None, None
@@ -480,6 +512,8 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
         deterministic = torch.are_deterministic_algorithms_enabled()
     flags |= (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_PREFILTERED if prefiltered else 0)
     flags |= _lib.FLAG_DETERMINISTIC if deterministic else 0
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (means, cov6, opacities, colors, extra, means2d)):
+        flags |= _lib.FLAG_BACKWARD_FOLLOWS  # the forward zero-fills the backward's accumulator rows on its way
     if extra_mode is not None:
         if extra is not None:
             raise ValueError("give either `extra` or `extra_mode`")

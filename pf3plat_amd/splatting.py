@@ -20,40 +20,16 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from .geometry import depth_to_relative_disparity, get_fov, get_projection_matrix, homogenize_points
-from .rasterizer import get_backend, pack_views, rasterize_views
+from .rasterizer import get_backend, rasterize_views
 from .types import DepthRenderingMode
-
-def _cameras(extrinsics, intrinsics, near, far, scale_invariant: bool):
-    """Shared camera set-up of render_cuda (reference :64-71, :80-87): returns per-view
-    (view_matrix^T, full_projection^T, campos, tan_fov_x, tan_fov_y, scale)."""
-    if scale_invariant:
-        scale = 1 / near
-        extrinsics = extrinsics.clone()
-        extrinsics[..., :3, 3] = extrinsics[..., :3, 3] * scale[:, None]
-        near = near * scale
-        far = far * scale
-    else:
-        scale = torch.ones_like(near)
-    fov_x, fov_y = get_fov(intrinsics).unbind(dim=-1)
-    tan_fov_x = (0.5 * fov_x).tan()
-    tan_fov_y = (0.5 * fov_y).tan()
-    projection_matrix = get_projection_matrix(near, far, fov_x, fov_y).transpose(-1, -2)
-    view_matrix = extrinsics.inverse().transpose(-1, -2)
-    full_projection = view_matrix @ projection_matrix
-    return view_matrix, full_projection, extrinsics[:, :3, 3], tan_fov_x, tan_fov_y, scale
 
 
 def _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invariant: bool) -> Tensor:
-    """Camera records for `rasterize_views`: one `gsr_setup_views` launch when the backend has it (the HIP library), else the
-    batched torch ops above (the arithmetic of the reference wrapper; used by the CPU tests)."""
+    """Camera records for `rasterize_views`: the arithmetic of the reference wrapper at cuda_splatting.py:64-71 / :80-87
+    (1 / near rescale, get_fov, get_projection_matrix, extrinsics.inverse(), view @ proj) in ONE launch of the raster
+    library (`gsr_setup_views`), straight into the records the kernels read.  Cameras carry no gradient (settings object)."""
     with torch.no_grad():
-        backend = get_backend()
-        if hasattr(backend, "setup_views"):
-            return backend.setup_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
-        view_matrix, full_projection, campos, tan_x, tan_y, scale = _cameras(extrinsics, intrinsics, near, far, scale_invariant)
-        bg = background_color if background_color.dim() == 2 else background_color.reshape(1, 3).expand(extrinsics.shape[0], 3)
-        return pack_views(view_matrix, full_projection, campos, tan_x, tan_y, bg, scale, near=near, far=far)
+        return get_backend().setup_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
 
 
 def render_cuda(
@@ -101,53 +77,20 @@ def render_cuda_orthographic(
 ) -> Tensor:
     """Fake orthographic projection: camera moved back, tiny field of view (reference :130-220).
     Keeps the reference's `fov_y = atan(2 tan_fov_y)` quirk (:160)."""
-    b, _, _ = extrinsics.shape
     assert use_sh or gaussian_sh_coefficients.shape[-1] == 1
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
     with torch.no_grad():
-        fov_x = torch.tensor(fov_degrees, device=extrinsics.device).deg2rad()
-        tan_fov_x = (0.5 * fov_x).tan()
-        distance_to_near = (0.5 * width) / tan_fov_x
-        tan_fov_y = 0.5 * height / distance_to_near
-        fov_y = (2 * tan_fov_y).atan()
-        near = near + distance_to_near
-        far = far + distance_to_near
-        move_back = torch.eye(4, dtype=torch.float32, device=extrinsics.device).repeat(b, 1, 1)
-        move_back[:, 2, 3] = -distance_to_near
-        extrinsics = extrinsics @ move_back
-        if dump is not None:
-            dump["extrinsics"] = extrinsics
-            dump["fov_x"] = fov_x
-            dump["fov_y"] = fov_y
-            dump["near"] = near
-            dump["far"] = far
-        projection_matrix = get_projection_matrix(near, far, fov_x.expand(b), fov_y).transpose(-1, -2)
-        view_matrix = extrinsics.inverse().transpose(-1, -2)
-        full_projection = view_matrix @ projection_matrix
-        viewbuf = pack_views(view_matrix, full_projection, extrinsics[:, :3, 3], tan_fov_x.expand(b),
-                             tan_fov_y.expand(b) if tan_fov_y.dim() == 0 else tan_fov_y, background_color, None)
+        viewbuf, moved = get_backend().setup_views_orthographic(extrinsics, width, height, near, far, background_color,
+                                                                float(fov_degrees))
+    if dump is not None:
+        dump.update(moved)  # extrinsics (b, 4, 4) after the move, fov_x (scalar), fov_y / near / far (b,)
     # harmonics (b, g, 3, d_sh) and covariances (b, g, 3, 3) go to the operator as they are (as in render_cuda)
     colors = gaussian_sh_coefficients if use_sh else gaussian_sh_coefficients[:, :, :, 0]
     color, _, _ = rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, colors, viewbuf,
         image_shape=image_shape, sh_degree=degree, use_sh=use_sh, views_per_set=1, sh_planar=True, cov_3x3=True)
     return color
-
-
-def depth_fake_color(extrinsics: Tensor, gaussian_means: Tensor, near: Tensor, far: Tensor,
-                     mode: DepthRenderingMode) -> Tensor:
-    """Per-(view, Gaussian) scalar that the depth render blends (reference :238-251): camera-space z in
-    un-normalised units, mapped by `mode` (the `log` mode keeps the reference's min/max quirk, :251)."""
-    camera_space = torch.einsum("bij,bgj->bgi", extrinsics.inverse(), homogenize_points(gaussian_means))
-    fake_color = camera_space[..., 2]
-    if mode == "disparity":
-        fake_color = 1 / fake_color
-    elif mode == "relative_disparity":
-        fake_color = depth_to_relative_disparity(fake_color, near[:, None], far[:, None])
-    elif mode == "log":
-        fake_color = fake_color.minimum(near[:, None]).maximum(far[:, None]).log()
-    return fake_color
 
 
 def render_depth_cuda(
@@ -167,15 +110,21 @@ def render_depth_cuda(
     is blended here once, as the extra channel of a colour-less pass, with f(z) (`depth_fake_color`
     below states it in torch) evaluated inside the kernels.  Gaussians receive the same gradients as in
     the reference; the (unused) gradient the reference's torch graph sends to `extrinsics` through
-    `extrinsics.inverse()` is not produced."""
-    b, g = gaussian_opacities.shape
+    `extrinsics.inverse()` is not produced.
+
+    `gaussian_*` may hold ONE copy of the Gaussians per scene while the cameras hold `views_per_scene` views per scene
+    (batch = scenes x views_per_scene, scene-major): the views of a scene then share that copy, as in `render_views`."""
+    b = extrinsics.shape[0]
+    sets, g = gaussian_opacities.shape
+    if b % max(sets, 1) != 0:
+        raise ValueError(f"{b} cameras cannot be split over {sets} Gaussian sets")
     dev = gaussian_means.device
-    bg = torch.zeros((b, 3), dtype=torch.float32, device=dev)
-    viewbuf = _viewbuf(extrinsics, intrinsics, near, far, bg, scale_invariant)
-    zero_rgb = torch.zeros((b, g, 3), dtype=torch.float32, device=dev)
+    viewbuf = _viewbuf(extrinsics, intrinsics, near, far, torch.zeros(3, dtype=torch.float32, device=dev), scale_invariant)
+    # no colour is wanted: one shared zero colour row per set costs nothing to blend next to the depth channel
+    zero_rgb = torch.zeros((1, 1, 3), dtype=torch.float32, device=dev).expand(sets, g, 3)
     _, depth, _ = rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, zero_rgb, viewbuf,
-        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=1, extra_mode=mode, cov_3x3=True)
+        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=b // max(sets, 1), extra_mode=mode, cov_3x3=True)
     return depth
 
 

@@ -118,12 +118,13 @@ def scene_operator_inputs(scene: Scene, use_sh: bool = True):
 
 
 def scene_viewbuf(scene: Scene, scale_invariant: bool = True) -> Tensor:
-    """Camera records (V, 48) of a Scene, built by the same camera set-up `render_cuda` uses."""
-    from .rasterizer import pack_views
-    from .splatting import _cameras
+    """Camera records (V, 48) of a Scene on the raster backend's device: one `setup_views` launch, as `render_cuda` does."""
+    from .rasterizer import get_backend
 
     s, v = scene.extrinsics.shape[:2]
-    vm, fp, cp, tx, ty, sc = _cameras(scene.extrinsics.reshape(s * v, 4, 4), scene.intrinsics.reshape(s * v, 3, 3),
-                                      scene.near.reshape(s * v), scene.far.reshape(s * v), scale_invariant)
-    return pack_views(vm, fp, cp, tx, ty, scene.background.reshape(1, 3).expand(s * v, 3), sc,
-                      near=scene.near.reshape(s * v), far=scene.far.reshape(s * v))
+    backend = get_backend()
+    dev = scene.extrinsics.device if scene.extrinsics.is_cuda else getattr(backend, "default_device", scene.extrinsics.device)
+    mv = lambda t: t.to(dev)
+    return backend.setup_views(mv(scene.extrinsics.reshape(s * v, 4, 4)), mv(scene.intrinsics.reshape(s * v, 3, 3)),
+                               mv(scene.near.reshape(s * v)), mv(scene.far.reshape(s * v)), mv(scene.background.reshape(3)),
+                               scale_invariant)

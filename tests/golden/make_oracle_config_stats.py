@@ -15,6 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 from pf3plat_amd import synthetic  # noqa: E402
 from pf3plat_amd.rasterizer import RasterConfig  # noqa: E402
+from tests import gpu_util  # noqa: E402
 from tests.oracle_backend import OracleBackend  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle_config_stats.json")
@@ -25,7 +26,7 @@ def stats_of(name):
     seed, n, hw = CONFIGS[name]
     sc = synthetic.make_scene(seed, n, hw)
     means, cov6, opac, shs = synthetic.scene_operator_inputs(sc)
-    vb = synthetic.scene_viewbuf(sc)
+    vb = gpu_util.scene_viewbuf(sc)
     cfg = RasterConfig(1, 1, 1, n, hw[0], hw[1], 4, 25, 4, False)
     ob = OracleBackend(dtype=np.float32, threads=min(16, os.cpu_count() or 8))
     color, _, radii, _ = ob.forward(cfg, vb, means, cov6, opac, shs, None)

@@ -101,6 +101,10 @@ def scene_tensors(scene, use_sh=True):
 
 
 def scene_viewbuf(scene, scale_invariant=True):
-    from pf3plat_amd.synthetic import scene_viewbuf as _svb
-
-    return _svb(scene, scale_invariant)
+    """Camera records (V, 48) of a Scene as a CPU tensor, built by the oracle's camera arithmetic (oracle/cameras.py): both
+    sides of a parity test render with exactly these records, so the raster path is what is compared (the device camera
+    set-up has its own test against the same functions)."""
+    s, v = scene.extrinsics.shape[:2]
+    return OracleBackend().setup_views(scene.extrinsics.reshape(s * v, 4, 4), scene.intrinsics.reshape(s * v, 3, 3),
+                                       scene.near.reshape(s * v), scene.far.reshape(s * v), scene.background.reshape(3),
+                                       scale_invariant)

@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from oracle import OracleRasterizer
+from oracle import OracleRasterizer, cameras
 
 
 class OracleBackend:
@@ -101,7 +101,8 @@ class OracleBackend:
         self.last_stats = stats
         return color, extra_img, radii, handles
 
-    def backward(self, cfg, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d):
+    def backward(self, cfg, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d,
+                 rows_in_workspace=False):
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         V, N, S = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         d_means = torch.zeros((S, N, 3), dtype=tdt)
@@ -139,6 +140,23 @@ class OracleBackend:
             d_cov6 = d9
         assert tuple(d_colors.shape) == colors_in_shape
         return d_means, d_cov6, d_opac, d_colors, d_extra, d_m2d
+
+    # ---- camera set-up: the reference wrapper's arithmetic as restated in oracle/cameras.py (numpy fp32)
+    default_device = torch.device("cpu")
+
+    @staticmethod
+    def _np(t):
+        return t.detach().cpu().numpy().astype(np.float32)
+
+    def setup_views(self, extrinsics, intrinsics, near, far, background, scale_invariant=True):
+        rec = cameras.view_records(self._np(extrinsics), self._np(intrinsics), self._np(near), self._np(far), self._np(background),
+                                   bool(scale_invariant))
+        return torch.from_numpy(rec)
+
+    def setup_views_orthographic(self, extrinsics, width, height, near, far, background, fov_degrees):
+        rec, moved = cameras.view_records_orthographic(self._np(extrinsics), self._np(width), self._np(height), self._np(near),
+                                                       self._np(far), self._np(background), float(fov_degrees))
+        return torch.from_numpy(rec), {k: torch.from_numpy(np.asarray(v)) for k, v in moved.items()}
 
     def mark_visible(self, cfg, viewbuf, means):
         out = torch.zeros((cfg.num_sets, cfg.num_gaussians), dtype=torch.bool)

@@ -62,9 +62,10 @@ def test_flag_bits_are_validated_and_ablation_switches_are_not_in_the_product_li
     be = rasterizer.HipBackend()
     z = ctypes.c_size_t()
     sizes = lambda d: lib.gsr_workspace_sizes(ctypes.byref(d), ctypes.byref(z), ctypes.byref(z), ctypes.byref(z))
-    ok = _lib.FLAG_PREFILTERED | _lib.FLAG_DEBUG | _lib.FLAG_SH_PLANAR | _lib.FLAG_COV_3X3 | _lib.FLAG_DETERMINISTIC | (4 << 4)
+    ok = (_lib.FLAG_PREFILTERED | _lib.FLAG_DEBUG | _lib.FLAG_SH_PLANAR | _lib.FLAG_COV_3X3 | _lib.FLAG_DETERMINISTIC |
+          _lib.FLAG_BACKWARD_FOLLOWS | (4 << 4))
     assert sizes(be._dims(rasterizer.RasterConfig(1, 1, 1, 100, 16, 16, 4, 25, 4, True, ok), 1000)) == 0
-    for bad in (0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x8000, 0x10000, 1 << 30, 5 << 4, 7 << 4):
+    for bad in (0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x8000, 0x20000, 1 << 30, 5 << 4, 7 << 4):
         assert sizes(be._dims(rasterizer.RasterConfig(1, 1, 1, 100, 16, 16, 4, 25, 4, True, bad), 1000)) == -1, hex(bad)
     hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
     product, _, _ = hdr.partition("#ifdef GSR_ABLATE")
@@ -75,6 +76,13 @@ def test_flag_bits_are_validated_and_ablation_switches_are_not_in_the_product_li
     d = be._dims(rasterizer.RasterConfig(2, 1, 2, 100, 16, 16, 4, 25, 4, False, _lib.FLAG_DETERMINISTIC), 1000)
     assert lib.gsr_backward_scratch_bytes(ctypes.byref(d)) == 2 * 100 * 12 * 8
     assert lib.gsr_last_failed_stage() == -1
+    # a forward that announces its backward keeps the accumulator rows inside geom
+    plain, with_rows = ctypes.c_size_t(), ctypes.c_size_t()
+    d0 = be._dims(rasterizer.RasterConfig(2, 1, 2, 100, 16, 16, 4, 25, 4, False), 1000)
+    d1 = be._dims(rasterizer.RasterConfig(2, 1, 2, 100, 16, 16, 4, 25, 4, False, _lib.FLAG_BACKWARD_FOLLOWS), 1000)
+    assert lib.gsr_workspace_sizes(ctypes.byref(d0), ctypes.byref(plain), ctypes.byref(z), ctypes.byref(z)) == 0
+    assert lib.gsr_workspace_sizes(ctypes.byref(d1), ctypes.byref(with_rows), ctypes.byref(z), ctypes.byref(z)) == 0
+    assert with_rows.value - plain.value >= 2 * 100 * 12 * 4
 
 
 def test_no_cpu_fallback_path():

@@ -11,6 +11,7 @@ import torch
 
 from pf3plat_amd import synthetic
 from pf3plat_amd.rasterizer import RasterConfig
+from tests import gpu_util
 from tests.golden.make_oracle_config_stats import CONFIGS, stats_of
 
 GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_config_stats.json")))
@@ -35,7 +36,7 @@ def test_hip_lands_on_the_committed_statistics(name):
     dev = torch.device("cuda:0")
     sc = synthetic.make_scene(seed, n, hw)
     means, cov6, opac, shs = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
-    vb = synthetic.scene_viewbuf(sc).to(dev)
+    vb = gpu_util.scene_viewbuf(sc).to(dev)
     cfg = RasterConfig(1, 1, 1, n, hw[0], hw[1], 4, 25, 4, False)
     color, _, radii, _ = HipBackend().forward(cfg, vb, means, cov6, opac, shs, None)
     img = color.cpu().numpy().astype(np.float64)

@@ -239,11 +239,11 @@ def test_per_view_rasterizer_upstream_signature():
     assert rel_l2(g[9], o[9]) < 1e-4 and rel_l2(g[9], g[6]) > 1e-2  # scale_modifier reaches the covariance
 
 
-def test_setup_views_kernel_matches_reference_camera_arithmetic():
-    """gsr_setup_views (one launch) == the wrapper's batched torch ops (which tests/test_wrapper_fixtures.py pins to the
-    reference's cuda_splatting.py:64-87), for rotated/translated cameras, off-centre principal points and both scale modes."""
-    from pf3plat_amd.rasterizer import pack_views
-    from pf3plat_amd.splatting import _cameras
+def test_setup_views_kernels_match_the_oracle_camera_arithmetic():
+    """gsr_setup_views / gsr_setup_views_orthographic (one launch each) == oracle/cameras.py (which tests/test_wrapper_fixtures.py
+    pins to the reference's cuda_splatting.py:64-87 and :153-181), for rotated/translated cameras, off-centre principal
+    points, both scale modes, and the orthographic move-back with its dump values."""
+    from oracle import cameras
     from tests.util import look_at_c2w
 
     v = 5
@@ -260,8 +260,16 @@ def test_setup_views_kernel_matches_reference_camera_arithmetic():
     be = rasterizer.get_backend()
     for si in (True, False):
         got = be.setup_views(ext.to(DEV), intr.to(DEV), near.to(DEV), far.to(DEV), bg.to(DEV), si).cpu()
-        vm, fp, cp, tx, ty, sc = _cameras(ext, intr, near, far, si)
-        want = pack_views(vm, fp, cp, tx, ty, bg, sc, near=near, far=far)
-        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+        want = cameras.view_records(ext.numpy(), intr.numpy(), near.numpy(), far.numpy(), bg.numpy(), si)
+        np.testing.assert_allclose(got.numpy(), want, rtol=2e-5, atol=2e-6)
     one_bg = be.setup_views(ext.to(DEV), intr.to(DEV), near.to(DEV), far.to(DEV), bg[0].to(DEV), True).cpu()
     assert torch.allclose(one_bg[:, 37:40], bg[0].expand(v, 3))
+    width, height = 4 + 4 * torch.rand(v, generator=gen), 3 + 4 * torch.rand(v, generator=gen)
+    for fov in (10.0, 0.1):
+        got, dump = be.setup_views_orthographic(ext.to(DEV), width.to(DEV), height.to(DEV), near.to(DEV), far.to(DEV), bg.to(DEV), fov)
+        want, wdump = cameras.view_records_orthographic(ext.numpy(), width.numpy(), height.numpy(), near.numpy(), far.numpy(),
+                                                        bg.numpy(), fov)
+        # the tiny field of view makes distances ~1e3..1e5: compare relative to the size of each record's entries
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
+        for k in ("extrinsics", "fov_x", "fov_y", "near", "far"):
+            np.testing.assert_allclose(dump[k].cpu().numpy(), wdump[k], rtol=1e-5, atol=1e-6, err_msg=k)

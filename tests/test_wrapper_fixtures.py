@@ -30,10 +30,10 @@ def ref_calls(prefix):
     return out
 
 
-def check_call(ours, ref, colour_key):
-    np.testing.assert_allclose(ours["viewmatrix"].reshape(4, 4), ref["viewmatrix"], **TOL)
-    np.testing.assert_allclose(ours["projmatrix"].reshape(4, 4), ref["projmatrix"], **TOL)
-    np.testing.assert_allclose(ours["campos"], ref["campos"], **TOL)
+def check_call(ours, ref, colour_key, cam_tol=TOL):
+    np.testing.assert_allclose(ours["viewmatrix"].reshape(4, 4), ref["viewmatrix"], **cam_tol)
+    np.testing.assert_allclose(ours["projmatrix"].reshape(4, 4), ref["projmatrix"], **cam_tol)
+    np.testing.assert_allclose(ours["campos"], ref["campos"], **cam_tol)
     np.testing.assert_allclose([ours["tanfovx"], ours["tanfovy"]], ref["tanfov"], **TOL)
     np.testing.assert_allclose(ours["bg"], ref["bg"], **TOL)
     assert (ours["height"], ours["width"]) == tuple(ref["hw"])
@@ -107,7 +107,8 @@ def test_case_e_orthographic_with_dump(oracle_backend):
                                          fov_degrees=10.0, dump=dump)
     for k in ("extrinsics", "fov_x", "fov_y", "near", "far"):
         np.testing.assert_allclose(dump[k].numpy(), FIX["E_dump_" + k], **TOL)
-    check_call(oracle_backend.calls[0][0], ref_calls("E_")[0], "shs")
+    # the camera sits ~23 units back: one fp32 ulp of its translation row is 1.9e-6, the size of TOL itself - two ulps allowed
+    check_call(oracle_backend.calls[0][0], ref_calls("E_")[0], "shs", cam_tol=dict(rtol=4e-6, atol=4e-6))
 
 
 def test_case_f_decoder_three_views_colour_and_depth_in_one_call(oracle_backend):

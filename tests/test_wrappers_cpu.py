@@ -115,8 +115,19 @@ def test_mark_visible_and_empty_scene(oracle_backend):
 def test_builtin_depth_channel_equals_explicit_fake_colour(oracle_backend, mode):
     """extra_mode (f(z) evaluated by the operator, gradient folded into d_means) == the reference's formulation: f(z) as an
     explicit torch tensor (depth_fake_color, cuda_splatting.py:238-251) blended as an extra array, autograd doing the chain."""
+    from pf3plat_amd.geometry import depth_to_relative_disparity, homogenize_points
     from pf3plat_amd.rasterizer import rasterize_views
-    from pf3plat_amd.splatting import _viewbuf, depth_fake_color
+    from pf3plat_amd.splatting import _viewbuf
+
+    def depth_fake_color(extrinsics, means, near, far, mode):  # the scalar the reference blends, cuda_splatting.py:238-251
+        z = torch.einsum("bij,bgj->bgi", extrinsics.inverse(), homogenize_points(means))[..., 2]
+        if mode == "disparity":
+            return 1 / z
+        if mode == "relative_disparity":
+            return depth_to_relative_disparity(z, near[:, None], far[:, None])
+        if mode == "log":
+            return z.minimum(near[:, None]).maximum(far[:, None]).log()
+        return z
 
     sc = synthetic.make_scene(6, 200, (16, 20), num_views=2, near=1.7)
     ext, intr, nr, fr = sc.extrinsics[0], sc.intrinsics[0], sc.near[0], sc.far[0]
@@ -137,19 +148,18 @@ def test_builtin_depth_channel_equals_explicit_fake_colour(oracle_backend, mode)
         assert rel_l2(a, b) < 5e-5, (mode, name, rel_l2(a, b))
 
 
-def test_gaussians_container_helpers():
-    import pytest
-    import torch
-
-    from pf3plat_amd.types import Gaussians
-
-    g = Gaussians(torch.zeros(2, 5, 3), torch.zeros(2, 5, 3, 3), torch.zeros(2, 5, 3, 25), torch.ones(2, 5))
-    assert (g.num_scenes, g.num_gaussians, g.d_sh, g.sh_degree) == (2, 5, 25, 4)
-    c = g.check().clone()
-    c.means += 1
-    assert float(g.means.sum()) == 0 and float(c.means.sum()) == 30
-    assert g.to(torch.float64).harmonics.dtype == torch.float64 and not g.detach().means.requires_grad
-    with pytest.raises(ValueError, match="covariances"):
-        Gaussians(g.means, torch.zeros(2, 5, 6), g.harmonics, g.opacities).check()
-    with pytest.raises(ValueError, match="harmonics"):
-        Gaussians(g.means, g.covariances, torch.zeros(2, 5, 3, 24), g.opacities).check()
+def test_render_depth_shares_one_gaussian_copy_between_the_views_of_a_scene(oracle_backend):
+    """render_depth_cuda with (scenes x views) cameras and ONE set of Gaussians per scene == the reference's shape (Gaussians
+    repeated per view), and the decoder's render_depth makes no per-view copies of the Gaussians."""
+    sc = synthetic.make_scene(7, 150, (16, 16), num_views=3, near=1.3)
+    g = sc.gaussians
+    ext, intr, nr, fr = sc.extrinsics[0], sc.intrinsics[0], sc.near[0], sc.far[0]
+    shared = pf3plat_amd.render_depth_cuda(ext, intr, nr, fr, (16, 16), g.means, g.covariances, g.opacities, mode="disparity")
+    rep = lambda t: t.expand(3, *t.shape[1:]).contiguous()
+    repeated = pf3plat_amd.render_depth_cuda(ext, intr, nr, fr, (16, 16), rep(g.means), rep(g.covariances), rep(g.opacities),
+                                             mode="disparity")
+    assert shared.shape == (3, 16, 16) and torch.equal(shared, repeated)
+    oracle_backend.record = True
+    dec = pf3plat_amd.DecoderSplattingCUDA()
+    d = dec.render_depth(g, sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 16), mode="disparity")
+    assert torch.equal(d[0], shared) and len(oracle_backend.calls) == 1 and len(oracle_backend.calls[0]) == 3

@@ -7,20 +7,18 @@ import math
 import numpy as np
 import torch
 
-from pf3plat_amd.geometry import get_fov, get_projection_matrix
+from oracle import cameras
 
 
 def make_camera(c2w=None, fx=0.86, fy=0.86, cx=0.5, cy=0.5, near=1.0, far=100.0, dtype=np.float64):
-    """Returns dict(viewmatrix, projmatrix, campos, tanfovx, tanfovy) as numpy (transposed matrices)."""
-    c2w = torch.eye(4) if c2w is None else torch.as_tensor(c2w, dtype=torch.float32)
-    k = torch.tensor([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], dtype=torch.float32)[None]
-    fov_x, fov_y = get_fov(k).unbind(-1)
-    proj = get_projection_matrix(torch.tensor([near]), torch.tensor([far]), fov_x, fov_y)[0].T
-    view = c2w.inverse().T
-    full = view @ proj
-    return dict(viewmatrix=view.numpy().astype(dtype).reshape(16), projmatrix=full.numpy().astype(dtype).reshape(16),
-                campos=c2w[:3, 3].numpy().astype(dtype), tanfovx=float((0.5 * fov_x).tan()),
-                tanfovy=float((0.5 * fov_y).tan()))
+    """Returns dict(viewmatrix, projmatrix, campos, tanfovx, tanfovy) as numpy (transposed matrices), built by the oracle's
+    camera arithmetic (oracle/cameras.py; no scale-invariant rescale)."""
+    c2w = np.eye(4, dtype=np.float32) if c2w is None else np.asarray(c2w, dtype=np.float32)
+    k = np.array([[[fx, 0, cx], [0, fy, cy], [0, 0, 1]]], dtype=np.float32)
+    rec = cameras.view_records(c2w[None], k, np.array([near], np.float32), np.array([far], np.float32), np.zeros(3, np.float32),
+                               scale_invariant=False)[0]
+    return dict(viewmatrix=rec[0:16].astype(dtype), projmatrix=rec[16:32].astype(dtype), campos=rec[32:35].astype(dtype),
+                tanfovx=float(rec[35]), tanfovy=float(rec[36]))
 
 
 def look_at_c2w(eye, target=(0, 0, 5.0), up=(0, -1.0, 0)):

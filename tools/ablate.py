@@ -169,8 +169,35 @@ def bwd_phases():
           f" | total {q0(raw[:, 4] - raw[:, 0])} | kernel span {(raw[:, 4].max() - raw[:, 0].min()).item():.2f} | start skew {q0(raw[:, 0] - raw[:, 0].min())}", flush=True)
 
 
+def bwd_ablate():
+    """Backward stage times with and without the per-splat atomics of the blend backward."""
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 300000
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(2, n, (256, 256))
+    means, cov6, opac, shs = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
+    vb = synthetic.scene_viewbuf(sc).to(dev)
+    cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False)
+    be = HipBackend()
+    plan = be.make_plan(cfg, dev, capacity=8 * n, backward=True)
+    be.run_forward(plan, vb, means, cov6, opac, shs)
+    plan = be.make_plan(cfg, dev, capacity=be.capacity_for(cfg, be.read_status(plan), headroom=1.1), backward=True)
+    g = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(3)).to(dev)
+    be.run_forward(plan, vb, means, cov6, opac, shs)
+    for name, fl in (("baseline", 0), ("bwd_no_atomic", 0x8000)):
+        plan["dims"].flags = fl
+        acc = {}
+        for it in range(25):
+            ms = be.run_backward(plan, vb, means, cov6, opac, shs, None, g, profile=True)
+            if it >= 5:
+                for k, v in ms.items():
+                    acc[k] = acc.get(k, 0.0) + v / 20
+        print(f"{name:20s}", {k: round(v * 1e3, 1) for k, v in acc.items()}, "us", flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 2 and sys.argv[2] == "bwd":
+    if len(sys.argv) > 2 and sys.argv[2] == "bwdabl":
+        bwd_ablate()
+    elif len(sys.argv) > 2 and sys.argv[2] == "bwd":
         bwd_phases()
     else:
         main()

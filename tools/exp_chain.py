@@ -40,6 +40,9 @@ def main():
     img = plan["color"].double()
     out = f"{label:28s} fwd {best * 1e6:7.2f} us/step  image sum {img.sum().item():.6f} absmax {img.abs().max().item():.6f} finite {bool(torch.isfinite(img).all())} status {st}"
     if len(sys.argv) > 3:
+        from pf3plat_amd import _lib
+        cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False, _lib.FLAG_BACKWARD_FOLLOWS)
+        plan = be.make_plan(cfg, dev, capacity=int(plan["dims"].pair_capacity), backward=True)
         g = torch.rand((1, 3, 256, 256), generator=torch.Generator().manual_seed(3)).to(dev)
         for _ in range(5):
             be.run_forward(plan, vb, means, cov6, opac, shs)
