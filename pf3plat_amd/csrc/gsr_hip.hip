@@ -1830,6 +1830,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   __shared__ float4 sGeo[4][kBB];   // x, y, a2, b2
   __shared__ float4 sGeo2[4][kBB];  // c2, opacity, id bits, 0
   __shared__ float4 sCol[4][kBB];   // r, g, b, extra
+  __shared__ __attribute__((aligned(16))) float sG[4][64];  // dL/dpixel (r, g, b, extra) of the tile's 64 pixels
   const Grid& g = p.g;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v = blockIdx.y;
@@ -1863,13 +1864,10 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   // ---- lane = (entry, pixel row) view (stage R): dL/dpixel of this lane's row of 8 pixels
   const int er = lane >> 3, pr = lane & 7;
   const int rpy = ty * 8 + pr, rpx0 = tx * 8;
-  float rg0[8], rg1[8], rg2[8], rge[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const bool in = (rpx0 + k < g.W) && (rpy < g.H);
-    const size_t q = (size_t)rpy * g.W + rpx0 + k;
-    rg0[k] = in ? dcol[q] : 0.f; rg1[k] = in ? dcol[HW + q] : 0.f; rg2[k] = in ? dcol[2 * HW + q] : 0.f;
-    rge[k] = (kExtra && in) ? dext[q] : 0.f;
+  // dL/dpixel of the tile for that view, by channel, in LDS (1 KB): 24 - 32 registers per lane as arrays
+  if (wave == 0) {
+    sG[0][lane] = g0; sG[1][lane] = g1; sG[2][lane] = g2;
+    if (kExtra) sG[3][lane] = ge;
   }
   const float hW = 0.5f * (float)g.W, hH = 0.5f * (float)g.H;
 
@@ -1946,8 +1944,17 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     const float4 a = sGeo[ring][e0 + er], a2 = sGeo2[ring][e0 + er];
     const float wk[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
     const float qk[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+    auto row8 = [&](int c, float (&o)[8]) {
+      const float4 x = *reinterpret_cast<const float4*>(&sG[c][8 * pr]), y = *reinterpret_cast<const float4*>(&sG[c][8 * pr + 4]);
+      o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
+    };
+    float rg0[8], rg1[8], rg2[8], rge[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    row8(0, rg0); row8(1, rg1); row8(2, rg2);
+    if (kExtra) row8(3, rge);
     // Only the moments of q = G dL/dalpha are accumulated per pixel; opacity and conic enter after the reduction because
     // dL/dG = o dL/dalpha and dG/ddelx = ln2 (2 a2 gdx + b2 gdy), dG/ddely = ln2 (2 c2 gdy + b2 gdx) are linear in them.
+    // (Two pixels per packed-fp32 instruction was tried here: 5 % fewer instructions, but the register pairs it needs push
+    // the kernel past its 128 registers - the spills cost more than the packing saves.)
     float S0 = 0, Sx = 0, Sxx = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
     const float dx0 = a.x - (float)rpx0, dy = a.y - (float)rpy;
 #pragma unroll
@@ -2077,7 +2084,26 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     load_row(0, sg_first);
   }
   if (M > 0) {
-    stage_rows(sh_in, p.colors + ((size_t)set * N + g0) * rowf, cnt, rowf, ldstride, lane);
+    const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
+    const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
+    if (ldstride == rowf && ((((uintptr_t)sh_src) & 15) == 0)) {
+      // all of the wave's 64 x 3M floats requested before the first one is parked in LDS: one memory latency, not nineteen
+      constexpr int kPre = 19;  // 64 * 75 / 4 / 64 = 18.75
+      float4 pre[kPre];
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        const int k = lane + 64 * q;
+        pre[q] = (k < sh_n4) ? reinterpret_cast<const float4*>(sh_src)[k] : make_float4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int q = 0; q < kPre; ++q) {
+        const int k = lane + 64 * q;
+        if (k < sh_n4) reinterpret_cast<float4*>(sh_in)[k] = pre[q];
+      }
+      for (int k = (sh_n4 << 2) + lane; k < sh_total; k += 64) sh_in[k] = sh_src[k];
+    } else {
+      stage_rows(sh_in, sh_src, cnt, rowf, ldstride, lane);
+    }
     __syncthreads();
   }
   // With one view per set the SH gradient of coefficient k can take the LDS slot of coefficient k as soon as the mean
