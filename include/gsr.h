@@ -165,6 +165,24 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
                  void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
                  float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream);
 
+/* The same two calls with the covariances in the form PF3plat's encoder produces them (reference
+ * src/model/encoder/common/gaussian_adapter.py:63-83, gaussians.py:8-44): `scale_rot` (num_sets, N, 7) = scale x, y, z and a
+ * quaternion x, y, z, w; Sigma = M diag(scale^2) M^T with M = F Rq, Rq the rotation of the quaternion (normalised through
+ * two_s = 2 / (|q|^2 + 1e-8), as quaternion_to_matrix does) and F an optional rotation into world space: `frames`
+ * (num_sets, num_frames, 3, 3), the N Gaussians of a set being num_frames equal consecutive groups (one per source view:
+ * the camera-to-world rotation of gaussian_adapter.py:81-83); NULL / 0 = no frame.  The covariance is built in registers
+ * on load - no (N, 3, 3) array exists - and the backward returns dL_dscale_rot (num_sets, N, 7) directly.  GSR_FLAG_COV_3X3 does
+ * not apply.  Everything else as in gsr_forward / gsr_backward. */
+int gsr_forward_scale_rot(const GsrDims* dims, const GsrView* views, const float* means, const float* scale_rot,
+                          const float* frames, int num_frames, const float* opacities, const float* colors,
+                          const float* extra, float* out_color, float* out_extra, int32_t* radii, void* geom, void* bin,
+                          void* img, void* stream);
+int gsr_backward_scale_rot(const GsrDims* dims, const GsrView* views, const float* means, const float* scale_rot,
+                           const float* frames, int num_frames, const float* opacities, const float* colors,
+                           const float* extra, const void* geom, const void* bin, const void* img, const float* dL_dcolor,
+                           const float* dL_dextra_img, void* scratch, float* dL_dmeans, float* dL_dscale_rot,
+                           float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream);
+
 /* GSR_FLAG_DEBUG: the stage of the last failed call of this host thread (forward: 0 preprocess/binning, 1 count + scans,
  * 2 emit, 3 sort + colour, 4 blend; backward: 0 blend backward, 1 preprocess backward), or -1. */
 int gsr_last_failed_stage(void);

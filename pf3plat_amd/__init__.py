@@ -15,6 +15,7 @@ from .splatting import (  # noqa: F401
     render_depth_cuda,
     render_views,
 )
+from .adapter import AdaptedGaussians, GaussianAdapter, GaussianAdapterCfg  # noqa: F401
 from .decoder import DecoderSplattingCUDA, DecoderSplattingCUDACfg, get_decoder  # noqa: F401
 from .geometry import depth_to_relative_disparity, get_fov, get_projection_matrix, homogenize_points  # noqa: F401
 

@@ -110,6 +110,10 @@ def load():
     lib.gsr_forward.argtypes = [dp] + [vp] * 13
     lib.gsr_backward.restype = ctypes.c_int
     lib.gsr_backward.argtypes = [dp] + [vp] * 19
+    lib.gsr_forward_scale_rot.restype = ctypes.c_int
+    lib.gsr_forward_scale_rot.argtypes = [dp, vp, vp, vp, vp, ctypes.c_int] + [vp] * 10
+    lib.gsr_backward_scale_rot.restype = ctypes.c_int
+    lib.gsr_backward_scale_rot.argtypes = [dp, vp, vp, vp, vp, ctypes.c_int] + [vp] * 16
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
     lib.gsr_setup_views.restype = ctypes.c_int
@@ -131,7 +135,7 @@ EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
-    "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic",
+    "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
 )
 # gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).

@@ -1,0 +1,109 @@
+"""Encoder-side Gaussian adapter: from per-pixel network outputs to the Gaussians the decoder renders - the step right in
+front of the raster path.  Counterpart of the reference's `GaussianAdapter`
+(src/model/encoder/common/gaussian_adapter.py:30-125; same constructor cfg, same `forward` arguments, `get_scale_multiplier`,
+`d_sh`, `d_in`) with one difference in what comes out: the (N, 3, 3) world-space covariances are NOT materialised.  The
+adapter returns scales, unit quaternions and the camera-to-world rotation of every source view; the raster library builds
+Sigma = (C R) diag(s^2) (C R)^T in registers as it loads a Gaussian (`gsr_forward_scale_rot`) and its backward returns
+dL/dscale and dL/dquaternion directly.  That removes the 36 bytes per Gaussian the covariance costs in each direction (written
+by the adapter, read by the forward, its gradient written by the backward and read by autograd) and six small torch
+kernels.  `AdaptedGaussians.covariances` still yields the matrices (as differentiable torch ops) for callers that want them.
+
+`rotate_sh` (reference src/misc/sh_rotation.py: Wigner-D rotation of the harmonics into world space, built on e3nn) is not part
+of this package; pass a callable with that signature to the constructor to apply it.  Without it the harmonics stay in the
+source camera's frame.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor, nn
+
+from .types import Gaussians
+
+
+@dataclass
+class GaussianAdapterCfg:
+    gaussian_scale_min: float
+    gaussian_scale_max: float
+    sh_degree: int
+
+
+@dataclass
+class AdaptedGaussians:
+    """Per-pixel Gaussians of a batch of scenes, grouped by source view: every tensor is (scene, view, ray, ...)."""
+
+    means: Tensor  # (b, v, r, 3) world space
+    scales: Tensor  # (b, v, r, 3)
+    rotations: Tensor  # (b, v, r, 4) unit quaternions x, y, z, w, in the source camera's frame
+    harmonics: Tensor  # (b, v, r, 3, d_sh)
+    opacities: Tensor  # (b, v, r)
+    frames: Tensor  # (b, v, 3, 3) camera-to-world rotation of every source view (no gradient)
+
+    @property
+    def covariances(self) -> Tensor:
+        """(b, v, r, 3, 3) world-space covariances, materialised with torch ops (the raster path does not need them)."""
+        x, y, z, w = self.rotations.unbind(-1)
+        t = 2 / ((self.rotations * self.rotations).sum(-1) + 1e-8)
+        rot = torch.stack((1 - t * (y * y + z * z), t * (x * y - z * w), t * (x * z + y * w),
+                           t * (x * y + z * w), 1 - t * (x * x + z * z), t * (y * z - x * w),
+                           t * (x * z - y * w), t * (y * z + x * w), 1 - t * (x * x + y * y)), -1).unflatten(-1, (3, 3))
+        m = self.frames[:, :, None] @ rot
+        return (m * (self.scales * self.scales)[..., None, :]) @ m.transpose(-1, -2)
+
+    def for_decoder(self) -> Gaussians:
+        """One set of Gaussians per scene in the decoder's layout: views flattened into the Gaussian axis (view-major, so the
+        Gaussians of a source view are consecutive - the grouping the kernels' `frames` argument expects)."""
+        b, v, r = self.opacities.shape
+        flat = lambda t: t.reshape(b, v * r, *t.shape[3:])
+        return Gaussians(means=flat(self.means), covariances=None, harmonics=flat(self.harmonics), opacities=flat(self.opacities),
+                         scales=flat(self.scales), rotations=flat(self.rotations), frames=self.frames)
+
+
+class GaussianAdapter(nn.Module):
+    def __init__(self, cfg: GaussianAdapterCfg, rotate_sh: Optional[Callable[[Tensor, Tensor], Tensor]] = None):
+        super().__init__()
+        self.cfg = cfg
+        self.rotate_sh = rotate_sh
+        # band l of the harmonics starts small (0.1 x 0.25^l): the DC term dominates at initialisation
+        band = torch.arange(self.d_sh, dtype=torch.float32).sqrt().floor()
+        self.register_buffer("sh_mask", torch.where(band == 0, torch.ones(()), 0.1 * 0.25 ** band), persistent=False)
+
+    @property
+    def d_sh(self) -> int:
+        return (self.cfg.sh_degree + 1) ** 2
+
+    @property
+    def d_in(self) -> int:
+        return 7 + 3 * self.d_sh
+
+    def get_scale_multiplier(self, intrinsics: Tensor, pixel_size: Tensor, multiplier: float = 0.1) -> Tensor:
+        """How large one pixel is at unit depth, summed over x and y: (K[:2, :2]^-1 pixel_size) . (1, 1), times `multiplier`."""
+        return multiplier * torch.linalg.solve(intrinsics[..., :2, :2], pixel_size.expand(*intrinsics.shape[:-2], 2)).sum(-1)
+
+    def forward(self, extrinsics: Tensor, intrinsics: Tensor, coordinates: Tensor, depths: Tensor, opacities: Tensor,
+                raw_gaussians: Tensor, image_shape: tuple, eps: float = 1e-8) -> AdaptedGaussians:
+        """extrinsics (b, v, 1, 4, 4) / intrinsics (b, v, 1, 3, 3) of the source views (broadcast over rays), coordinates
+        (b, v, r, 2) in [0, 1]^2, depths / opacities (b, v, r), raw_gaussians (b, v, r, 7 + 3 d_sh) = scale(3) | quaternion
+        xyzw(4) | harmonics(3 x d_sh)."""
+        h, w = image_shape
+        raw_scale, raw_quat, raw_sh = raw_gaussians.split((3, 4, 3 * self.d_sh), dim=-1)
+        lo, hi = self.cfg.gaussian_scale_min, self.cfg.gaussian_scale_max
+        pixel = torch.tensor((1.0 / w, 1.0 / h), dtype=torch.float32, device=extrinsics.device)
+        footprint = depths * self.get_scale_multiplier(intrinsics, pixel)  # world size of 0.1 pixel at the Gaussian's depth
+        scales = (lo + (hi - lo) * raw_scale.sigmoid()) * footprint[..., None]
+        rotations = raw_quat / (raw_quat.norm(dim=-1, keepdim=True) + eps)
+        harmonics = raw_sh.unflatten(-1, (3, self.d_sh)).broadcast_to((*opacities.shape, 3, self.d_sh)) * self.sh_mask
+        c2w = extrinsics[..., :3, :3].detach()
+        # mean = camera centre + depth x (unit ray through the pixel, rotated into world space)
+        ray = torch.linalg.solve(intrinsics, F.pad(coordinates, (0, 1), value=1.0).unsqueeze(-1)).squeeze(-1)
+        ray = F.normalize(ray, dim=-1)
+        direction = (extrinsics[..., :3, :3] @ ray.unsqueeze(-1)).squeeze(-1)
+        means = extrinsics[..., :3, 3] + direction * depths[..., None]
+        if self.rotate_sh is not None:
+            harmonics = self.rotate_sh(harmonics, c2w[..., None, :, :])
+        b, v, r = opacities.shape
+        return AdaptedGaussians(means=means, scales=scales, rotations=rotations.broadcast_to((b, v, r, 4)), harmonics=harmonics,
+                                opacities=opacities, frames=c2w.reshape(b, v, 3, 3))

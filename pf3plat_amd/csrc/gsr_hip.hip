@@ -147,6 +147,9 @@ struct Params {
   int chunk;  // Gaussians per binning workgroup (choose_chunk)
   const GsrView* views;
   const float *means, *cov6, *opac, *colors, *extra;
+  const float* frames;   // scale/rotation input form (gsr_forward_scale_rot): cov6 points at (S, N, 7) records, frames at
+  int num_frames;        // (S, F, 3, 3) rotations (nullable) applied to the Gaussians of each of the F equal groups of a set
+  int scale_rot;         // 1: that form is in use
   float* out_color;
   float* out_extra;
   int32_t* radii;
@@ -176,7 +179,7 @@ struct Params {
   // backward only
   const float *dL_dcolor, *dL_dextra_img;
   float* scratch;
-  float *dL_dmeans, *dL_dcov6, *dL_dopac, *dL_dcolors, *dL_dextra, *dL_dmeans2D;
+  float *dL_dmeans, *dL_dcov6, *dL_dopac, *dL_dcolors, *dL_dextra, *dL_dmeans2D;  // (scale_rot: dL_dcov6 is (S, N, 7))
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -270,6 +273,84 @@ __device__ __forceinline__ void load_cov6(const float* cov, size_t gi, bool c9, 
     const float* c = cov + 6 * gi;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = c[k];
+  }
+}
+
+// Scale / rotation input form: what PF3plat's GaussianAdapter does between its raw network outputs and the covariance it
+// hands to the decoder (reference src/model/encoder/common/gaussians.py:8-44 quaternion_to_matrix + build_covariance,
+// gaussian_adapter.py:79-83 rotation into world space), evaluated on load instead of materialising (N, 3, 3) matrices:
+//   record = scale (x, y, z), quaternion (x, y, z, w);   two_s = 2 / (|q|^2 + 1e-8);   Rq from the quaternion;
+//   M = F Rq  (F: camera-to-world rotation of the Gaussian's source view, optional);   Sigma = M diag(s^2) M^T.
+__device__ __forceinline__ void sr_matrix(const float* sr, const float* F, float* M, float& ts) {
+  const float i = sr[3], j = sr[4], k = sr[5], r = sr[6];
+  ts = 2.f / (i * i + j * j + k * k + r * r + 1e-8f);
+  const float Rq[9] = {1.f - ts * (j * j + k * k), ts * (i * j - k * r), ts * (i * k + j * r),
+                       ts * (i * j + k * r), 1.f - ts * (i * i + k * k), ts * (j * k - i * r),
+                       ts * (i * k - j * r), ts * (j * k + i * r), 1.f - ts * (i * i + j * j)};
+  if (F) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) M[3 * a + b] = F[3 * a] * Rq[b] + F[3 * a + 1] * Rq[3 + b] + F[3 * a + 2] * Rq[6 + b];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 9; ++a) M[a] = Rq[a];
+  }
+}
+__device__ __forceinline__ void cov6_from_sr(const float* sr, const float* F, float* o) {
+  float M[9], ts;
+  sr_matrix(sr, F, M, ts);
+  const float s0 = sr[0] * sr[0], s1 = sr[1] * sr[1], s2 = sr[2] * sr[2];
+  auto S = [&](int a, int b) { return M[3 * a] * s0 * M[3 * b] + M[3 * a + 1] * s1 * M[3 * b + 1] + M[3 * a + 2] * s2 * M[3 * b + 2]; };
+  o[0] = S(0, 0); o[1] = S(0, 1); o[2] = S(0, 2); o[3] = S(1, 1); o[4] = S(1, 2); o[5] = S(2, 2);
+}
+// dL/d(record) from dL/dcov6 (doubled off-diagonals, as the raster backward produces them)
+__device__ __forceinline__ void sr_backward(const float* sr, const float* F, const float* dc, float* dsr) {
+  float M[9], ts;
+  sr_matrix(sr, F, M, ts);
+  const float G[9] = {dc[0], 0.5f * dc[1], 0.5f * dc[2], 0.5f * dc[1], dc[3], 0.5f * dc[4], 0.5f * dc[2], 0.5f * dc[4], dc[5]};
+  float dM[9];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float m[3] = {M[k], M[3 + k], M[6 + k]};  // column k of M
+    float Gm[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) Gm[a] = G[3 * a] * m[0] + G[3 * a + 1] * m[1] + G[3 * a + 2] * m[2];
+    dsr[k] = 2.f * sr[k] * (m[0] * Gm[0] + m[1] * Gm[1] + m[2] * Gm[2]);
+    const float s2 = 2.f * sr[k] * sr[k];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) dM[3 * a + k] = s2 * Gm[a];
+  }
+  float D[9];  // dL/dRq = F^T dL/dM
+  if (F) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int b = 0; b < 3; ++b) D[3 * a + b] = F[a] * dM[b] + F[3 + a] * dM[3 + b] + F[6 + a] * dM[6 + b];
+  } else {
+#pragma unroll
+    for (int a = 0; a < 9; ++a) D[a] = dM[a];
+  }
+  const float i = sr[3], j = sr[4], k = sr[5], r = sr[6];
+  // Rq = I + two_s P(q):  dL/dq = two_s sum D : dP/dq  -  two_s^2 q sum D : P
+  const float DP = D[0] * -(j * j + k * k) + D[1] * (i * j - k * r) + D[2] * (i * k + j * r) + D[3] * (i * j + k * r) +
+                   D[4] * -(i * i + k * k) + D[5] * (j * k - i * r) + D[6] * (i * k - j * r) + D[7] * (j * k + i * r) +
+                   D[8] * -(i * i + j * j);
+  const float di = D[1] * j + D[2] * k + D[3] * j - 2.f * i * D[4] - r * D[5] + k * D[6] + r * D[7] - 2.f * i * D[8];
+  const float dj = -2.f * j * D[0] + i * D[1] + r * D[2] + i * D[3] + k * D[5] - r * D[6] + k * D[7] - 2.f * j * D[8];
+  const float dk = -2.f * k * D[0] - r * D[1] + i * D[2] + r * D[3] - 2.f * k * D[4] + j * D[5] + i * D[6] + j * D[7];
+  const float dr = -k * D[1] + j * D[2] + k * D[3] - i * D[5] - j * D[6] + i * D[7];
+  const float c = ts * ts * DP;
+  dsr[3] = ts * di - c * i; dsr[4] = ts * dj - c * j; dsr[5] = ts * dk - c * k; dsr[6] = ts * dr - c * r;
+}
+// The covariance of Gaussian i of `set` in whichever input form the call uses
+__device__ __forceinline__ void load_covariance(const Params& p, int set, int i, size_t gi, float* o) {
+  if (p.scale_rot) {
+    const int N = p.d.num_gaussians;
+    const float* F = p.frames ? p.frames + ((size_t)set * p.num_frames + (size_t)i / (size_t)(N / p.num_frames)) * 9 : nullptr;
+    cov6_from_sr(p.cov6 + 7 * gi, F, o);
+  } else {
+    load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, o);
   }
 }
 
@@ -534,7 +615,7 @@ __device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i,
 
   const float mx = p.means[3 * gi + 0] * cam.scale, my = p.means[3 * gi + 1] * cam.scale, mz = p.means[3 * gi + 2] * cam.scale;
   float cov6[6];
-  load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, cov6);
+  load_covariance(p, set, i, gi, cov6);
 #pragma unroll
   for (int k = 0; k < 6; ++k) cov6[k] *= cam.scale2;
   const float op = p.opac[gi];
@@ -2080,7 +2161,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   float sg_first[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   if (in_range) {
     rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2];
-    load_cov6(p.cov6, gi, (p.d.flags & GSR_FLAG_COV_3X3) != 0, rcov);
+    load_covariance(p, set, i, gi, rcov);
     load_row(0, sg_first);
   }
   if (M > 0) {
@@ -2247,7 +2328,13 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   if (in_range) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) p.dL_dmeans[3 * gi + j] = dmean[j];
-    if (p.d.flags & GSR_FLAG_COV_3X3) {
+    if (p.scale_rot) {
+      const float* F = p.frames ? p.frames + ((size_t)set * p.num_frames + (size_t)i / (size_t)(N / p.num_frames)) * 9 : nullptr;
+      float dsr[7];
+      sr_backward(p.cov6 + 7 * gi, F, dcov, dsr);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) p.dL_dcov6[7 * gi + k] = dsr[k];
+    } else if (p.d.flags & GSR_FLAG_COV_3X3) {
       float* o = p.dL_dcov6 + 9 * gi;
       o[0] = dcov[0]; o[1] = dcov[1]; o[2] = dcov[2]; o[3] = 0.f; o[4] = dcov[3]; o[5] = dcov[4]; o[6] = 0.f; o[7] = 0.f; o[8] = dcov[5];
     } else {
@@ -2625,11 +2712,22 @@ int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8) {
   return GSR_OK;
 }
 
+struct SrArgs {  // scale / rotation input form: cov6 is (S, N, 7); frames (S, F, 3, 3) or null
+  const float* frames;
+  int num_frames;
+};
+static bool sr_ok(const GsrDims* d, const SrArgs* sr) {
+  if (!sr) return true;
+  if (d->flags & GSR_FLAG_COV_3X3) return false;
+  if (!sr->frames) return sr->num_frames == 0;
+  return sr->num_frames > 0 && d->num_gaussians % sr->num_frames == 0;
+}
+
 static int forward_impl(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
                         const float* opacities, const float* colors, const float* extra, float* out_color,
                         float* out_extra, int32_t* radii, void* geom, void* bin, void* img, hipStream_t st,
-                        hipEvent_t* ev) {
-  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+                        hipEvent_t* ev, const SrArgs* sr = nullptr) {
+  if (!dims_ok(dims) || !sr_ok(dims, sr)) return GSR_ERR_INVALID_ARGUMENT;
   const GsrDims& d = *dims;
   const size_t V = d.num_views, N = d.num_gaussians, HW = (size_t)d.height * d.width;
   if (V == 0) return GSR_OK;
@@ -2638,6 +2736,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   if (d.has_extra && N > 0 && !extra && ((d.flags >> 4) & 7) == 0) return GSR_ERR_INVALID_ARGUMENT;  // (an empty array has no address)
   Params p = base_params(dims, views, means, cov6, opacities, colors, extra, geom, bin, img);
   p.out_color = out_color; p.out_extra = out_extra; p.radii = radii;
+  if (sr) { p.scale_rot = 1; p.frames = sr->frames; p.num_frames = sr->frames ? sr->num_frames : 1; }
   static std::atomic<uint32_t> call_counter{1u};
   p.call_tag = call_counter.fetch_add(1u, std::memory_order_relaxed);
   const Layout L = make_layout(d);
@@ -2762,12 +2861,12 @@ int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* 
   return rc;
 }
 
-int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
-                 const float* opacities, const float* colors, const float* extra, const void* geom,
-                 const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
-                 void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
-                 float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_) {
-  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+static int backward_impl(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                         const float* opacities, const float* colors, const float* extra, const void* geom,
+                         const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
+                         void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
+                         float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_, const SrArgs* sr) {
+  if (!dims_ok(dims) || !sr_ok(dims, sr)) return GSR_ERR_INVALID_ARGUMENT;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const GsrDims& d = *dims;
   const size_t V = d.num_views, N = d.num_gaussians;
@@ -2779,6 +2878,7 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   Params p = base_params(dims, views, means, cov6, opacities, colors, extra, const_cast<void*>(geom),
                          const_cast<void*>(bin), const_cast<void*>(img));
   p.dL_dcolor = dL_dcolor; p.dL_dextra_img = d.has_extra ? dL_dextra_img : nullptr;
+  if (sr) { p.scale_rot = 1; p.frames = sr->frames; p.num_frames = sr->frames ? sr->num_frames : 1; }
   p.scratch = own_rows ? reinterpret_cast<float*>(p.grad_rows) : static_cast<float*>(scratch);
   p.dL_dmeans = dL_dmeans; p.dL_dcov6 = dL_dcov6; p.dL_dopac = dL_dopacities; p.dL_dcolors = dL_dcolors;
   p.dL_dextra = d.has_extra ? dL_dextra : nullptr; p.dL_dmeans2D = dL_dmeans2D;
@@ -2814,6 +2914,34 @@ int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, 
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
+}
+
+int gsr_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
+                 const float* opacities, const float* colors, const float* extra, const void* geom,
+                 const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
+                 void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
+                 float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_) {
+  return backward_impl(dims, views, means, cov6, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img, scratch,
+                       dL_dmeans, dL_dcov6, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_, nullptr);
+}
+
+int gsr_forward_scale_rot(const GsrDims* dims, const GsrView* views, const float* means, const float* scale_rot,
+                          const float* frames, int num_frames, const float* opacities, const float* colors,
+                          const float* extra, float* out_color, float* out_extra, int32_t* radii, void* geom, void* bin,
+                          void* img, void* stream_) {
+  const SrArgs sr{frames, num_frames};
+  return forward_impl(dims, views, means, scale_rot, opacities, colors, extra, out_color, out_extra, radii, geom, bin, img,
+                      static_cast<hipStream_t>(stream_), nullptr, &sr);
+}
+
+int gsr_backward_scale_rot(const GsrDims* dims, const GsrView* views, const float* means, const float* scale_rot,
+                           const float* frames, int num_frames, const float* opacities, const float* colors,
+                           const float* extra, const void* geom, const void* bin, const void* img, const float* dL_dcolor,
+                           const float* dL_dextra_img, void* scratch, float* dL_dmeans, float* dL_dscale_rot,
+                           float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_) {
+  const SrArgs sr{frames, num_frames};
+  return backward_impl(dims, views, means, scale_rot, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img,
+                       scratch, dL_dmeans, dL_dscale_rot, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_, &sr);
 }
 
 // Measurement aid (bench.py): gsr_backward with events between its two stages (blend backward, preprocess backward);

@@ -65,7 +65,7 @@ class DecoderSplattingCUDA(Decoder):
             extrinsics, intrinsics, near, far, image_shape,
             self.background_color.to(extrinsics.device),
             gaussians.means, gaussians.covariances, gaussians.harmonics, gaussians.opacities,
-            depth_mode=depth_mode,
+            depth_mode=depth_mode, gaussian_scales=gaussians.scales, gaussian_rotations=gaussians.rotations, frames=gaussians.frames,
         )
         return DecoderOutput(color, depth)
 

@@ -53,6 +53,7 @@ class RasterConfig:
     max_sh_eval: int = 4
     has_extra: bool = False
     flags: int = 0  # _lib.FLAG_SH_PLANAR | _lib.FLAG_COV_3X3 (input layouts)
+    scale_rot: bool = False  # the covariance argument is (S, N, 7) scale + quaternion (x, y, z, w) records (gsr_forward_scale_rot)
 
 
 def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx: Tensor, tanfovy: Tensor,
@@ -203,7 +204,8 @@ class HipBackend:
                 scratch=None if cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS else torch.empty(
                     max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=u8, device=device),
                 d_means=torch.empty((s, n, 3), dtype=f32, device=device),
-                d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=device),
+                d_cov6=torch.empty((s, n, 7) if cfg.scale_rot else (s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6),
+                                   dtype=f32, device=device),
                 d_opac=torch.empty((s, n), dtype=f32, device=device),
                 d_colors=torch.empty(colors_shape, dtype=f32, device=device),
                 d_extra=torch.empty((v, n), dtype=f32, device=device) if cfg.has_extra else None,
@@ -211,7 +213,17 @@ class HipBackend:
             )
         return plan
 
-    def run_forward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra=None, profile: bool = False, out_color=None):
+    @staticmethod
+    def _frames_args(cfg, frames):
+        if frames is None:
+            return None, 0
+        if frames.dim() != 4 or frames.shape[0] != cfg.num_sets or frames.shape[2:] != (3, 3) or cfg.num_gaussians % frames.shape[1]:
+            raise ValueError("frames must be (sets, F, 3, 3) with F dividing the number of Gaussians")
+        frames = frames.detach().to(torch.float32).contiguous()  # (a QR factor, e.g., arrives column-major)
+        return frames, int(frames.shape[1])
+
+    def run_forward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra=None, profile: bool = False, out_color=None,
+                    frames=None):
         """Enqueue one forward launch chain on the current stream.  profile=True returns per-stage ms (synchronises).
         out_color: render into this contiguous (V, 3, H, W) fp32 tensor instead of the plan's own image (e.g. a slot of a
         buffer that is all-gathered later: no copy)."""
@@ -223,7 +235,11 @@ class HipBackend:
                 _ptr(color), _ptr(plan["extra_img"]), _ptr(plan["radii"]), _ptr(plan["geom"]), _ptr(plan["bin"]),
                 _ptr(plan["img"]), stream)
         with torch.cuda.device(plan["device"]):  # kernels launch on the process's current device: make it the tensors' device
-            if profile:
+            if plan["cfg"].scale_rot:
+                fr, nf = self._frames_args(plan["cfg"], frames)
+                ms = None
+                rc = self.lib.gsr_forward_scale_rot(*args[:4], _ptr(fr), nf, *args[4:])
+            elif profile:
                 ms = (ctypes.c_float * len(_lib.FWD_STAGES))()
                 rc = self.lib.gsr_forward_profile(*args, ms)
             else:
@@ -233,7 +249,7 @@ class HipBackend:
         return None if ms is None else dict(zip(_lib.FWD_STAGES, [float(x) for x in ms]))
 
     def run_backward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img=None,
-                     want_means2d: bool = True, profile: bool = False):
+                     want_means2d: bool = True, profile: bool = False, frames=None):
         cfg = plan["cfg"]
         stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
@@ -242,7 +258,11 @@ class HipBackend:
                 _ptr(plan["d_cov6"]), _ptr(plan["d_opac"]), _ptr(plan["d_colors"]), _ptr(plan["d_extra"]),
                 _ptr(plan["d_means2d"] if want_means2d else None), stream)
         with torch.cuda.device(plan["device"]):
-            if profile:
+            if cfg.scale_rot:
+                fr, nf = self._frames_args(cfg, frames)
+                ms = None
+                rc = self.lib.gsr_backward_scale_rot(*args[:4], _ptr(fr), nf, *args[4:])
+            elif profile:
                 ms = (ctypes.c_float * len(_lib.BWD_STAGES))()
                 rc = self.lib.gsr_backward_profile(*args, ms)
             else:
@@ -259,7 +279,8 @@ class HipBackend:
                 "max_list": int(st[12:16].view(torch.int32).item())}
 
     # ---- autograd-facing calls: fresh outputs/workspaces per call, kept alive for backward
-    def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None):
+    def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None,
+                frames=None):
         """Pair-count policy (`self.sync_policy`):
         "sync"  - (default) read the 16-byte status block back after every call (one host sync, as the reference extension
                   does with its num_rendered) and retry with the exact size on overflow: a jump in the pair count from one
@@ -278,7 +299,7 @@ class HipBackend:
         cap = self._default_capacity(cfg) if capacity is None else int(capacity)
         for attempt in range(3):
             plan = self.make_plan(cfg, dev, cap)
-            self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra)
+            self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
             saved = (plan["dims"], plan["geom"], plan["bin"], plan["img"])
             out = (plan["color"], plan["extra_img"], plan["radii"], saved)
             if n == 0 or v == 0:
@@ -334,7 +355,7 @@ class HipBackend:
             self.check_pending(only_ws=binb.data_ptr())
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
-                 want_means2d: bool, rows_in_workspace: bool = False):
+                 want_means2d: bool, rows_in_workspace: bool = False, frames=None):
         """rows_in_workspace: the forward ran with FLAG_BACKWARD_FOLLOWS and this is the first backward over it - accumulate
         into the rows it zero-filled inside geom (no scratch, no zero-fill pass)."""
         dims, geom, binb, img = saved
@@ -346,7 +367,8 @@ class HipBackend:
                     scratch=None if (rows_in_workspace and cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) else torch.empty(
                         max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=torch.uint8, device=dev),
                     d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
-                    d_cov6=torch.empty((s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6), dtype=f32, device=dev),
+                    d_cov6=torch.empty((s, n, 7) if cfg.scale_rot else (s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6),
+                                       dtype=f32, device=dev),
                     d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
                     d_extra=torch.empty((v, n), dtype=f32, device=dev) if (cfg.has_extra and not (cfg.flags >> 4) & 7) else None,
                     d_means2d=torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None)
@@ -355,7 +377,7 @@ class HipBackend:
             if cfg.has_extra:
                 g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
                                else g_extra_img.contiguous().to(f32))
-            self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d)
+            self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d, frames=frames)
         return plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
 
     def setup_views(self, extrinsics, intrinsics, near, far, background, scale_invariant: bool = True) -> Tensor:
@@ -438,9 +460,10 @@ def set_backend(backend):
 # --------------------------------------------------------------------------------------------------
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, cov6, opac, colors, extra, means2d, viewbuf, cfg: RasterConfig):
+    def forward(ctx, means, cov6, opac, colors, extra, means2d, viewbuf, cfg: RasterConfig, frames=None):
         backend = get_backend()
-        color, extra_img, radii, saved = backend.forward(cfg, viewbuf, means, cov6, opac, colors, extra)
+        color, extra_img, radii, saved = backend.forward(cfg, viewbuf, means, cov6, opac, colors, extra, frames=frames)
+        ctx.frames = frames
         ctx.cfg = cfg
         ctx.saved_ws = saved
         ctx.rows_fresh = bool(cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS)  # accumulator rows zero-filled by the forward, usable once
@@ -465,18 +488,18 @@ class _RasterizeViews(torch.autograd.Function):
             g_color = torch.zeros((cfg.num_views, 3, cfg.height, cfg.width), dtype=torch.float32, device=means.device)
         d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
             cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d,
-            rows_in_workspace=ctx.rows_fresh)
+            rows_in_workspace=ctx.rows_fresh, frames=ctx.frames)
         ctx.rows_fresh = False
         # the workspaces stay with ctx (freed with the graph): a second backward (retain_graph=True, several autograd.grad
         # calls over one render) runs on them again, as upstream's Function can
-        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, None, None
+        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, None, None, None
 
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
                     image_shape, sh_degree: int, use_sh: bool, views_per_set: int, extra: Optional[Tensor] = None,
                     means2d: Optional[Tensor] = None, max_sh_eval: int = 4, sh_planar: bool = False, cov_3x3: bool = False,
                     extra_mode: Optional[str] = None, debug: bool = False, prefiltered: bool = False,
-                    deterministic: Optional[bool] = None):
+                    deterministic: Optional[bool] = None, scale_rot: bool = False, frames: Optional[Tensor] = None):
     """Render V = num_sets * views_per_set views in one launch chain.
 
     means (S,N,3); cov6 (S,N,6) or, with cov_3x3, the full symmetric (S,N,3,3); opacities (S,N); colors (S,N,M,3) or, with
@@ -486,6 +509,9 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     Returns (color (V,3,H,W), extra_img (V,H,W) | None, radii (V,N) int32).  Differentiable w.r.t. means, cov6, opacities,
     colors, extra (gradients come back in the layouts given; means2d receives the screen-space gradient); cameras get none,
     like the reference operator.
+    scale_rot: `cov6` is (S,N,7) = scale (x,y,z) + quaternion (x,y,z,w), the form PF3plat's encoder emits (reference
+    gaussian_adapter.py:63-83); the covariance R diag(s^2) R^T - rotated into world space by `frames` (S,F,3,3), one rotation per
+    group of N/F consecutive Gaussians, no gradient - is built inside the kernels and the gradient comes back as (S,N,7).
     debug: upstream's `settings.debug` - the library synchronises and checks for errors after every stage and names the
     stage that failed.  deterministic: the backward accumulates per-Gaussian gradients in 64-bit fixed point (bit-identical
     from run to run); None = follow `torch.are_deterministic_algorithms_enabled()`.
@@ -504,7 +530,14 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
         extra = extra.to(f32).contiguous()
     if use_sh and colors.dim() != 4:
         raise ValueError("shs must be (sets, N, M, 3) or (sets, N, 3, M)")
-    if cov6.shape[2:] != ((3, 3) if cov_3x3 else (6,)):
+    if scale_rot:
+        if cov_3x3 or cov6.shape[2:] != (7,):
+            raise ValueError(f"scale/rotation records have shape {tuple(cov6.shape)}; expected (sets, N, 7)")
+        if frames is not None:
+            frames = frames.detach().to(f32).contiguous()
+    elif frames is not None:
+        raise ValueError("`frames` goes with scale_rot=True")
+    elif cov6.shape[2:] != ((3, 3) if cov_3x3 else (6,)):
         raise ValueError(f"covariances have shape {tuple(cov6.shape)}; expected (sets, N, {'3, 3' if cov_3x3 else '6'})")
     m = (colors.shape[3] if sh_planar else colors.shape[2]) if use_sh else 0
     flags = (_lib.FLAG_SH_PLANAR if (sh_planar and use_sh) else 0) | (_lib.FLAG_COV_3X3 if cov_3x3 else 0)
@@ -519,8 +552,10 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
             raise ValueError("give either `extra` or `extra_mode`")
         flags |= EXTRA_MODES[extra_mode] << 4
     has_extra = extra is not None or extra_mode is not None
-    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags)
-    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg)
+    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags,
+                       bool(scale_rot))
+    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg,
+                                                    frames)
     return color, (extra_img if has_extra else None), radii
 
 

@@ -141,6 +141,9 @@ def render_views(
     gaussian_opacities: Tensor,  # (scene, gaussian)
     depth_mode: Optional[DepthRenderingMode] = None,
     scale_invariant: bool = True,
+    gaussian_scales: Optional[Tensor] = None,  # (scene, gaussian, 3)   } instead of gaussian_covariances (pass None there):
+    gaussian_rotations: Optional[Tensor] = None,  # (scene, gaussian, 4) } the covariance is built inside the kernels
+    frames: Optional[Tensor] = None,  # (scene, F, 3, 3) world rotation per group of gaussian / F consecutive Gaussians
 ):
     """Fused decoder path: all views of all scenes in one launch chain, Gaussians read once per scene
     (no V-fold `repeat`, reference decoder_splatting_cuda.py:52-56), depth as a 4th blended channel.
@@ -152,10 +155,16 @@ def render_views(
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
     viewbuf = _viewbuf(ext, intr, nr, fr, background_color.reshape(3), scale_invariant)
-    color, depth, _ = rasterize_views(
-        gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, viewbuf,
-        image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra_mode=depth_mode, sh_planar=True,
-        cov_3x3=True)
+    if gaussian_covariances is None:  # scale + quaternion records, as the encoder's adapter emits them
+        records = torch.cat((gaussian_scales, gaussian_rotations), dim=-1)
+        color, depth, _ = rasterize_views(
+            gaussian_means, records, gaussian_opacities, gaussian_sh_coefficients, viewbuf, image_shape=image_shape,
+            sh_degree=degree, use_sh=True, views_per_set=v, extra_mode=depth_mode, sh_planar=True, scale_rot=True, frames=frames)
+    else:
+        color, depth, _ = rasterize_views(
+            gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, viewbuf,
+            image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra_mode=depth_mode, sh_planar=True,
+            cov_3x3=True)
     h, w = image_shape
     color = color.reshape(s, v, 3, h, w)
     if depth is not None:

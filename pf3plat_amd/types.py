@@ -14,9 +14,14 @@ DepthRenderingMode = Literal["depth", "log", "disparity", "relative_disparity"]
 @dataclass
 class Gaussians:
     means: Tensor  # (scene, gaussian, 3) world-space centres
-    covariances: Tensor  # (scene, gaussian, 3, 3) symmetric world-space covariance (the upper triangle is what is read)
+    covariances: Optional[Tensor]  # (scene, gaussian, 3, 3) symmetric world-space covariance (the upper triangle is what is read)
     harmonics: Tensor  # (scene, gaussian, 3, d_sh) SH coefficients per colour channel, d_sh = (degree + 1)^2
     opacities: Tensor  # (scene, gaussian) in (0, 1)
+    # the form the encoder's adapter produces (pf3plat_amd.adapter): when `covariances` is None the decoder hands these to the
+    # raster kernels, which build Sigma = (F R) diag(scale^2) (F R)^T on load
+    scales: Optional[Tensor] = None  # (scene, gaussian, 3)
+    rotations: Optional[Tensor] = None  # (scene, gaussian, 4) quaternions x, y, z, w
+    frames: Optional[Tensor] = None  # (scene, F, 3, 3) world rotation of each of the F equal consecutive groups of Gaussians
 
 
 @dataclass

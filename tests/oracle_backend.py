@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from oracle import OracleRasterizer, cameras
+from oracle import OracleRasterizer, adapter, cameras
 
 
 class OracleBackend:
@@ -56,7 +56,14 @@ class OracleBackend:
             colors = colors.permute(0, 1, 3, 2)
         return cov6, colors
 
-    def forward(self, cfg, viewbuf, means, cov6, opac, colors, extra, capacity=None):
+    def forward(self, cfg, viewbuf, means, cov6, opac, colors, extra, capacity=None, frames=None):
+        sr_graph = None
+        if getattr(cfg, "scale_rot", False):  # covariance from (S, N, 7) scale + quaternion records, kept differentiable
+            with torch.enable_grad():
+                sr_leaf = cov6.detach().to(torch.float32 if self.dtype == np.float32 else torch.float64).requires_grad_(True)
+                cov_graph = adapter.cov6_from_scale_rotation(sr_leaf, None if frames is None else frames.detach())
+            sr_graph = (sr_leaf, cov_graph)
+            cov6 = cov_graph.detach().to(torch.float32)
         cov6, colors = self._canon(cfg, cov6, colors)
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
@@ -99,10 +106,17 @@ class OracleBackend:
         if self.record:
             self.calls.append(percall)
         self.last_stats = stats
+        if sr_graph is not None:
+            handles.append(sr_graph)
         return color, extra_img, radii, handles
 
     def backward(self, cfg, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d,
-                 rows_in_workspace=False):
+                 rows_in_workspace=False, frames=None):
+        sr_graph = None
+        if getattr(cfg, "scale_rot", False):
+            sr_graph = saved[-1]
+            saved = saved[:-1]
+            cov6 = sr_graph[1].detach()
         tdt = torch.float32 if self.dtype == np.float32 else torch.float64
         V, N, S = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         d_means = torch.zeros((S, N, 3), dtype=tdt)
@@ -139,6 +153,10 @@ class OracleBackend:
                 d9[..., i, j] = d_cov6[..., k]
             d_cov6 = d9
         assert tuple(d_colors.shape) == colors_in_shape
+        if sr_graph is not None:  # chain rule back to the records
+            sr_leaf, cov_graph = sr_graph
+            (d_cov6,) = torch.autograd.grad(cov_graph, sr_leaf, d_cov6.to(cov_graph.dtype), retain_graph=True)
+            d_cov6 = d_cov6.to(tdt)
         return d_means, d_cov6, d_opac, d_colors, d_extra, d_m2d
 
     # ---- camera set-up: the reference wrapper's arithmetic as restated in oracle/cameras.py (numpy fp32)
