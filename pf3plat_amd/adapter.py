@@ -8,9 +8,9 @@ dL/dscale and dL/dquaternion directly.  That removes the 36 bytes per Gaussian t
 by the adapter, read by the forward, its gradient written by the backward and read by autograd) and six small torch
 kernels.  `AdaptedGaussians.covariances` still yields the matrices (as differentiable torch ops) for callers that want them.
 
-`rotate_sh` (reference src/misc/sh_rotation.py: Wigner-D rotation of the harmonics into world space, built on e3nn) is not part
-of this package; pass a callable with that signature to the constructor to apply it.  Without it the harmonics stay in the
-source camera's frame.
+The harmonics are rotated into world space by `pf3plat_amd.sh_rotation.rotate_sh` (the reference uses its e3nn-based
+src/misc/sh_rotation.py at gaussian_adapter.py:90); another callable of that signature, or None for no rotation, can be
+passed to the constructor.
 """
 from __future__ import annotations
 
@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 from torch import Tensor, nn
 
+from .sh_rotation import rotate_sh as _rotate_sh
 from .types import Gaussians
 
 
@@ -63,7 +64,7 @@ class AdaptedGaussians:
 
 
 class GaussianAdapter(nn.Module):
-    def __init__(self, cfg: GaussianAdapterCfg, rotate_sh: Optional[Callable[[Tensor, Tensor], Tensor]] = None):
+    def __init__(self, cfg: GaussianAdapterCfg, rotate_sh: Optional[Callable[[Tensor, Tensor], Tensor]] = _rotate_sh):
         super().__init__()
         self.cfg = cfg
         self.rotate_sh = rotate_sh

@@ -38,7 +38,7 @@ def test_oracle_restatement_matches_reference_build_covariance():
 
 def _adapted():
     lo, hi, deg = FIX["B_cfg"]
-    ad = GaussianAdapter(GaussianAdapterCfg(float(lo), float(hi), int(deg)))
+    ad = GaussianAdapter(GaussianAdapterCfg(float(lo), float(hi), int(deg)), rotate_sh=None)  # the fixture's harmonics are un-rotated
     hw = tuple(int(x) for x in FIX["B_hw"])
     raw = t("B_in_raw").requires_grad_(True)
     out = ad.forward(t("B_in_ext")[:, :, None], t("B_in_intr")[:, :, None], t("B_in_coords"), t("B_in_depths"), t("B_in_opac"), raw, hw)
@@ -56,6 +56,15 @@ def test_adapter_matches_reference_gaussian_adapter():
     np.testing.assert_allclose(out.frames.numpy(), FIX["B_in_ext"][:, :, :3, :3])
     g = out.for_decoder()
     assert g.covariances is None and g.means.shape == (1, 2 * 192, 3) and g.scales.shape == (1, 384, 3) and g.frames.shape == (1, 2, 3, 3)
+    # by default the harmonics are rotated into world space, band by band (DC untouched)
+    from pf3plat_amd.sh_rotation import rotate_sh
+    lo, hi, deg = FIX["B_cfg"]
+    hw = tuple(int(x) for x in FIX["B_hw"])
+    rot = GaussianAdapter(GaussianAdapterCfg(float(lo), float(hi), int(deg))).forward(
+        t("B_in_ext")[:, :, None], t("B_in_intr")[:, :, None], t("B_in_coords"), t("B_in_depths"), t("B_in_opac"), t("B_in_raw"), hw)
+    want = rotate_sh(out.harmonics.detach(), out.frames[:, :, None, None])
+    assert torch.allclose(rot.harmonics, want, atol=1e-6) and torch.equal(rot.harmonics[..., 0], out.harmonics[..., 0].detach())
+    assert not torch.allclose(rot.harmonics[..., 1:], out.harmonics[..., 1:].detach(), atol=1e-3)
 
 
 def _render(dec, g, sc, device="cpu"):

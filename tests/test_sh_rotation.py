@@ -1,0 +1,75 @@
+"""SURVEY.md 8f-4 `rotate_sh`: in the basis the rasterizer evaluates, rotating the coefficients is the same as rotating the
+argument; the bands do not mix, rotations compose, and a rotated scene rendered with rotated coefficients gives the image of
+the unrotated one (oracle rasterizer)."""
+import numpy as np
+import torch
+
+from oracle import OracleRasterizer
+from pf3plat_amd.sh_rotation import band_rotations, rotate_sh, sh_basis
+from tests.util import make_camera, random_small_scene
+
+
+def _rot(seed):
+    q, _ = torch.linalg.qr(torch.randn(3, 3, generator=torch.Generator().manual_seed(seed), dtype=torch.float64))
+    return q * torch.sign(torch.det(q))
+
+
+def test_basis_is_the_one_the_oracle_evaluates():
+    """A single Gaussian coloured by one coefficient at a time: oracle colour - 0.5 == sh_basis(direction)."""
+    cam = make_camera()
+    mean = np.array([[0.3, -0.2, 4.0]])
+    d = mean[0] / np.linalg.norm(mean[0])
+    want = sh_basis(torch.tensor(d)).numpy()
+    for k in range(25):
+        sh = np.zeros((1, 25, 3))
+        sh[0, k, :] = 1.0
+        o = OracleRasterizer(np.float64)
+        o.forward(height=8, width=8, bg=(0, 0, 0), sh_degree=4, means3D=mean, opacities=np.array([0.5]),
+                  cov3D_precomp=np.array([[0.01, 0, 0, 0.01, 0, 0.01]]), shs=sh, **cam)
+        rgb = o.geometry()["rgb"][0]
+        assert abs(max(want[k] + 0.5, 0.0) - rgb[0]) < 1e-9, k
+
+
+def test_rotating_coefficients_equals_rotating_the_argument():
+    g = torch.Generator().manual_seed(0)
+    c = torch.randn((5, 3, 25), generator=g, dtype=torch.float64)
+    r = torch.stack([_rot(s) for s in range(5)])[:, None]  # (5, 1, 3, 3) broadcast over the channel axis
+    rc = rotate_sh(c, r)
+    d = torch.nn.functional.normalize(torch.randn((5, 40, 3), generator=g, dtype=torch.float64), dim=-1)
+    world = d @ r[:, 0].transpose(-1, -2)  # R d
+    lhs = torch.einsum("bpn,bcn->bpc", sh_basis(world), rc)
+    rhs = torch.einsum("bpn,bcn->bpc", sh_basis(d), c)
+    np.testing.assert_allclose(lhs.numpy(), rhs.numpy(), atol=1e-10)
+    # band 0 untouched; identity rotation is the identity; rotations compose; band matrices are orthogonal
+    np.testing.assert_allclose(rc[..., 0].numpy(), c[..., 0].numpy(), atol=1e-12)
+    np.testing.assert_allclose(rotate_sh(c, torch.eye(3, dtype=torch.float64)).numpy(), c.numpy(), atol=1e-10)
+    a, b = _rot(7), _rot(8)
+    np.testing.assert_allclose(rotate_sh(rotate_sh(c, b), a).numpy(), rotate_sh(c, a @ b).numpy(), atol=1e-9)
+    for m in band_rotations(a, 4):
+        np.testing.assert_allclose((m @ m.T).numpy(), np.eye(m.shape[0]), atol=1e-9)
+    # float32 in, float32 out; lower degrees
+    assert rotate_sh(c[..., :9].float(), r.float()).dtype == torch.float32
+
+
+def test_rotated_scene_with_rotated_coefficients_renders_the_same_image():
+    sc = random_small_scene(3, 60, sh_coeffs=25, dtype=np.float64)
+    cam = make_camera(dtype=np.float64)
+    r = _rot(21).numpy()
+    t = np.array([0.4, -0.3, 0.2])
+
+    def render(means, cov6, shs, c2w):
+        o = OracleRasterizer(np.float64)
+        return o.forward(height=24, width=32, bg=(0.1, 0.2, 0.3), sh_degree=4, means3D=means, opacities=sc["opac"],
+                         cov3D_precomp=cov6, shs=shs, **make_camera(c2w, dtype=np.float64)).color
+
+    base = render(sc["means"], sc["cov6"], sc["colors"], np.eye(4))
+    cov = np.zeros((60, 3, 3))
+    for k, (i, j) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+        cov[:, i, j] = cov[:, j, i] = sc["cov6"][:, k]
+    cov_r = r @ cov @ r.T
+    cov6_r = np.stack([cov_r[:, 0, 0], cov_r[:, 0, 1], cov_r[:, 0, 2], cov_r[:, 1, 1], cov_r[:, 1, 2], cov_r[:, 2, 2]], -1)
+    shs_r = rotate_sh(torch.tensor(sc["colors"]).permute(0, 2, 1), torch.tensor(r)).permute(0, 2, 1).numpy()  # (N, M, 3) <-> (N, 3, M)
+    c2w = np.eye(4)
+    c2w[:3, :3], c2w[:3, 3] = r, t
+    moved = render(sc["means"] @ r.T + t, cov6_r, shs_r, c2w)
+    np.testing.assert_allclose(moved, base, atol=2e-6)
