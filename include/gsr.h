@@ -222,6 +222,18 @@ int gsr_cov_from_scale_rot(int64_t n, const float* scales, const float* rotation
 int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float* rotations, float scale_modifier,
                                     const float* dL_dcov6, float* dL_dscales, float* dL_drotations, void* stream);
 
+/* Image losses of the step right after the raster path, one launch: for `num_images` images (num_images, 3, H, W)
+ *   L = mse_weight * mean((prediction - target)^2) + ssim_weight * (1 - mean(SSIM map))
+ * with the reference's definitions (src/loss/loss_mse.py:23-36; src/loss/loss_multissim.py:24-83: 11 x 11 Gaussian window, sigma
+ * 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2; both means run over every element of the batch).  Writes dL/dprediction
+ * (nullable) in the layout gsr_backward takes as dL_dcolor, and one slot of 4 floats per workgroup into `partials`
+ * (gsr_image_loss_partials(...) slots, workgroups of an image consecutive): sum of squared errors, sum of squared errors of
+ * the inputs clipped to [0, 1] (compute_psnr, src/evaluation/metrics.py:11-19), sum of the SSIM map, 0.  The caller adds the
+ * slots up (a deterministic reduction) and forms the scalars. */
+size_t gsr_image_loss_partials(int num_images, int height, int width);
+int gsr_image_loss(int num_images, int height, int width, const float* prediction, const float* target, float mse_weight,
+                   float ssim_weight, float* dL_dprediction, float* partials, void* stream);
+
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
  * Forward stages: 0 preprocess (geometry, hit masks and - images of up to 8192 tiles - the whole binning) 1 the colour pass

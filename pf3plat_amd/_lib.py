@@ -114,6 +114,10 @@ def load():
     lib.gsr_forward_scale_rot.argtypes = [dp, vp, vp, vp, vp, ctypes.c_int] + [vp] * 10
     lib.gsr_backward_scale_rot.restype = ctypes.c_int
     lib.gsr_backward_scale_rot.argtypes = [dp, vp, vp, vp, vp, ctypes.c_int] + [vp] * 16
+    lib.gsr_image_loss_partials.restype = ctypes.c_size_t
+    lib.gsr_image_loss_partials.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.gsr_image_loss.restype = ctypes.c_int
+    lib.gsr_image_loss.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     lib.gsr_mark_visible.restype = ctypes.c_int
     lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
     lib.gsr_setup_views.restype = ctypes.c_int
@@ -136,6 +140,7 @@ EXPORTED_SYMBOLS = (
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
     "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
+    "gsr_image_loss", "gsr_image_loss_partials",
 )
 # gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).

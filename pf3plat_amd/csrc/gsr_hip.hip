@@ -1409,7 +1409,11 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
     // (LDS-bound, memory idle).  Four groups 2 us apart let one group's gather overlap another's bucket sort (measured:
     // forward 81.2 -> 77.0 us).  Later rounds start whenever a slot frees up and are out of phase by themselves.
     if (bid < 1024u) {
-      for (int q = 0; q < (int)((bid >> 3) & 3); ++q) __builtin_amdgcn_s_sleep(64);
+#ifndef GSR_DEPHASE_GROUPS
+#define GSR_DEPHASE_GROUPS 4
+#define GSR_DEPHASE_SLEEP 64
+#endif
+      for (int q = 0; q < (int)((bid >> 3) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_DEPHASE_SLEEP);
     }
     const uint2* col = p.pair_mat + (size_t)v * R * (T + 8) + t;
     const size_t cstride = (size_t)T + 8;
@@ -3021,6 +3025,144 @@ int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float*
   if (!scales || !rotations || !dL_dcov6) return GSR_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_cov_from_scale_rot_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream_),
                      (long long)n, scales, rotations, scale_modifier, dL_dcov6, dL_dscales, dL_drotations);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Image losses next to the raster path: the reference's photometric terms - LossMse (src/loss/loss_mse.py:23-36:
+// weight x mean squared error), LossMultiSSIM (src/loss/loss_multissim.py:24-83: weight x (1 - mean SSIM map), 11 x 11 Gaussian
+// window, sigma 1.5, zero padding, C1 = 0.01^2, C2 = 0.03^2) and the clipped squared error behind compute_psnr
+// (src/evaluation/metrics.py:11-19) - evaluated in ONE launch that also writes dL/dprediction in the (image, 3, H, W) layout
+// gsr_backward reads as dL_dcolor.  In torch the SSIM term alone is five depthwise convolutions forward and their
+// transposes backward (dozens of launches on images this small).
+//   SSIM map S = A B / (C D),  A = 2 mu1 mu2 + C1,  B = 2 sigma12 + C2,  C = mu1^2 + mu2^2 + C1,  D = sigma1^2 + sigma2^2 + C2,
+//   with mu = w * x, sigma1^2 = w * x1^2 - mu1^2, sigma12 = w * x1 x2 - mu1 mu2 (w * . = windowed mean).  For the prediction x1:
+//   dS/dx1(p) = [w * dmu](p) + 2 x1(p) [w * a](p) + x2(p) [w * b](p)   (the window is symmetric), where at every map position
+//   a = dS/d(w*x1^2) = -A B / (C D^2),  b = dS/d(w*x1x2) = 2 A / (C D),
+//   dmu = dS/dmu1 = 2 mu2 (B - A) / (C D) - 2 mu1 A B / (C^2 D) + 2 mu1 A B / (C D^2).
+// One workgroup = one 16 x 16 tile of one channel of one image: inputs on the 36 x 36 halo region -> five windowed means on
+// 26 x 26 (separable) -> S, a, b, dmu there (zero outside the image: those map positions do not exist) -> three windowed sums
+// back on 16 x 16.  Partial sums (squared error, clipped squared error, SSIM map) go to one slot per workgroup: the caller adds
+// them up (deterministic).
+// ------------------------------------------------------------------------------------------------
+namespace gsr {
+constexpr int kLossTile = 16, kLossR = 5, kLossMid = kLossTile + 2 * kLossR, kLossIn = kLossTile + 4 * kLossR;  // 16, 26, 36
+
+__global__ __launch_bounds__(256) void k_image_loss(int H, int W, const float* __restrict__ pred, const float* __restrict__ target,
+                                                    float mse_scale, float ssim_scale, float* __restrict__ grad, float* __restrict__ partials) {
+  __shared__ float x1[kLossIn][kLossIn + 1], x2[kLossIn][kLossIn + 1];
+  __shared__ float hz[5][kLossIn][kLossMid + 1];     // horizontal pass of x1, x2, x1^2, x2^2, x1 x2 (rows: 36, columns: 26)
+  __shared__ float mp[3][kLossMid][kLossMid + 1];    // a, b, dmu on the 26 x 26 region
+  __shared__ float hb[3][kLossMid][kLossTile + 1];   // their horizontal pass (rows: 26, columns: 16)
+  __shared__ float red[3][4];
+  const int tid = threadIdx.x, img_c = blockIdx.z;   // image * 3 + channel
+  const int ox = blockIdx.x * kLossTile, oy = blockIdx.y * kLossTile;
+  const float* p1 = pred + (size_t)img_c * H * W;
+  const float* p2 = target + (size_t)img_c * H * W;
+  // window: exp(-(k - 5)^2 / (2 sigma^2)) normalised, sigma = 1.5 (loss_multissim.py:50-52), as the reference computes it in fp32
+  float wgt[11];
+  {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { wgt[k] = expf(-(float)((k - 5) * (k - 5)) / 4.5f); s += wgt[k]; }
+#pragma unroll
+    for (int k = 0; k < 11; ++k) wgt[k] /= s;
+  }
+  for (int e = tid; e < kLossIn * kLossIn; e += 256) {
+    const int r = e / kLossIn, c = e - r * kLossIn, y = oy - 2 * kLossR + r, x = ox - 2 * kLossR + c;
+    const bool in = x >= 0 && x < W && y >= 0 && y < H;
+    x1[r][c] = in ? p1[(size_t)y * W + x] : 0.f;
+    x2[r][c] = in ? p2[(size_t)y * W + x] : 0.f;
+  }
+  __syncthreads();
+  for (int e = tid; e < kLossIn * kLossMid; e += 256) {
+    const int r = e / kLossMid, c = e - r * kLossMid;
+    float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float a = x1[r][c + k], b = x2[r][c + k], w = wgt[k];
+      s1 += w * a; s2 += w * b; s11 += w * (a * a); s22 += w * (b * b); s12 += w * (a * b);
+    }
+    hz[0][r][c] = s1; hz[1][r][c] = s2; hz[2][r][c] = s11; hz[3][r][c] = s22; hz[4][r][c] = s12;
+  }
+  __syncthreads();
+  float sum_s = 0.f;
+  constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+  for (int e = tid; e < kLossMid * kLossMid; e += 256) {
+    const int r = e / kLossMid, c = e - r * kLossMid, y = oy - kLossR + r, x = ox - kLossR + c;
+    float mu1 = 0, mu2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+      const float w = wgt[k];
+      mu1 += w * hz[0][r + k][c]; mu2 += w * hz[1][r + k][c]; s11 += w * hz[2][r + k][c]; s22 += w * hz[3][r + k][c]; s12 += w * hz[4][r + k][c];
+    }
+    float a = 0.f, b = 0.f, dmu = 0.f;
+    if (x >= 0 && x < W && y >= 0 && y < H) {
+      const float A = 2.f * mu1 * mu2 + C1, B = 2.f * (s12 - mu1 * mu2) + C2;
+      const float C = mu1 * mu1 + mu2 * mu2 + C1, D = (s11 - mu1 * mu1) + (s22 - mu2 * mu2) + C2;
+      const float iC = 1.f / C, iD = 1.f / D, AB = A * B;
+      a = -AB * iC * iD * iD;
+      b = 2.f * A * iC * iD;
+      dmu = 2.f * mu2 * (B - A) * iC * iD - 2.f * mu1 * AB * iC * iC * iD + 2.f * mu1 * AB * iC * iD * iD;
+      if (r >= kLossR && r < kLossR + kLossTile && c >= kLossR && c < kLossR + kLossTile) sum_s += AB * iC * iD;  // this tile's own pixels
+    }
+    mp[0][r][c] = a; mp[1][r][c] = b; mp[2][r][c] = dmu;
+  }
+  __syncthreads();
+  for (int e = tid; e < kLossMid * kLossTile; e += 256) {
+    const int r = e / kLossTile, c = e - r * kLossTile;
+    float s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { const float w = wgt[k]; s0 += w * mp[0][r][c + k]; s1 += w * mp[1][r][c + k]; s2 += w * mp[2][r][c + k]; }
+    hb[0][r][c] = s0; hb[1][r][c] = s1; hb[2][r][c] = s2;
+  }
+  __syncthreads();
+  float sum_se = 0.f, sum_ce = 0.f;
+  {
+    const int r = tid / kLossTile, c = tid - r * kLossTile, y = oy + r, x = ox + c;
+    if (x < W && y < H) {
+      float wa = 0, wb = 0, wm = 0;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) { const float w = wgt[k]; wa += w * hb[0][r + k][c]; wb += w * hb[1][r + k][c]; wm += w * hb[2][r + k][c]; }
+      const float v1 = x1[r + 2 * kLossR][c + 2 * kLossR], v2 = x2[r + 2 * kLossR][c + 2 * kLossR];
+      const float d = v1 - v2;
+      sum_se = d * d;
+      const float dc = fminf(fmaxf(v2, 0.f), 1.f) - fminf(fmaxf(v1, 0.f), 1.f);
+      sum_ce = dc * dc;
+      if (grad) grad[(size_t)img_c * H * W + (size_t)y * W + x] = mse_scale * 2.f * d - ssim_scale * (wm + 2.f * v1 * wa + v2 * wb);
+    }
+  }
+  sum_se = wave_sum(sum_se); sum_ce = wave_sum(sum_ce); sum_s = wave_sum(sum_s);
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sum_se; red[1][tid >> 6] = sum_ce; red[2][tid >> 6] = sum_s; }
+  __syncthreads();
+  if (tid < 3) {
+    const size_t slot = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    partials[slot * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+    if (tid == 0) partials[slot * 4 + 3] = 0.f;
+  }
+}
+}  // namespace gsr
+
+extern "C" {
+
+size_t gsr_image_loss_partials(int num_images, int height, int width) {
+  if (num_images <= 0 || height <= 0 || width <= 0) return 0;
+  return (size_t)num_images * 3 * ((height + gsr::kLossTile - 1) / gsr::kLossTile) * ((width + gsr::kLossTile - 1) / gsr::kLossTile);
+}
+
+int gsr_image_loss(int num_images, int height, int width, const float* prediction, const float* target, float mse_weight,
+                   float ssim_weight, float* dL_dprediction, float* partials, void* stream_) {
+  if (num_images < 0 || height <= 0 || width <= 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (num_images == 0) return GSR_OK;
+  if (!prediction || !target || !partials || (size_t)num_images * 3 > 65535) return GSR_ERR_INVALID_ARGUMENT;
+  const double count = (double)num_images * 3.0 * height * width;  // both reference losses average over every element
+  const dim3 grid((unsigned)((width + gsr::kLossTile - 1) / gsr::kLossTile), (unsigned)((height + gsr::kLossTile - 1) / gsr::kLossTile),
+                  (unsigned)num_images * 3u);
+  hipLaunchKernelGGL(gsr::k_image_loss, grid, dim3(256), 0, static_cast<hipStream_t>(stream_), height, width, prediction, target,
+                     (float)(mse_weight / count), (float)(ssim_weight / count), dL_dprediction, partials);
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
 }
