@@ -183,6 +183,28 @@ int gsr_backward_scale_rot(const GsrDims* dims, const GsrView* views, const floa
                            const float* dL_dextra_img, void* scratch, float* dL_dmeans, float* dL_dscale_rot,
                            float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream);
 
+/* gsr_backward with options (camera-pose gradients, opt-in - the reference gets none through the operator
+ * although PF3plat learns poses).  opt == NULL: exactly gsr_backward.  scale_rot != 0: `cov` / `dL_dcov` are (S, N, 7) records
+ * with `frames` / `num_frames` as in gsr_backward_scale_rot.  dL_dviews != NULL: (V, 48) floats laid out like GsrView receive
+ * dL/d viewmatrix [0, 16), dL/d projmatrix [16, 32), dL/d campos [32, 35) (zeros behind) - the two matrices as independent
+ * inputs, the way the operator takes them; tan-fov, background and scale get none.  Every place the forward reads a camera
+ * is differentiated (EWA covariance through t = V p and J Wr, projection to pixel coordinates, view direction of the
+ * harmonics, depth of the built-in extra channel); depth ordering and culling are not, as for the Gaussians.  pose_partials:
+ * gsr_pose_partials_bytes(dims) bytes of scratch (one row per view and 64-Gaussian unit; reduced in a fixed order). */
+typedef struct GsrBackwardOptions {
+  const float* frames;
+  int32_t num_frames;
+  int32_t scale_rot;
+  float* dL_dviews;
+  float* pose_partials;
+} GsrBackwardOptions;
+size_t gsr_pose_partials_bytes(const GsrDims* dims);
+int gsr_backward_ex(const GsrDims* dims, const GsrView* views, const float* means, const float* cov, const float* opacities,
+                    const float* colors, const float* extra, const void* geom, const void* bin, const void* img,
+                    const float* dL_dcolor, const float* dL_dextra_img, void* scratch, float* dL_dmeans, float* dL_dcov,
+                    float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, const GsrBackwardOptions* opt,
+                    void* stream);
+
 /* GSR_FLAG_DEBUG: the stage of the last failed call of this host thread (forward: 0 preprocess/binning, 1 count + scans,
  * 2 emit, 3 sort + colour, 4 blend; backward: 0 blend backward, 1 preprocess backward), or -1. */
 int gsr_last_failed_stage(void);

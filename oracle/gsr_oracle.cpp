@@ -58,14 +58,14 @@ void* forward(const int* dims, const R* view, const R* proj, const R* campos, R 
 
 template <class R>
 void backward(void* hv, const R* dL_dcolor, const R* dL_dextra_pix, R* dL_dmeans, R* dL_dcov6, R* dL_dopac,
-              R* dL_dsh_or_rgb, R* dL_dextra, R* dL_dmeans2D, R* dL_dscales, R* dL_drots, int threads) {
+              R* dL_dsh_or_rgb, R* dL_dextra, R* dL_dmeans2D, R* dL_dscales, R* dL_drots, R* dL_dcamera, int threads) {
   auto* h = static_cast<Handle<R>*>(hv);
   omp_set_num_threads(std::max(1, threads));
   ScreenGrads<R> g;
   double t0 = now();
   blend_backward(h->s, dL_dcolor, h->has_extra ? dL_dextra_pix : nullptr, g, threads > 1);
   double t1 = now();
-  preprocess_backward(h->s, g, dL_dmeans, dL_dcov6, dL_dopac, dL_dsh_or_rgb, dL_dextra, dL_dmeans2D, dL_dscales, dL_drots);
+  preprocess_backward(h->s, g, dL_dmeans, dL_dcov6, dL_dopac, dL_dsh_or_rgb, dL_dextra, dL_dmeans2D, dL_dscales, dL_drots, dL_dcamera);
   double t2 = now();
   h->t_bwd_blend = t1 - t0; h->t_bwd_pre = t2 - t1;
 }
@@ -121,9 +121,9 @@ extern "C" {
   }                                                                                                                  \
   void gsro_backward_##SUF(void* h, const R* dL_dcolor, const R* dL_dextra_pix, R* dL_dmeans, R* dL_dcov6,           \
                            R* dL_dopac, R* dL_dsh_or_rgb, R* dL_dextra, R* dL_dmeans2D, R* dL_dscales, R* dL_drots,  \
-                           int threads) {                                                                            \
+                           R* dL_dcamera, int threads) {                                                             \
     backward<R>(h, dL_dcolor, dL_dextra_pix, dL_dmeans, dL_dcov6, dL_dopac, dL_dsh_or_rgb, dL_dextra, dL_dmeans2D,   \
-                dL_dscales, dL_drots, threads);                                                                      \
+                dL_dscales, dL_drots, dL_dcamera, threads);                                                          \
   }                                                                                                                  \
   void gsro_get_geom_##SUF(void* h, R* xy, R* depth, R* conic_opacity, R* rgb, int* tiles_touched,                   \
                            uint8_t* clamped, int* rect) {                                                            \

@@ -519,7 +519,13 @@ void blend_backward(const State<R>& s, const R* dL_dpix, const R* dL_dextra_pix,
 // [EXT] backward.cu computeCov2DCUDA, preprocessCUDA (projection + SH), computeCov3D.
 template <class R>
 void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmeans, R* dL_dcov6, R* dL_dopac,
-                         R* dL_dsh_or_rgb, R* dL_dextra, R* dL_dmeans2D, R* dL_dscales, R* dL_drots) {
+                         R* dL_dsh_or_rgb, R* dL_dextra, R* dL_dmeans2D, R* dL_dscales, R* dL_drots,
+                         R* dL_dcamera = nullptr) {
+  // dL_dcamera (optional, 35 values): gradient of the camera the operator was given - viewmatrix [0,16), projmatrix [16,32),
+  // campos [32,35) as independent inputs.  The upstream extension returns none (rasterize_points.cu:119 ff. hands back
+  // gradients of the Gaussians only); this is the chain rule through the same forward statements with the same conventions as
+  // the Gaussians' gradients above (clamped frustum coordinates pass no gradient, depth order and culling are constants).
+  // Pinned by fp64 finite differences in tests/test_oracle_pose_grad.py.
   const Dims& d = s.d;
   const int P = d.P, W = d.W, H = d.H;
   const Camera<R>& cam = s.cam;
@@ -533,9 +539,12 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
   if (dL_dmeans2D) std::fill(dL_dmeans2D, dL_dmeans2D + 3 * (size_t)P, R(0));
   if (dL_dscales) std::fill(dL_dscales, dL_dscales + 3 * (size_t)P, R(0));
   if (dL_drots) std::fill(dL_drots, dL_drots + 4 * (size_t)P, R(0));
+  if (dL_dcamera) std::fill(dL_dcamera, dL_dcamera + 35, R(0));
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < P; ++i) {
     if (!(s.radii[i] > 0)) continue;
+    R dcamera[35];
+    for (int k = 0; k < 35; ++k) dcamera[k] = R(0);
     const R* p = &s.means[3 * (size_t)i];
     const R* cov6 = &s.cov6_used[6 * (size_t)i];
     dL_dopac[i] = g.dopacity[i];
@@ -586,6 +595,17 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
     // transformVec4x3Transpose: dL/dmean_j = sum_i Wr[i][j] dt_i, Wr[i][j] = view[4*j+i]
     R dmean[3];
     for (int j = 0; j < 3; ++j) dmean[j] = v[4 * j + 0] * dtx + v[4 * j + 1] * dty + v[4 * j + 2] * dtz;
+    {  // camera: t_k = sum_j view[4j+k] p_j (p_3 = 1);  M_0j = J00 view[4j] + J02 view[4j+2],  M_1j = J11 view[4j+1] + J12 view[4j+2]
+      const R ph[4] = {p[0], p[1], p[2], R(1)}, dt[3] = {dtx, dty, dtz};
+      for (int j = 0; j < 4; ++j)
+        for (int k = 0; k < 3; ++k) dcamera[4 * j + k] += dt[k] * ph[j];
+      const R J00 = c2.fx * tz, J02 = -c2.fx * c2.t[0] * tz2, J11 = c2.fy * tz, J12 = -c2.fy * c2.t[1] * tz2;
+      for (int j = 0; j < 3; ++j) {
+        dcamera[4 * j + 0] += dM[j] * J00;
+        dcamera[4 * j + 1] += dM[3 + j] * J11;
+        dcamera[4 * j + 2] += dM[j] * J02 + dM[3 + j] * J12;
+      }
+    }
     // --- preprocessCUDA backward: projection
     R m_hom[4];
     xform4x4(cam.proj, p, m_hom);
@@ -597,6 +617,15 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
     dmean[0] += (pr[0] * m_w - pr[3] * mul1) * d2x + (pr[1] * m_w - pr[3] * mul2) * d2y;
     dmean[1] += (pr[4] * m_w - pr[7] * mul1) * d2x + (pr[5] * m_w - pr[7] * mul2) * d2y;
     dmean[2] += (pr[8] * m_w - pr[11] * mul1) * d2x + (pr[9] * m_w - pr[11] * mul2) * d2y;
+    {  // camera: p_hom_k = sum_j proj[4j+k] p_j;  ndc = p_hom.xy / (p_hom.w + eps)
+      const R ph[4] = {p[0], p[1], p[2], R(1)};
+      const R gx = d2x * m_w, gy = d2y * m_w, gw = -(d2x * mul1 + d2y * mul2);
+      for (int j = 0; j < 4; ++j) {
+        dcamera[16 + 4 * j + 0] += gx * ph[j];
+        dcamera[16 + 4 * j + 1] += gy * ph[j];
+        dcamera[16 + 4 * j + 3] += gw * ph[j];
+      }
+    }
     // --- SH backward
     if (d.M > 0) {
       const R dir_o[3] = {p[0] - cam.campos[0], p[1] - cam.campos[1], p[2] - cam.campos[2]};
@@ -620,13 +649,19 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
       // dnormvdv
       const R sum2 = dir_o[0] * dir_o[0] + dir_o[1] * dir_o[1] + dir_o[2] * dir_o[2];
       const R invsum32 = R(1) / std::sqrt(sum2 * sum2 * sum2);
-      dmean[0] += ((sum2 - dir_o[0] * dir_o[0]) * ddir[0] - dir_o[1] * dir_o[0] * ddir[1] - dir_o[2] * dir_o[0] * ddir[2]) * invsum32;
-      dmean[1] += (-dir_o[0] * dir_o[1] * ddir[0] + (sum2 - dir_o[1] * dir_o[1]) * ddir[1] - dir_o[2] * dir_o[1] * ddir[2]) * invsum32;
-      dmean[2] += (-dir_o[0] * dir_o[2] * ddir[0] - dir_o[1] * dir_o[2] * ddir[1] + (sum2 - dir_o[2] * dir_o[2]) * ddir[2]) * invsum32;
+      const R gd[3] = {
+          ((sum2 - dir_o[0] * dir_o[0]) * ddir[0] - dir_o[1] * dir_o[0] * ddir[1] - dir_o[2] * dir_o[0] * ddir[2]) * invsum32,
+          (-dir_o[0] * dir_o[1] * ddir[0] + (sum2 - dir_o[1] * dir_o[1]) * ddir[1] - dir_o[2] * dir_o[1] * ddir[2]) * invsum32,
+          (-dir_o[0] * dir_o[2] * ddir[0] - dir_o[1] * dir_o[2] * ddir[1] + (sum2 - dir_o[2] * dir_o[2]) * ddir[2]) * invsum32};
+      for (int j = 0; j < 3; ++j) { dmean[j] += gd[j]; dcamera[32 + j] -= gd[j]; }  // direction = mean - campos
     } else {
       for (int ch = 0; ch < 3; ++ch) dL_dsh_or_rgb[3 * (size_t)i + ch] = g.dcolor[3 * (size_t)i + ch];
     }
     for (int j = 0; j < 3; ++j) dL_dmeans[3 * (size_t)i + j] = dmean[j];
+    if (dL_dcamera) {
+#pragma omp critical(gsro_camera_grad)
+      for (int k = 0; k < 35; ++k) dL_dcamera[k] += dcamera[k];
+    }
     if (!d.use_scale_rot) {
       for (int k = 0; k < 6; ++k) dL_dcov6[6 * (size_t)i + k] = dcov[k];
     } else {

@@ -153,11 +153,12 @@ class OracleRasterizer:
             "means2D": np.zeros((P, 3), self.dtype),
             "scales": np.zeros((P, 3), self.dtype) if use_sr else None,
             "rotations": np.zeros((P, 4), self.dtype) if use_sr else None,
+            "camera": np.zeros((35,), self.dtype),  # viewmatrix [0,16), projmatrix [16,32), campos [32,35) - see gsr_oracle.hpp
         }
         fn = getattr(self.lib, f"gsro_backward_{self.suf}")
         fn(ctypes.c_void_p(self._h), _ptr(g), _ptr(ge), _ptr(out["means3D"]), _ptr(out["cov3D_precomp"]),
            _ptr(out["opacities"]), _ptr(out["colors"]), _ptr(out["extra"]), _ptr(out["means2D"]),
-           _ptr(out["scales"]), _ptr(out["rotations"]), ctypes.c_int(self.threads))
+           _ptr(out["scales"]), _ptr(out["rotations"]), _ptr(out["camera"]), ctypes.c_int(self.threads))
         st = (ctypes.c_longlong * 8)()
         tm = (ctypes.c_double * 5)()
         getattr(self.lib, f"gsro_stats_{self.suf}")(ctypes.c_void_p(self._h), st, tm)

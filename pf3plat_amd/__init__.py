@@ -8,6 +8,7 @@ from .rasterizer import (  # noqa: F401
     get_backend,
     pack_views,
     rasterize_views,
+    views_from_cameras,
 )
 from .splatting import (  # noqa: F401
     render_cuda,

@@ -180,6 +180,7 @@ struct Params {
   const float *dL_dcolor, *dL_dextra_img;
   float* scratch;
   float *dL_dmeans, *dL_dcov6, *dL_dopac, *dL_dcolors, *dL_dextra, *dL_dmeans2D;  // (scale_rot: dL_dcov6 is (S, N, 7))
+  float* pose_partials;  // camera gradients requested: [view][preprocess_bwd workgroup][kPoseFloats]
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2126,6 +2127,8 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
 // computeCov2DCUDA + preprocessCUDA; oracle preprocess_backward).  One wavefront per 64 Gaussians of a SET;
 // loops over the set's views so SH is read once and every gradient is written once.
 // ------------------------------------------------------------------------------------------------
+constexpr int kPoseFloats = 35;  // dL/d viewmatrix (16), projmatrix (16), campos (3) of a view
+template <bool kPose>
 __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x, set = blockIdx.y;
@@ -2220,7 +2223,16 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       if (p.dL_dextra) p.dL_dextra[oi] = sg[9];
       if (p.dL_dmeans2D) { p.dL_dmeans2D[3 * oi + 0] = sg[0]; p.dL_dmeans2D[3 * oi + 1] = sg[1]; p.dL_dmeans2D[3 * oi + 2] = 0.f; }
     }
-    if (!vis) continue;
+    // Camera gradients (opt-in): what this (view, Gaussian) contributes to dL/d viewmatrix [0..16), projmatrix
+    // [16..32) and campos [32..35) - every place the forward reads them: t = V p and M = J Wr in the EWA covariance, the
+    // projection p_hom = F p, the view direction of the harmonics, the depth of the built-in extra channel.  Summed over
+    // the wave below, one partial row per (view, workgroup); k_pose_reduce adds the rows up.
+    float pose[kPose ? kPoseFloats : 1];
+    if (kPose) {
+#pragma unroll
+      for (int k = 0; k < kPoseFloats; ++k) pose[k] = 0.f;
+    }
+    if (vis) {
     seen = true;
     const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
     float cov6[6];
@@ -2271,6 +2283,20 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     float dm[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) dm[j] = vw[4 * j + 0] * dtx + vw[4 * j + 1] * dty + vw[4 * j + 2] * dtz;
+    if (kPose) {
+      const float mj[4] = {mx, my, mz, 1.f}, dt[3] = {dtx, dty, dtz};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pose[4 * j + k] += dt[k] * mj[j];  // t_k = sum_j V[4j + k] m_j
+      const float J00 = c2.fx * tz, J02 = -(c2.fx * c2.t0) * tz2, J11 = c2.fy * tz, J12 = -(c2.fy * c2.t1) * tz2;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {  // M[0][j] = J00 V[4j] + J02 V[4j+2],  M[1][j] = J11 V[4j+1] + J12 V[4j+2]
+        pose[4 * j + 0] += dM[j] * J00;
+        pose[4 * j + 1] += dM[3 + j] * J11;
+        pose[4 * j + 2] += dM[j] * J02 + dM[3 + j] * J12;
+      }
+    }
     // --- projection
     const float* pr = cam.projmatrix;
     const float mh3 = pr[3] * mx + pr[7] * my + pr[11] * mz + pr[15];
@@ -2280,6 +2306,16 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     dm[0] += (pr[0] * m_w - pr[3] * mul1) * sg[0] + (pr[1] * m_w - pr[3] * mul2) * sg[1];
     dm[1] += (pr[4] * m_w - pr[7] * mul1) * sg[0] + (pr[5] * m_w - pr[7] * mul2) * sg[1];
     dm[2] += (pr[8] * m_w - pr[11] * mul1) * sg[0] + (pr[9] * m_w - pr[11] * mul2) * sg[1];
+    if (kPose) {  // p_hom_k = sum_j F[4j + k] m_j;  ndc = p_hom.xy / (p_hom.w + eps)
+      const float mj[4] = {mx, my, mz, 1.f};
+      const float gk[4] = {sg[0] * m_w, sg[1] * m_w, 0.f, -(sg[0] * mul1 + sg[1] * mul2)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pose[16 + 4 * j + 0] += gk[0] * mj[j];
+        pose[16 + 4 * j + 1] += gk[1] * mj[j];
+        pose[16 + 4 * j + 3] += gk[3] * mj[j];
+      }
+    }
     // --- SH
     if (M > 0) {
       const float ox = mx - cam.campos[0], oy = my - cam.campos[1], oz = mz - cam.campos[2];
@@ -2309,9 +2345,11 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       else sh_block([] { return 1; }, [&] { return M; });
       const float sum2 = ox * ox + oy * oy + oz * oz;
       const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-      dm[0] += ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
-      dm[1] += (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
-      dm[2] += (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+      const float gdir0 = ((sum2 - ox * ox) * ddx - oy * ox * ddy - oz * ox * ddz) * invsum32;
+      const float gdir1 = (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
+      const float gdir2 = (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
+      dm[0] += gdir0; dm[1] += gdir1; dm[2] += gdir2;
+      if (kPose) { pose[32] -= gdir0; pose[33] -= gdir1; pose[34] -= gdir2; }  // direction = mean - campos
     } else {
       dcol[0] += sg[6]; dcol[1] += sg[7]; dcol[2] += sg[8];
     }
@@ -2324,9 +2362,19 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       (void)extra_from_depth(emode, z, cam.reserved[0], cam.reserved[1], dfdz);
       const float gz = sg[9] * dfdz;
       dmean[0] += gz * vw[2]; dmean[1] += gz * vw[6]; dmean[2] += gz * vw[10];
+      if (kPose) { const float gs = gz / cam.scale; pose[2] += gs * mx; pose[6] += gs * my; pose[10] += gs * mz; pose[14] += gs; }
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
+    }  // vis
+    if (kPose) {
+      float* row = p.pose_partials + ((size_t)v * gridDim.x + blockIdx.x) * kPoseFloats;
+#pragma unroll
+      for (int k = 0; k < kPoseFloats; ++k) {
+        const float s = wave_sum(pose[k]);
+        if (lane == 0) row[k] = s;
+      }
+    }
   }
   if (dbg) stamps[2] = __builtin_amdgcn_s_memrealtime();
   if (in_range) {
@@ -2395,6 +2443,27 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     unsigned long long* o = reinterpret_cast<unsigned long long*>(p.dL_dmeans2D + 3 * ((size_t)set * Vs * N + g0));
     for (int q = 0; q < 5; ++q) o[q] = stamps[q];
   }
+}
+
+// Sum of the per-workgroup camera-gradient rows of one view -> dL/dview record (48 floats: viewmatrix, projmatrix, campos, 0...).
+// Fixed order: deterministic.
+__global__ __launch_bounds__(256) void k_pose_reduce(const float* partials, int rows, float* dL_dviews) {
+  __shared__ float part[4][kPoseFloats];
+  const int v = blockIdx.x, tid = threadIdx.x;
+  const float* base = partials + (size_t)v * rows * kPoseFloats;
+  float acc[kPoseFloats];
+#pragma unroll
+  for (int k = 0; k < kPoseFloats; ++k) acc[k] = 0.f;
+  for (int r = tid; r < rows; r += 256)
+#pragma unroll
+    for (int k = 0; k < kPoseFloats; ++k) acc[k] += base[(size_t)r * kPoseFloats + k];
+#pragma unroll
+  for (int k = 0; k < kPoseFloats; ++k) {
+    const float s = wave_sum(acc[k]);
+    if ((tid & 63) == 0) part[tid >> 6][k] = s;
+  }
+  __syncthreads();
+  if (tid < 48) dL_dviews[(size_t)v * 48 + tid] = tid < kPoseFloats ? part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid] : 0.f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2869,7 +2938,8 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
                          const float* opacities, const float* colors, const float* extra, const void* geom,
                          const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
                          void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
-                         float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_, const SrArgs* sr) {
+                         float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_, const SrArgs* sr,
+                         float* dL_dviews = nullptr, float* pose_partials = nullptr) {
   if (!dims_ok(dims) || !sr_ok(dims, sr)) return GSR_ERR_INVALID_ARGUMENT;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const GsrDims& d = *dims;
@@ -2912,7 +2982,15 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
-  hipLaunchKernelGGL(k_preprocess_bwd, dim3((unsigned)((N + 63) / 64), (unsigned)d.num_sets), dim3(64), shmem, st, p);
+  const dim3 pgrid((unsigned)((N + 63) / 64), (unsigned)d.num_sets);
+  if (dL_dviews) {
+    if (!pose_partials) return GSR_ERR_INVALID_ARGUMENT;
+    p.pose_partials = pose_partials;
+    hipLaunchKernelGGL(k_preprocess_bwd<true>, pgrid, dim3(64), shmem, st, p);
+    hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V), dim3(256), 0, st, pose_partials, (int)pgrid.x, dL_dviews);
+  } else {
+    hipLaunchKernelGGL(k_preprocess_bwd<false>, pgrid, dim3(64), shmem, st, p);
+  }
   GSR_STAGE_DONE(1);
 #undef GSR_STAGE_DONE
   if (ev) GSR_CHECK(hipEventRecord(ev[e++], st));
@@ -2946,6 +3024,24 @@ int gsr_backward_scale_rot(const GsrDims* dims, const GsrView* views, const floa
   const SrArgs sr{frames, num_frames};
   return backward_impl(dims, views, means, scale_rot, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img,
                        scratch, dL_dmeans, dL_dscale_rot, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_, &sr);
+}
+
+size_t gsr_pose_partials_bytes(const GsrDims* dims) {
+  if (!dims_ok(dims)) return 0;
+  return (size_t)dims->num_views * (size_t)((dims->num_gaussians + 63) / 64) * kPoseFloats * sizeof(float);
+}
+
+int gsr_backward_ex(const GsrDims* dims, const GsrView* views, const float* means, const float* cov, const float* opacities,
+                    const float* colors, const float* extra, const void* geom, const void* bin, const void* img,
+                    const float* dL_dcolor, const float* dL_dextra_img, void* scratch, float* dL_dmeans, float* dL_dcov,
+                    float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, const GsrBackwardOptions* opt,
+                    void* stream_) {
+  if (!opt) return backward_impl(dims, views, means, cov, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img, scratch,
+                                 dL_dmeans, dL_dcov, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_, nullptr);
+  const SrArgs sr{opt->frames, opt->num_frames};
+  return backward_impl(dims, views, means, cov, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img, scratch,
+                       dL_dmeans, dL_dcov, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_, opt->scale_rot ? &sr : nullptr,
+                       opt->dL_dviews, opt->pose_partials);
 }
 
 // Measurement aid (bench.py): gsr_backward with events between its two stages (blend backward, preprocess backward);

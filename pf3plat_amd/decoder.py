@@ -60,12 +60,14 @@ class DecoderSplattingCUDA(Decoder):
         far: Tensor,  # (batch, view)
         image_shape: tuple,
         depth_mode: Optional[DepthRenderingMode] = None,
+        pose_gradients: bool = False,  # extension: let the render's gradient reach `extrinsics`
     ) -> DecoderOutput:
         color, depth = render_views(
             extrinsics, intrinsics, near, far, image_shape,
             self.background_color.to(extrinsics.device),
             gaussians.means, gaussians.covariances, gaussians.harmonics, gaussians.opacities,
             depth_mode=depth_mode, gaussian_scales=gaussians.scales, gaussian_rotations=gaussians.rotations, frames=gaussians.frames,
+            pose_gradients=pose_gradients,
         )
         return DecoderOutput(color, depth)
 

@@ -249,7 +249,8 @@ class HipBackend:
         return None if ms is None else dict(zip(_lib.FWD_STAGES, [float(x) for x in ms]))
 
     def run_backward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img=None,
-                     want_means2d: bool = True, profile: bool = False, frames=None):
+                     want_means2d: bool = True, profile: bool = False, frames=None, d_views=None):
+        """d_views: a (V, 48) fp32 tensor that receives the camera gradients (gsr_backward_ex)."""
         cfg = plan["cfg"]
         stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
@@ -258,7 +259,16 @@ class HipBackend:
                 _ptr(plan["d_cov6"]), _ptr(plan["d_opac"]), _ptr(plan["d_colors"]), _ptr(plan["d_extra"]),
                 _ptr(plan["d_means2d"] if want_means2d else None), stream)
         with torch.cuda.device(plan["device"]):
-            if cfg.scale_rot:
+            if d_views is not None:
+                fr, nf = self._frames_args(cfg, frames) if cfg.scale_rot else (None, 0)
+                partials = plan.get("pose_partials")
+                if partials is None:
+                    partials = plan["pose_partials"] = torch.empty(
+                        max(16, int(self.lib.gsr_pose_partials_bytes(args[0]))), dtype=torch.uint8, device=plan["device"])
+                opt = _lib.GsrBackwardOptions(_ptr(fr), nf, int(cfg.scale_rot), _ptr(d_views), _ptr(partials))
+                ms = None
+                rc = self.lib.gsr_backward_ex(*args[:-1], ctypes.byref(opt), stream)
+            elif cfg.scale_rot:
                 fr, nf = self._frames_args(cfg, frames)
                 ms = None
                 rc = self.lib.gsr_backward_scale_rot(*args[:4], _ptr(fr), nf, *args[4:])
@@ -355,9 +365,10 @@ class HipBackend:
             self.check_pending(only_ws=binb.data_ptr())
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
-                 want_means2d: bool, rows_in_workspace: bool = False, frames=None):
+                 want_means2d: bool, rows_in_workspace: bool = False, frames=None, want_views: bool = False):
         """rows_in_workspace: the forward ran with FLAG_BACKWARD_FOLLOWS and this is the first backward over it - accumulate
-        into the rows it zero-filled inside geom (no scratch, no zero-fill pass)."""
+        into the rows it zero-filled inside geom (no scratch, no zero-fill pass).  want_views: a seventh result, the (V, 48)
+        gradient of the camera records (view matrix, projection matrix, camera centre)."""
         dims, geom, binb, img = saved
         dev = viewbuf.device
         v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
@@ -377,8 +388,13 @@ class HipBackend:
             if cfg.has_extra:
                 g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
                                else g_extra_img.contiguous().to(f32))
-            self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d, frames=frames)
-        return plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
+            d_views = torch.empty((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
+            self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d, frames=frames,
+                              d_views=d_views)
+        else:
+            d_views = torch.zeros((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
+        out = plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
+        return out + (d_views,) if want_views else out
 
     def setup_views(self, extrinsics, intrinsics, near, far, background, scale_invariant: bool = True) -> Tensor:
         """(V,4,4) c2w, (V,3,3), (V,), (V,), (3,) or (V,3) -> (V,48) camera records, one kernel launch (gsr_setup_views)."""
@@ -486,13 +502,19 @@ class _RasterizeViews(torch.autograd.Function):
             extra = None  # built-in mode: no extra array; its gradient is folded into d_means by the backward kernel
         if g_color is None:
             g_color = torch.zeros((cfg.num_views, 3, cfg.height, cfg.width), dtype=torch.float32, device=means.device)
-        d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
-            cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d,
-            rows_in_workspace=ctx.rows_fresh, frames=ctx.frames)
+        if ctx.needs_input_grad[6]:  # cameras being learned (PF3plat's pose refinement): opt-in, SURVEY 8f-3
+            d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, d_views = ctx.backend.backward(
+                cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d,
+                rows_in_workspace=ctx.rows_fresh, frames=ctx.frames, want_views=True)
+        else:
+            d_views = None
+            d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
+                cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d,
+                rows_in_workspace=ctx.rows_fresh, frames=ctx.frames)
         ctx.rows_fresh = False
         # the workspaces stay with ctx (freed with the graph): a second backward (retain_graph=True, several autograd.grad
         # calls over one render) runs on them again, as upstream's Function can
-        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, None, None, None
+        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, d_views, None, None
 
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
@@ -545,7 +567,7 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
         deterministic = torch.are_deterministic_algorithms_enabled()
     flags |= (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_PREFILTERED if prefiltered else 0)
     flags |= _lib.FLAG_DETERMINISTIC if deterministic else 0
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (means, cov6, opacities, colors, extra, means2d)):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (means, cov6, opacities, colors, extra, means2d, viewbuf)):
         flags |= _lib.FLAG_BACKWARD_FOLLOWS  # the forward zero-fills the backward's accumulator rows on its way
     if extra_mode is not None:
         if extra is not None:
@@ -557,6 +579,49 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg,
                                                     frames)
     return color, (extra_img if has_extra else None), radii
+
+
+class _SetupViews(torch.autograd.Function):
+    """Camera records from camera-to-world extrinsics with a gradient path back to the extrinsics: the forward
+    is the library's one-launch set-up (gsr_setup_views); the backward carries the (V, 48) record gradient that
+    `rasterize_views` returns through  view = inv(c2w')^T,  full = view P^T,  campos = c2w'[:3, 3]  (c2w' = c2w with its
+    translation times 1 / near when scale_invariant) in closed form - a handful of 4x4 products per view.  Intrinsics, near
+    and far get no gradient (the operator itself treats the fields of view as constants)."""
+
+    @staticmethod
+    def forward(ctx, extrinsics, intrinsics, near, far, background, scale_invariant: bool):
+        viewbuf = get_backend().setup_views(extrinsics, intrinsics, near, far, background, scale_invariant)
+        ctx.save_for_backward(viewbuf)
+        ctx.ext_dtype = extrinsics.dtype
+        return viewbuf
+
+    @staticmethod
+    def backward(ctx, d_views):
+        (vb,) = ctx.saved_tensors
+        v = vb.shape[0]
+        vb, d_views = vb.double(), d_views.double()
+        w2c = vb[:, 0:16].reshape(v, 4, 4).transpose(1, 2)  # records hold the transposed world-to-camera matrix
+        scale, near, far = vb[:, 40], vb[:, 43] * vb[:, 40], vb[:, 44] * vb[:, 40]
+        proj = torch.zeros((v, 4, 4), dtype=torch.float64, device=vb.device)
+        proj[:, 0, 0], proj[:, 1, 1] = 1.0 / vb[:, 35], 1.0 / vb[:, 36]
+        proj[:, 2, 2], proj[:, 2, 3], proj[:, 3, 2] = far / (far - near), -(far * near) / (far - near), 1.0
+        d_view = d_views[:, 0:16].reshape(v, 4, 4) + d_views[:, 16:32].reshape(v, 4, 4) @ proj  # full = view @ proj^T
+        d_w2c = d_view.transpose(1, 2)
+        d_ext = -(w2c.transpose(1, 2) @ d_w2c @ w2c.transpose(1, 2))  # A = B^-1  =>  dL/dB = -A^T (dL/dA) A^T
+        d_ext[:, :3, 3] += d_views[:, 32:35]
+        d_ext[:, :3, 3] *= scale[:, None]
+        return d_ext.to(ctx.ext_dtype), None, None, None, None, None
+
+
+def views_from_cameras(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far: Tensor, background: Tensor,
+                       scale_invariant: bool = True, pose_gradients: bool = False) -> Tensor:
+    """(V,4,4) camera-to-world, (V,3,3) normalised intrinsics, (V,), (V,), (3,) | (V,3) -> (V,48) camera records in one launch
+    (the arithmetic of cuda_splatting.py:64-71, :80-87).  pose_gradients: keep a gradient path from the render back to
+    `extrinsics` (the reference has none through its rasterizer: opt-in)."""
+    if pose_gradients and torch.is_grad_enabled() and extrinsics.requires_grad:
+        return _SetupViews.apply(extrinsics, intrinsics, near, far, background, bool(scale_invariant))
+    with torch.no_grad():
+        return get_backend().setup_views(extrinsics, intrinsics, near, far, background, scale_invariant)
 
 
 class _CovFromScaleRot(torch.autograd.Function):

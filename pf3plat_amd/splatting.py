@@ -20,16 +20,16 @@ from typing import Optional
 import torch
 from torch import Tensor
 
-from .rasterizer import get_backend, rasterize_views
+from .rasterizer import get_backend, rasterize_views, views_from_cameras
 from .types import DepthRenderingMode
 
 
-def _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invariant: bool) -> Tensor:
+def _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invariant: bool, pose_gradients: bool = False) -> Tensor:
     """Camera records for `rasterize_views`: the arithmetic of the reference wrapper at cuda_splatting.py:64-71 / :80-87
     (1 / near rescale, get_fov, get_projection_matrix, extrinsics.inverse(), view @ proj) in ONE launch of the raster
-    library (`gsr_setup_views`), straight into the records the kernels read.  Cameras carry no gradient (settings object)."""
-    with torch.no_grad():
-        return get_backend().setup_views(extrinsics, intrinsics, near, far, background_color, scale_invariant)
+    library (`gsr_setup_views`), straight into the records the kernels read.  Cameras carry no gradient (settings object)
+    unless pose_gradients asks for one."""
+    return views_from_cameras(extrinsics, intrinsics, near, far, background_color, scale_invariant, pose_gradients)
 
 
 def render_cuda(
@@ -144,6 +144,7 @@ def render_views(
     gaussian_scales: Optional[Tensor] = None,  # (scene, gaussian, 3)   } instead of gaussian_covariances (pass None there):
     gaussian_rotations: Optional[Tensor] = None,  # (scene, gaussian, 4) } the covariance is built inside the kernels
     frames: Optional[Tensor] = None,  # (scene, F, 3, 3) world rotation per group of gaussian / F consecutive Gaussians
+    pose_gradients: bool = False,  # opt-in: the render's gradient reaches `extrinsics` (the reference's does not)
 ):
     """Fused decoder path: all views of all scenes in one launch chain, Gaussians read once per scene
     (no V-fold `repeat`, reference decoder_splatting_cuda.py:52-56), depth as a 4th blended channel.
@@ -154,7 +155,7 @@ def render_views(
     nr, fr = near.reshape(s * v), far.reshape(s * v)
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
-    viewbuf = _viewbuf(ext, intr, nr, fr, background_color.reshape(3), scale_invariant)
+    viewbuf = _viewbuf(ext, intr, nr, fr, background_color.reshape(3), scale_invariant, pose_gradients)
     if gaussian_covariances is None:  # scale + quaternion records, as the encoder's adapter emits them
         records = torch.cat((gaussian_scales, gaussian_rotations), dim=-1)
         color, depth, _ = rasterize_views(

@@ -51,7 +51,7 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
 
 
 def run_both(cfg: RasterConfig, viewbuf_cpu, means, cov6, opac, colors, extra=None, g_color=None, g_extra=None,
-             oracle_dtype=np.float32, want_means2d=True, capacity=None):
+             oracle_dtype=np.float32, want_means2d=True, capacity=None, want_views=False):
     """Forward (+ backward if g_color is given) on the HIP backend and on the oracle.  Inputs are CPU torch tensors."""
     dev = torch.device("cuda:0")
     hip = rasterizer.HipBackend()
@@ -68,10 +68,10 @@ def run_both(cfg: RasterConfig, viewbuf_cpu, means, cov6, opac, colors, extra=No
                            stats=ob.last_stats))
     if g_color is not None:
         hg = hip.backward(cfg, hsaved, vb_gpu, *args_gpu, g_color.to(dev), None if g_extra is None else g_extra.to(dev),
-                          want_means2d)
+                          want_means2d, want_views=want_views)
         torch.cuda.synchronize()
-        og = ob.backward(cfg, osaved, viewbuf_cpu, *args_cpu, g_color, g_extra, want_means2d)
-        names = ("means", "cov6", "opac", "colors", "extra", "means2d")
+        og = ob.backward(cfg, osaved, viewbuf_cpu, *args_cpu, g_color, g_extra, want_means2d, want_views=want_views)
+        names = ("means", "cov6", "opac", "colors", "extra", "means2d", "views")
         out["hip"]["grads"] = {n: (None if t is None else t.cpu().numpy()) for n, t in zip(names, hg)}
         out["oracle"]["grads"] = {n: (None if t is None else t.numpy()) for n, t in zip(names, og)}
     return out

@@ -111,7 +111,7 @@ class OracleBackend:
         return color, extra_img, radii, handles
 
     def backward(self, cfg, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d,
-                 rows_in_workspace=False, frames=None):
+                 rows_in_workspace=False, frames=None, want_views=False):
         sr_graph = None
         if getattr(cfg, "scale_rot", False):
             sr_graph = saved[-1]
@@ -128,6 +128,7 @@ class OracleBackend:
         emode = (cfg.flags >> 4) & 7
         d_extra = torch.zeros((V, N), dtype=tdt) if (cfg.has_extra and not emode) else None
         d_m2d = torch.zeros((V, N, 3), dtype=tdt) if want_means2d else None
+        d_views = torch.zeros((V, 48), dtype=tdt)
         for v in range(V):
             s = v // cfg.views_per_set
             o, f = saved[v]
@@ -136,11 +137,16 @@ class OracleBackend:
             d_means[s] += torch.from_numpy(g["means3D"]) * float(f["scale"])
             d_cov6[s] += torch.from_numpy(g["cov3D_precomp"]) * float(f["scale2"])
             d_opac[s] += torch.from_numpy(g["opacities"])
+            d_views[v, :35] = torch.from_numpy(g["camera"])
             d_colors[s] += torch.from_numpy(g["colors"])
             if cfg.has_extra and emode:
                 vm = f["viewmatrix"]
                 gz = torch.from_numpy(np.asarray(g["extra"] * f["dfdz"]))
                 d_means[s] += gz[:, None] * torch.tensor([vm[2], vm[6], vm[10]], dtype=tdt)[None, :]
+                # the built-in channel's depth z = (viewmatrix[2,6,10,14] . (m scale, 1)) / scale reads the camera too
+                m_s = means[s].detach().cpu().to(tdt)
+                d_views[v, [2, 6, 10]] += (gz[:, None] * m_s).sum(0)
+                d_views[v, 14] += gz.sum() / float(f["scale"])
             elif cfg.has_extra:
                 d_extra[v] = torch.from_numpy(g["extra"])
             if want_means2d:
@@ -157,7 +163,8 @@ class OracleBackend:
             sr_leaf, cov_graph = sr_graph
             (d_cov6,) = torch.autograd.grad(cov_graph, sr_leaf, d_cov6.to(cov_graph.dtype), retain_graph=True)
             d_cov6 = d_cov6.to(tdt)
-        return d_means, d_cov6, d_opac, d_colors, d_extra, d_m2d
+        out = d_means, d_cov6, d_opac, d_colors, d_extra, d_m2d
+        return out + (d_views,) if want_views else out
 
     # ---- camera set-up: the reference wrapper's arithmetic as restated in oracle/cameras.py (numpy fp32)
     default_device = torch.device("cpu")

@@ -332,6 +332,102 @@ def test_deterministic_backward_is_bit_identical_and_within_tolerance():
     parity_checks.check_grads(a, cfg)
 
 
+def _check_camera_grads(res, tol=parity_checks.TOL):
+    h, o = res["hip"]["grads"]["views"], res["oracle"]["grads"]["views"]
+    assert h.shape == o.shape and h.shape[1] == 48 and np.isfinite(h).all()
+    worst = 0.0
+    for v in range(h.shape[0]):
+        for name, lo, hi in (("viewmatrix", 0, 16), ("projmatrix", 16, 32), ("campos", 32, 35)):
+            scale = float(np.linalg.norm(o[v, lo:hi]))
+            if scale == 0.0:
+                assert not h[v, lo:hi].any(), (v, name)
+                continue
+            err = float(np.linalg.norm(h[v, lo:hi].astype(np.float64) - o[v, lo:hi])) / scale
+            worst = max(worst, err)
+            assert err < tol, (v, name, err, h[v, lo:hi], o[v, lo:hi])
+        assert not h[v, 35:].any()  # tan-fov, background, scale, near / far: no gradient
+        assert not h[v, [3, 7, 11, 15]].any() and not h[v, [18, 22, 26, 30]].any()  # entries the forward never reads
+    return worst
+
+
+@pytest.mark.parametrize("case", ["sh_depth_3views", "rgb_2sets", "disparity", "scale_rot"])
+def test_camera_gradients_match_the_oracle(case):
+    """SURVEY 8f-3 (gsr_backward_ex with dL_dviews): gradient of viewmatrix / projmatrix / campos of every view against the
+    oracle's (itself pinned by fp64 finite differences, tests/test_oracle_pose_grad.py); the Gaussians' gradients of the same
+    call are checked as usual."""
+    rng = np.random.default_rng(5)
+    if case == "sh_depth_3views":
+        sc = synthetic.make_scene(31, 6000, (64, 80), num_views=3, near=2.5)
+        cfg = RasterConfig(3, 1, 3, 6000, 64, 80, 4, 25, 4, True, 1 << 4)
+        args = gpu_util.scene_tensors(sc)
+        vb = gpu_util.scene_viewbuf(sc)
+    elif case == "disparity":
+        sc = synthetic.make_scene(32, 3000, (48, 48), num_views=2, near=1.3)
+        cfg = RasterConfig(2, 1, 2, 3000, 48, 48, 4, 25, 4, True, 2 << 4)
+        args = gpu_util.scene_tensors(sc)
+        vb = gpu_util.scene_viewbuf(sc)
+    elif case == "rgb_2sets":
+        sa, sb = synthetic.make_scene(33, 2000, (48, 48), num_views=2), synthetic.make_scene(34, 2000, (48, 48), num_views=2)
+        args = tuple(torch.cat([a, b]) for a, b in zip(gpu_util.scene_tensors(sa, False), gpu_util.scene_tensors(sb, False)))
+        vb = torch.cat([gpu_util.scene_viewbuf(sa), gpu_util.scene_viewbuf(sb)])
+        cfg = RasterConfig(4, 2, 2, 2000, 48, 48, 0, 0, 4, False)
+    else:
+        sc = synthetic.make_scene(35, 4096, (64, 64), num_views=2, near=1.5)
+        means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+        g = torch.Generator().manual_seed(3)
+        records = torch.cat((torch.rand((1, 4096, 3), generator=g) * 0.15 + 0.01, torch.randn((1, 4096, 4), generator=g)), -1)
+        args = (means, records, opac, colors)
+        vb = gpu_util.scene_viewbuf(sc)
+        cfg = RasterConfig(2, 1, 2, 4096, 64, 64, 4, 25, 4, False, 0, True)
+    v, h, w = cfg.num_views, cfg.height, cfg.width
+    gc = torch.tensor(rng.uniform(0, 1, (v, 3, h, w)).astype(np.float32))
+    ge = torch.tensor(rng.uniform(0, 1, (v, h, w)).astype(np.float32)) if cfg.has_extra else None
+    res = gpu_util.run_both(cfg, vb, *args, None, gc, ge, want_views=True)
+    worst = _check_camera_grads(res)
+    parity_checks.check_grads(res, cfg)
+    assert worst < parity_checks.TOL
+
+
+def test_camera_gradients_do_not_disturb_the_other_gradients_and_are_deterministic():
+    from pf3plat_amd import _lib
+
+    sc = synthetic.make_scene(36, 8000, (64, 64), num_views=2)
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    cfg = RasterConfig(2, 1, 2, 8000, 64, 64, 4, 25, 4, True, _lib.FLAG_DETERMINISTIC | (1 << 4))
+    gc = torch.rand((2, 3, 64, 64), generator=torch.Generator().manual_seed(0))
+    ge = torch.rand((2, 64, 64), generator=torch.Generator().manual_seed(1))
+    a = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, ge, want_views=True)
+    b = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, ge, want_views=True)
+    c = gpu_util.run_hip(cfg, vb, means, cov6, opac, colors, None, gc, ge)
+    np.testing.assert_array_equal(a["hip"]["grads"]["views"], b["hip"]["grads"]["views"])
+    for k in ("means", "cov6", "opac", "colors", "means2d"):
+        np.testing.assert_array_equal(a["hip"]["grads"][k], c["grads"][k], err_msg=k)
+    _check_camera_grads(a)
+
+
+def test_pose_gradients_through_the_decoder_on_the_device():
+    """Torch-facing path: DecoderSplattingCUDA.forward(pose_gradients=True) -> extrinsics.grad; a rigid shift of the world is
+    a shift of the cameras the other way, so the camera-centre gradients sum to minus the summed gradient of the means."""
+    import pf3plat_amd
+    from pf3plat_amd.types import Gaussians
+
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(37, 20000, (96, 96), num_views=3, near=1.5)
+    g = sc.gaussians
+    dec = pf3plat_amd.DecoderSplattingCUDA(dataset_cfg=pf3plat_amd.decoder.DatasetCfgLike((0.2, 0.1, 0.0)))
+    ext = sc.extrinsics.to(dev).requires_grad_(True)
+    means = g.means.to(dev).requires_grad_(True)
+    w = torch.rand((1, 3, 3, 96, 96), generator=torch.Generator().manual_seed(1)).to(dev)
+    wd = torch.rand((1, 3, 96, 96), generator=torch.Generator().manual_seed(2)).to(dev)
+    out = dec.forward(Gaussians(means, g.covariances.to(dev), g.harmonics.to(dev), g.opacities.to(dev)), ext,
+                      sc.intrinsics.to(dev), sc.near.to(dev), sc.far.to(dev), (96, 96), depth_mode="depth", pose_gradients=True)
+    ((out.color * w).sum() + (out.depth * wd).sum()).backward()
+    assert ext.grad is not None and torch.isfinite(ext.grad).all() and ext.grad[..., :3, :].abs().min() > 0
+    d_centres, d_means = ext.grad[0, :, :3, 3].sum(0).cpu(), means.grad[0].sum(0).cpu()
+    assert np.allclose(d_centres.numpy(), -d_means.numpy(), rtol=2e-3, atol=2e-3 * float(d_means.abs().max()))
+
+
 def test_debug_mode_synchronises_per_stage_and_changes_nothing():
     from pf3plat_amd import _lib
 
