@@ -493,6 +493,34 @@ def main():
                 pf3plat_amd.get_backend().check_pending(wait=True)
                 result["decoder_config4"] = {"workload": "DecoderSplattingCUDA.forward, B=1, G=131072, K=25, V=3, colour+depth (sync_policy lazy)",
                                              "ms_per_call": 1e3 * t4, "views_per_s": 3 / t4}
+                # the training step of configs[2] with camera gradients requested (gsr_backward_ex)
+                d_views = torch.empty((1, 48), dtype=torch.float32, device=dev)
+
+                def fb_pose():
+                    be.run_forward(plan_b, viewbuf, means, cov6, opac, shs)
+                    be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color, d_views=d_views)
+
+                for _ in range(5):
+                    fb_pose()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n_fb):
+                    fb_pose()
+                torch.cuda.synchronize()
+                result["fwd_bwd_pose_gradients_ms"] = 1e3 * (time.perf_counter() - t0) / n_fb
+                # MSE + SSIM + gradient image of 3 views of 256x256 in one launch
+                from pf3plat_amd import losses
+
+                pred = torch.rand((3, 3, H, W), device=dev).requires_grad_(True)
+                tgt3 = torch.rand((3, 3, H, W), device=dev)
+                for _ in range(5):
+                    losses.photometric_loss(pred, tgt3, 1.0, 0.2)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(100):
+                    losses.photometric_loss(pred, tgt3, 1.0, 0.2)
+                torch.cuda.synchronize()
+                result["image_loss_3x256x256_ms"] = 1e3 * (time.perf_counter() - t0) / 100
             except Exception as e:  # extras must never take the headline line down
                 result["extras_error"] = f"{type(e).__name__}: {e}"
         print(json.dumps(result))
