@@ -205,8 +205,8 @@ int gsr_backward_ex(const GsrDims* dims, const GsrView* views, const float* mean
                     float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, const GsrBackwardOptions* opt,
                     void* stream);
 
-/* GSR_FLAG_DEBUG: the stage of the last failed call of this host thread (forward: 0 preprocess/binning, 1 count + scans,
- * 2 emit, 3 sort + colour, 4 blend; backward: 0 blend backward, 1 preprocess backward), or -1. */
+/* GSR_FLAG_DEBUG: the stage of the last failed call of this host thread (forward: 0 colour, 1 preprocess/binning,
+ * 2 count + scans, 3 emit, 4 per-tile sort + blend; backward: 0 blend backward, 1 preprocess backward), or -1. */
 int gsr_last_failed_stage(void);
 
 /* Bytes of the `scratch` buffer gsr_backward needs for these dims (V * N * 12 floats; twice that with
@@ -258,13 +258,11 @@ int gsr_image_loss(int num_images, int height, int width, const float* predictio
 
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
- * Forward stages: 0 preprocess (geometry, hit masks and - images of up to 8192 tiles - the whole binning) 1 the colour pass
- * launched ALONE (an extra launch, measurement only: on the product path its workgroups ride in the sort launch) 2 count +
- * tile scans and 3 emit (windowed binning path only: empty, i.e. one event gap each, otherwise) 4 the sort launch as the
- * product issues it (per-tile gather + sort, with the colour workgroups riding along) 5 blend.  The product chain is
- * 0 + 2 + 3 + 4 + 5.
+ * Forward stages, in launch order: 0 the colour pass 1 preprocess (geometry, hit masks and - images of up to 8192 tiles - the
+ * whole binning) 2 count + tile scans and 3 emit (windowed binning path only: empty, i.e. one event gap each, otherwise)
+ * 4 the tile launch (per tile: gather + sort of its list, then its blend).
  * Backward stages: 0 blend backward 1 preprocess backward. */
-#define GSR_FWD_STAGES 6
+#define GSR_FWD_STAGES 5
 #define GSR_BWD_STAGES 2
 int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* means, const float* cov6,
                         const float* opacities, const float* colors, const float* extra, float* out_color,

@@ -153,6 +153,6 @@ EXPORTED_SYMBOLS = (
 )
 # gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).
-FWD_STAGES = ("preprocess", "color", "count_scan", "emit", "sort", "blend")
-FWD_DEBUG_STAGES = ("preprocess/binning", "count + scans", "emit", "sort + colour", "blend")
+FWD_STAGES = ("color", "preprocess", "count_scan", "emit", "tiles")
+FWD_DEBUG_STAGES = ("colour", "preprocess/binning", "count + scans", "emit", "per-tile sort + blend")
 BWD_STAGES = ("blend_bwd", "preprocess_bwd")

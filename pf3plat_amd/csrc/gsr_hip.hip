@@ -60,7 +60,7 @@ struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one
   float4 q3;  // bits: hit mask lo, hit mask hi, window origin (sx0 | sy0 << 12 | big << 31), depth
 };
 // The view-dependent colour lives in its own array (float4 per (view, Gaussian): r, g, b, bits(clamp mask)) because it is
-// produced by the colour workgroups that ride in the sort launch (color_unit), not by the geometry/binning kernel.
+// produced by the colour pass (k_color / color_unit), not by the geometry/binning kernel.
 // q3: the 8x8 tiles this splat must be listed in, as a 64-bit mask over the 8x8-tile window whose top-left tile is
 // (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); computed once in preprocess, consumed by count and emit.
 // Footprints wider than 8 tiles set `big` and are re-derived from q0/q1 by the binning kernels.
@@ -168,7 +168,7 @@ struct Params {
   uint32_t* tail_counter;
   unsigned long long* page_counter;  // in the status block: (call tag << 32) | pages of the key pool handed out so far
   uint32_t call_tag;       // unique per gsr_forward call of this process: a counter left by another call reads as zero
-  uint32_t sort_blocks;    // k_sort_tiles: workgroups [0, sort_blocks) sort a tile each, the rest evaluate one 64-Gaussian colour unit
+  uint32_t sort_blocks;    // workgroups of the tile launch = views x tiles
   uint32_t color_units;    // colour units per set = ceil(N / 64)
   uint32_t* tile_total;
   uint2* ranges;
@@ -599,7 +599,7 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
 // but the means:
 //   geometry (k_preprocess / k_preprocess_bin, feeds the binning chain): projection, EWA covariance, conic, radius,
 //       reference rect and the 64-bit 8x8-tile hit mask - 40 B in, 64 B out per (view, Gaussian), VALU-bound;
-//   colour (color_unit, further down: workgroups riding in the sort launch): SH -> RGB (+0.5, clamp mask) for every view
+//   colour (k_color / color_unit, further down: the first launch of the chain): SH -> RGB (+0.5, clamp mask) for every view
 //       of a set - 300 of the 352 input bytes per Gaussian, HBM-bound.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPreThreads = 256;
@@ -757,12 +757,11 @@ __device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
 // Colour role: SH -> RGB (+0.5, clamp mask) of one 64-Gaussian unit for every view of its set, by a group of kColorThreads
 // threads.  All of them request the unit's 64 x 3M SH floats (19 200 B at M = 25) as 16-byte coalesced loads, park them in
 // LDS (row stride 3M floats, odd => conflict-free) and wave w evaluates views w, w + 4, ... with lane = Gaussian (the SH of a
-// set is read ONCE however many views it has).  The colour pass is HBM-bound (300 of the 352 input bytes per Gaussian) and
-// has no launch of its own: its workgroups ride in the sort launch (k_sort_tiles: blockIdx >= sort_blocks), BEHIND the
-// per-tile sorts - they take the CU slots the sorts free as they finish.  One stream, no second queue, no events.
-// (Measured alternatives, all slower: colour beside the sorts at 6 or 8 workgroups per CU - the sorts' scattered gathers
-// queue behind the colour stream; colour workgroups beside the binning workgroups - with 19 KB of LDS per unit in flight
-// a CU holds too few units to cover their latency once their waves share SIMDs with VALU-bound ones; a second stream.)
+// set is read ONCE however many views it has).  The colour pass is HBM-bound (300 of the 352 input bytes per Gaussian): a
+// launch of its own (k_color), eight workgroups per CU, ~4.6 TB/s.  (Measured alternatives, all slower: colour workgroups
+// beside or behind the per-tile sorts in one launch - the sorts' scattered gathers and the stream only lose to each other,
+// whatever the order; beside the binning workgroups - with 19 KB of LDS per unit in flight a CU holds too few units to
+// cover their latency once their waves share SIMDs with VALU-bound ones; a second stream - 6 us per event.)
 constexpr int kColorThreads = 256;
 constexpr int kShPre = 5;  // float4 registers per thread that hold the unit's SH rows (64 * 75 / 4 / 256 = 4.7)
 constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 75: odd)
@@ -858,6 +857,15 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
+// The colour pass as the FIRST launch of the forward chain (independent of the binning).  Its first workgroup also puts the
+// page counter of the key pool to zero for this call: no taker of pages (binning, sorts) runs beside this kernel, and a
+// replay of the very same call (HIP graph: same tag) must not see the pages of the previous replay as taken.
+__global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
+  __shared__ __attribute__((aligned(16))) float lds[kColorLdsFloats];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;
+  color_unit(p, blockIdx.x, true, lds, (int)threadIdx.x);
+}
+
 // K1 (images of up to kTileWindow tiles): preprocess AND the whole binning of this workgroup's `chunk` Gaussians.
 //   1. preprocess the Gaussians; histogram their (tile, splat) pairs per tile in LDS; records leave through the transpose;
 //   2. exclusive scan of the histogram over the tiles = where each tile's pairs start INSIDE this workgroup's own region
@@ -868,7 +876,7 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
 //      collected in LDS (the 64 KB transpose area, free by now) so that the region is written by one linear copy - keys
 //      stored pair by pair are 64 separate 8-byte requests per instruction and were the longest phase of the old emit.
 // Nothing here depends on another workgroup: no count matrix prefix, no tile scan, no second pass over the records.
-// k_sort_tiles<true> later collects a tile's list from the <= rows regions (column (v, :, t) of the pair matrix).
+// sort_tile<true> (k_tile_fwd) later collects a tile's list from the <= rows regions (column (v, :, t) of the pair matrix).
 // (Same-address device atomics cost ~17 ns each on this chip, one after the other:
 // a counter hit by every workgroup of a launch is a serial section, hence the fixed slots here and in the sort.)
 __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) {
@@ -885,7 +893,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   for (int k = tid; k < T; k += kBinThreads) hist[k] = 0;
   if (tid == 0) {
     nbig = 0;
-    if (row == 0 && v == 0) {  // only k_sort_tiles touches these, and it runs after this kernel
+    if (row == 0 && v == 0) {  // only the tile launch touches these, and it runs after this kernel
       p.status->overflow = 0; p.status->max_list = 0; *p.tail_counter = 0u;
     }
   }
@@ -976,7 +984,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   __syncthreads();
   GSR_STAMP(2);
   const uint32_t base = sBase;
-  if (base == 0xffffffffu || total == 0) return;  // key buffer too small (k_sort_tiles reports it) / nothing to list
+  if (base == 0xffffffffu || total == 0) return;  // key buffer too small (the tile launch reports it) / nothing to list
   // ---- 4. the pairs, again, now to their slots
   const bool staged = total <= (uint32_t)kStagePairs;
   unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(dyn_stage);
@@ -1023,7 +1031,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
 //   k_tile_scan   : exclusive scan over all (v, tile) totals -> list ranges, pair total, overflow flag (or inside k_emit)
 //   k_emit        : LDS cursors start at range.x + row prefix; each pair takes its slot with one LDS atomic
 // Count and emit walk the same footprints with the same code, so slots match counts exactly.  Images of up to kTileWindow
-// tiles take k_preprocess_bin + k_sort_tiles<gather> instead (above / below).
+// tiles take k_preprocess_bin + the gathering sort of k_tile_fwd instead (above / below).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
   __shared__ uint32_t hist[kTileWindow];
@@ -1348,7 +1356,7 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 }
 
 // Per-tile depth sort, kSortThreads threads per tile; writes the sorted Gaussian indices (the reference's point_list).
-// Lists of up to kLds keys: LDS bucket sort - keys stay in registers, one LDS-atomic histogram over kLds / 4 buckets of the
+// Lists of up to kLds keys: LDS bucket sort - keys stay in registers, one LDS-atomic histogram over the buckets of the
 // tile's own depth range (float bits are monotonic for positive depths), exclusive scan, LDS-atomic scatter into bucket
 // order, then every key ranks itself among the few keys of its own bucket with the full 64-bit (depth, index) compare and
 // goes to its final place.  ~40 B of LDS traffic per key instead of ~800 B for an in-LDS bitonic network.  Degenerate depth
@@ -1361,31 +1369,24 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* w
 //   fixed slot of the index list (`stride` = pair_capacity / (2 x views x tiles) entries; a longer list takes a run of the
 //   shared second half from a bump counter: correct for any distribution as long as pair_capacity >= 2 x pairs, and free of
 //   shared counters when pair_capacity >= 2 x views x tiles x longest list).
-#ifndef GSR_SORT_OCC
-#define GSR_SORT_OCC 4
-#endif
+// LDS of a per-tile sort: kLds keys (8 B) then the bucket counters (4 B), in 8-byte words
+template <int kLds>
+struct SortLds {
+  // depth buckets: one per key slot in the 2048-key variant (a dense depth cluster otherwise makes buckets of 20-30 entries and
+  // ranking inside a bucket is quadratic: forward -1.1 us), a quarter of that in the 4096-key variant (LDS: four workgroups / CU)
+  static constexpr int kBuckets = kLds == 2048 ? 2048 : 1024, kBucketBits = kLds == 2048 ? 11 : 10;
+  static constexpr int kWords = kLds + kBuckets / 2;
+};
+
+// The sort of one tile's list: returns the tile's range of the index list (empty when the tile has no entry or the list did
+// not fit: then status->overflow is set).  All `return`s are workgroup-uniform.  The caller provides `smem`
+// (SortLds<kLds>::kWords 8-byte words, 16-byte aligned), red[8] and sInfo[4] in LDS.
 template <bool kGather, int kLds>
-__global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GSR_SORT_OCC, GSR_SORT_OCC))) void k_sort_tiles(const Params p) {
-  // kLds keys sort in LDS, over kLds / 4 depth buckets.  The 2048-key variant needs no more LDS than a colour unit
-  // (18.4 KB vs 19.2 KB), so eight workgroups of either role share a CU.
-  constexpr int kBk = kLds / 4, kBkBits = kLds == 4096 ? 10 : 9, kBpt = kBk / kSortThreads;
+__device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, unsigned long long* smem, uint32_t* red,
+                                           uint32_t* sInfo) {
+  // kLds keys sort in LDS over SortLds<kLds>::kBuckets depth buckets
+  constexpr int kBk = SortLds<kLds>::kBuckets, kBkBits = SortLds<kLds>::kBucketBits, kBpt = kBk / kSortThreads;
   static_assert(kLds == 4096 || kLds == 2048, "bucket geometry");
-  static_assert(kColorThreads == kSortThreads, "the colour role shares the sort kernel's workgroup shape");
-  // one block: keys (kLds x 8 B), then the bucket counters (kBk x 4 B) - or, in a colour workgroup, the unit's SH rows
-  constexpr int kSortWords = kLds + kBk / 2, kColorWords = kColorLdsFloats / 2;
-  __shared__ __attribute__((aligned(16))) unsigned long long smem[kSortWords > kColorWords ? kSortWords : kColorWords];
-  __shared__ uint32_t red[8];
-  __shared__ uint32_t sInfo[4];
-  uint32_t bid = blockIdx.x;
-  {
-    const uint32_t S = p.sort_blocks;
-    const bool colour = bid >= S;
-    if (colour) bid -= S;
-    if (colour) {  // workgroup-uniform: the colour pass rides in this launch (see color_unit)
-      color_unit(p, bid, true, reinterpret_cast<float*>(smem), (int)threadIdx.x);
-      return;
-    }
-  }
   unsigned long long* sk = smem;
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kLds);  // counts, then (same storage) scatter cursors
   uint32_t* cur = hist;
@@ -1397,6 +1398,7 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
 #define GSR_STAMP2(k) do { if (dbg && tid == 0) stamp2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
   GSR_STAMP(0);
   int n;
+  uint32_t obase = 0;  // where the tile's list starts in the index list
   unsigned long long* keys;  // global memory: contiguous keys (kGather: only for lists longer than the LDS sort)
   uint32_t* out;
   if (kGather) {
@@ -1414,7 +1416,10 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
 #define GSR_DEPHASE_GROUPS 4
 #define GSR_DEPHASE_SLEEP 64
 #endif
-      for (int q = 0; q < (int)((bid >> 3) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_DEPHASE_SLEEP);
+#ifndef GSR_DEPHASE_SHIFT
+#define GSR_DEPHASE_SHIFT 3
+#endif
+      for (int q = 0; q < (int)((bid >> GSR_DEPHASE_SHIFT) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_DEPHASE_SLEEP);
     }
     const uint2* col = p.pair_mat + (size_t)v * R * (T + 8) + t;
     const size_t cstride = (size_t)T + 8;
@@ -1476,10 +1481,11 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
     uint32_t rbase = (uint32_t)tg * p.stride, scratch = 0;
     if (!plain) {  // workgroup-uniform
       __syncthreads();
-      if (!sInfo[1]) return;
+      if (!sInfo[1]) return make_uint2(0u, 0u);
       rbase = sInfo[0]; scratch = sInfo[2];
     }
-    if (n == 0) return;
+    obase = rbase;
+    if (n == 0) return make_uint2(obase, obase);
     GSR_STAMP2(1);
     out = p.point_list + rbase;
     keys = p.keys + scratch;
@@ -1520,17 +1526,18 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
     }
     if (n == 1) {
       if (tid == 0) out[0] = (uint32_t)dst[0];
-      return;
+      return make_uint2(obase, obase + 1u);
     }
   } else {
     const uint2 rg = p.ranges[bid];
     n = (int)(rg.y - rg.x);
-    if (n == 0) return;
+    obase = rg.x;
+    if (n == 0) return rg;
     keys = p.keys + rg.x;
     out = p.point_list + rg.x;
     if (n == 1) {
       if (tid == 0) out[0] = (uint32_t)keys[0];
-      return;
+      return rg;
     }
   }
   int lgnp = 1;
@@ -1539,7 +1546,7 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
     __syncthreads();
     bitonic_block(keys, n, lgnp, tid);
     for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)keys[k];
-    return;
+    return make_uint2(obase, obase + (uint32_t)n);
   }
   constexpr int Q = kLds / kSortThreads;
   unsigned long long kreg[Q];
@@ -1598,21 +1605,29 @@ __global__ __launch_bounds__(kSortThreads) __attribute__((amdgpu_waves_per_eu(GS
       const uint32_t b = ((uint32_t)(key >> 32) - lo) >> shift;
       const int bs = b ? (int)cur[b - 1] : 0, be = (int)cur[b];
       int rank = bs;
-      for (int j = bs; j < be; ++j) rank += sk[j] < key ? 1 : 0;
+      // four members per step, requested together (a dense depth cluster makes buckets of 20-30 entries: the chain of
+      // dependent LDS reads is what this loop costs)
+      for (int j = bs; j < be; j += 4) {
+        const unsigned long long k0 = sk[j], k1 = sk[min(j + 1, be - 1)], k2 = sk[min(j + 2, be - 1)], k3 = sk[min(j + 3, be - 1)];
+        rank += (k0 < key ? 1 : 0) + ((j + 1 < be && k1 < key) ? 1 : 0) + ((j + 2 < be && k2 < key) ? 1 : 0) +
+                ((j + 3 < be && k3 < key) ? 1 : 0);
+      }
       out[rank] = (uint32_t)key;
     }
     GSR_STAMP(5);
     GSR_STAMP(6);
-    return;
+    return make_uint2(obase, obase + (uint32_t)n);
   }
   bitonic_block(sk, n, lgnp, tid);
   __syncthreads();
   GSR_STAMP(5);
   for (int k = tid; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
   GSR_STAMP(6);
+  return make_uint2(obase, obase + (uint32_t)n);
 #undef GSR_STAMP
 #undef GSR_STAMP2
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Blend helpers shared by the forward and backward blend kernels (both must take the same skip decisions).
@@ -1669,32 +1684,36 @@ __device__ __forceinline__ void stage_batch(const GeomRec* geom, const float4* r
   // lane = splat; null record (opacity 0) past the end of the list
   g = make_float4(0, 0, 0, 0); g2 = make_float2(0, 0); c = make_float4(0, 0, 0, 0);
   if (base + lane < n) {
+    // loads only - no arithmetic on the values here, so that nothing waits for them before they are parked (put_records
+    // moves the conic to the exp2 domain)
     const GeomRec* r = geom + id;
-    float4 q0 = r->q0, q1 = r->q1;
+    const float4 q0 = r->q0, q1 = r->q1;
     const float4 col = rgbc[id];
     const float ex = want_extra ? r->q2.y : 0.f;
-    to_exp2_domain(q0, q1);
     g = q0; g2 = make_float2(q1.x, q1.y); c = make_float4(col.x, col.y, col.z, ex);
   }
 }
 
-template <bool kExtra>
-__global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
+struct BlendLds {
   // records of a batch, laid out for PAIRS of consecutive entries (e, e+1) so that one ds_read_b128 yields the two
   // operands of two packed-fp32 instructions: [x x' y y'], [a2 a2' b2 b2'], [c2 c2' o o'], [r r' g g'], [b b' ex ex']
-  __shared__ float4 sXY[4][kFB / 2], sAB[4][kFB / 2], sCO[4][kFB / 2], sRG[4][kFB / 2], sBE[4][kFB / 2];
-  __shared__ float sP[2][kFwdWaves][64];  // segment products of batch b in sP[b & 1]
-  __shared__ float sPart[kFwdWaves][5][64];
-  __shared__ uint32_t sLast[kFwdWaves][64];
+  float4 sXY[4][kFB / 2], sAB[4][kFB / 2], sCO[4][kFB / 2], sRG[4][kFB / 2], sBE[4][kFB / 2];
+  float sP[2][kFwdWaves][64];  // segment products of batch b in sP[b & 1]
+  float sPart[kFwdWaves][5][64];
+  uint32_t sLast[kFwdWaves][64];
+};
+
+// The blend of tile t of view v over the index-list range rg (256 threads; `lds` may alias anything the workgroup is done with)
+template <bool kExtra>
+__device__ __forceinline__ void blend_tile(const Params& p, const int v, const int t, const uint2 rg, BlendLds& lds) {
+  auto& sXY = lds.sXY; auto& sAB = lds.sAB; auto& sCO = lds.sCO; auto& sRG = lds.sRG; auto& sBE = lds.sBE;
+  auto& sP = lds.sP; auto& sPart = lds.sPart; auto& sLast = lds.sLast;
   const Grid& g = p.g;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int v = blockIdx.y;
-  const int t = xcd_remap(blockIdx.x, g.T);
   const int tx = t % g.sgx, ty = t / g.sgx;
   const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
   const bool inside = pxi < g.W && pyi < g.H;
   const float pxf = (float)pxi, pyf = (float)pyi;
-  const uint2 rg = p.ranges[(size_t)v * g.T + t];
   const uint32_t n = rg.y - rg.x;
   const uint32_t nbat = (n + kFB - 1) / kFB;
   const uint32_t* plist = p.point_list + rg.x;
@@ -1762,7 +1781,8 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
       last += (uint32_t)alive0 + (uint32_t)alive1;  // entries this pixel's loop went through (a prefix of the list)
     }
   };
-  auto put_records = [&](int sb, const float4& q, const float2& q2, const float4& c) {  // lane = entry of the batch
+  auto put_records = [&](int sb, float4 q, float2 q2, const float4& c) {  // lane = entry of the batch
+    q.z = (-0.5f * kLog2e) * q.z; q.w = (-kLog2e) * q.w; q2.x = (-0.5f * kLog2e) * q2.x;  // to_exp2_domain
     const int o = (lane >> 1) * 4 + (lane & 1);
     float* xy = reinterpret_cast<float*>(sXY[sb]); float* ab = reinterpret_cast<float*>(sAB[sb]);
     float* co = reinterpret_cast<float*>(sCO[sb]); float* rg2 = reinterpret_cast<float*>(sRG[sb]);
@@ -1772,37 +1792,48 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
   };
 
   if (nbat > 0) {
-    // ---- prologue: waves 0 / 1 stage batches 0 / 1, wave 2 fetches the list ids of batch 2; everyone evaluates batch 0
+    // ---- gather pipeline: wave w brings in the batches b = w (mod 4).  The records of a batch are requested FOUR iterations
+    // before they are parked in LDS (and its list ids four iterations before that): a tile that is left alone on its SIMDs runs
+    // an iteration in ~0.4 us, less than one trip to HBM - with the loads issued only one iteration ahead the last tiles of
+    // every CU ran at memory latency (1.4 us per batch, measured) exactly when nothing else was there to cover it.
+    // Prologue: waves 0 / 1 stage batches 0 / 1 at once and request 4 / 5; waves 2 / 3 request 2 / 3; everyone evaluates batch 0.
     float4 sg = make_float4(0, 0, 0, 0), sc = sg;
     float2 sg2 = make_float2(0, 0);
     uint32_t id_next = 0;
+    const auto list_id = [&](uint32_t b) { return (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u; };
     if (lane < kFB) {
-      if (wave == 0 || (wave == 1 && nbat > 1)) {
-        const uint32_t b = (uint32_t)wave;
-        const uint32_t id = (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u;
-        stage_batch(geom, rgbc, n, b * kFB, lane, id, kExtra, sg, sg2, sc);
-        put_records((int)b, sg, sg2, sc);
-      } else if (wave == 2) {
-        id_next = (2u * kFB + lane < n) ? plist[2 * kFB + lane] : 0u;
+      const uint32_t w = (uint32_t)wave;
+      if (w < 2) {
+        const uint32_t id0 = list_id(w), id4 = list_id(w + 4);
+        id_next = list_id(w + 8);
+        if (w < nbat) {
+          stage_batch(geom, rgbc, n, w * kFB, lane, id0, kExtra, sg, sg2, sc);
+          put_records((int)w, sg, sg2, sc);
+        }
+        stage_batch(geom, rgbc, n, (w + 4) * kFB, lane, id4, kExtra, sg, sg2, sc);
+      } else {
+        const uint32_t id2 = list_id(w);
+        id_next = list_id(w + 4);
+        stage_batch(geom, rgbc, n, w * kFB, lane, id2, kExtra, sg, sg2, sc);
       }
     }
     __syncthreads();
     eval(0);
     __syncthreads();
     if (dbg) tm1 = __builtin_readcyclecounter();
-    // ---- steady state, iteration i: A(i), E(i+1) | records of batch i+2 gathered, list ids of batch i+3 fetched
+    // ---- steady state, iteration i: A(i), E(i+1) | batch i+2 parked in LDS, batch i+6 requested, ids of batch i+10 requested
     for (uint32_t i = 0; i < nbat; ++i) {
       const float P0 = sP[i & 1][0][lane], P1 = sP[i & 1][1][lane], P2 = sP[i & 1][2][lane], P3 = sP[i & 1][3][lane];
       const uint32_t bs = i + 2;
-      const bool do_stage = (wave == (int)(bs & 3)) && (bs < nbat) && (lane < kFB);
-      if (do_stage) stage_batch(geom, rgbc, n, bs * kFB, lane, id_next, kExtra, sg, sg2, sc);  // global gather in flight
-      if (wave == (int)((i + 3) & 3) && lane < kFB) id_next = ((i + 3) * kFB + lane < n) ? plist[(i + 3) * kFB + lane] : 0u;
+      const bool duty = (wave == (int)(bs & 3)) && (lane < kFB);
       const float t1 = Tb * P0, t2 = t1 * P1, t3 = t2 * P2, t4 = t3 * P3;  // the same chain in every wave
       const bool last_batch = __all(t4 < 0.0001f);  // every pixel has stopped by the end of this batch: no need to evaluate the next
       accum(i, wave == 0 ? Tb : wave == 1 ? t1 : wave == 2 ? t2 : t3);
       if (i + 1 < nbat && !last_batch) eval(i + 1);
-      if (do_stage) {
-        put_records((int)(bs & 3), sg, sg2, sc);
+      if (duty) {
+        if (bs < nbat) put_records((int)(bs & 3), sg, sg2, sc);
+        if (bs + 4 < nbat) stage_batch(geom, rgbc, n, (bs + 4) * kFB, lane, id_next, kExtra, sg, sg2, sc);
+        id_next = list_id(bs + 8);
       }
       Tb = t4;
       consumed = (i + 1) * kFB;
@@ -1824,8 +1855,6 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
     o[0] = tm0; o[1] = ((unsigned long long)hw << 32) | (unsigned)(tm1 - tm0); o[2] = __builtin_readcyclecounter();
     o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
   }
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)  // every taker of key-pool pages (binning, sort) has finished: leave the
-    *p.page_counter = (unsigned long long)p.call_tag << 32;     // counter at zero for a replay of this very call (HIP graph: same tag)
   if (wave == 0) {
     if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
     if (inside) {
@@ -1850,6 +1879,23 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_blend_fwd(const Params p) {
       if (kExtra) p.out_extra[(size_t)v * HW + pix] = E;
     }
   }
+}
+
+// One launch per tile for both: the tile's sort (its gather latency under the blend arithmetic of the other tiles of the CU),
+// then - the index list written and a barrier later - its blend, over the same LDS.
+template <bool kGather, int kLds, bool kExtra>
+__global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
+  static_assert(kSortThreads == kFwdThreads, "one workgroup shape for the two phases");
+  constexpr int kSortWords = SortLds<kLds>::kWords, kBlendWords = (int)((sizeof(BlendLds) + 7) / 8);
+  __shared__ __attribute__((aligned(16))) unsigned long long smem[kSortWords > kBlendWords ? kSortWords : kBlendWords];
+  __shared__ uint32_t red[8];
+  __shared__ uint32_t sInfo[4];
+  const uint32_t bid = blockIdx.x;
+  const uint2 rg = sort_tile<kGather, kLds>(p, bid, smem, red, sInfo);
+  __syncthreads();  // the list is this workgroup's own: its stores are visible to its waves from here on; the keys are dead
+  const int tg = kGather ? xcd_remap((int)bid, (int)p.sort_blocks) : (int)bid;
+  const int v = tg / p.g.T;
+  blend_tile<kExtra>(p, v, tg - v * p.g.T, rg, *reinterpret_cast<BlendLds*>(smem));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2837,18 +2883,15 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const bool do_color = !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH);
   p.color_units = (uint32_t)((N + 63) / 64);
   const unsigned color_blocks = do_color ? p.color_units * (unsigned)d.num_sets : 0u;
-  // One stream, three launches: binning -> per-tile sorts + the colour pass riding in the same grid -> blend.  Profile mode
-  // (ev != null) times exactly that chain, and - first, as an extra - a launch of the colour workgroups alone, so that the
-  // colour pass also has a time of its own (gsr_forward_profile moves it to stage 1; it is not part of the chain).
+  // One stream, three launches, each waiting for the one before: the colour pass (independent of the binning; an HBM stream
+  // at full occupancy), the binning, then one launch per tile for its sort AND its blend.  (Until round 2 the colour
+  // workgroups rode behind the sorts in a separate sort launch: same time, the sorts and the stream do not overlap.)
   GSR_MARK();
-  if (ev && color_blocks) {
-    Params pc = p;
-    pc.sort_blocks = 0;
-    hipLaunchKernelGGL((k_sort_tiles<true, 2048>), dim3(color_blocks), dim3(kSortThreads), 0, st, pc);
-  }
-  if (ev) GSR_MARK();
-  // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin + gathering sort: 2 launches);
-  // larger ones the windowed path (preprocess, count, prefix, scan, emit, sort: 5-6 launches).
+  if (color_blocks) hipLaunchKernelGGL(k_color, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
+  GSR_STAGE_DONE(0);
+  GSR_MARK();
+  // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers: 2 launches);
+  // larger ones the windowed path (preprocess, count, prefix, scan, emit, then the tile launch: 5-6 launches).
   const bool fused_bin = p.g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   if (fused_bin) {
     static std::atomic<unsigned long long> lds_set{0ull};  // per device: > 64 KB of dynamic LDS has to be asked for
@@ -2864,7 +2907,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   } else {
     hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   }
-  GSR_STAGE_DONE(0);
+  GSR_STAGE_DONE(1);
   GSR_MARK();
   if (!fused_bin) {
     hipLaunchKernelGGL(k_count, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
@@ -2872,27 +2915,28 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   }
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
   if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
-  GSR_STAGE_DONE(1);
+  GSR_STAGE_DONE(2);
   GSR_MARK();
   if (!fused_bin) {
     if (scan_in_emit) hipLaunchKernelGGL(k_emit<true>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
     else hipLaunchKernelGGL(k_emit<false>, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads), 0, st, p);
   }
-  GSR_STAGE_DONE(2);
-  GSR_MARK();
-  p.sort_blocks = (uint32_t)VT;
-  const dim3 sgrid((unsigned)VT + color_blocks);
-  if (fused_bin) {
-    // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
-    if (p.stride <= 2048u) hipLaunchKernelGGL((k_sort_tiles<true, 2048>), sgrid, dim3(kSortThreads), 0, st, p);
-    else hipLaunchKernelGGL((k_sort_tiles<true, 4096>), sgrid, dim3(kSortThreads), 0, st, p);
-  } else {
-    hipLaunchKernelGGL((k_sort_tiles<false, 4096>), sgrid, dim3(kSortThreads), 0, st, p);
-  }
   GSR_STAGE_DONE(3);
   GSR_MARK();
-  if (d.has_extra) hipLaunchKernelGGL(k_blend_fwd<true>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
-  else hipLaunchKernelGGL(k_blend_fwd<false>, dim3((unsigned)p.g.T, (unsigned)V), dim3(kFwdThreads), 0, st, p);
+  p.sort_blocks = (uint32_t)VT;
+  {
+    const dim3 tgrid((unsigned)VT);
+#define GSR_TILES(G, L)                                                                                  \
+  do {                                                                                                   \
+    if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd<G, L, true>), tgrid, dim3(kFwdThreads), 0, st, p);   \
+    else hipLaunchKernelGGL((k_tile_fwd<G, L, false>), tgrid, dim3(kFwdThreads), 0, st, p);              \
+  } while (0)
+    // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
+    if (!fused_bin) GSR_TILES(false, 4096);
+    else if (p.stride <= 2048u) GSR_TILES(true, 2048);
+    else GSR_TILES(true, 4096);
+#undef GSR_TILES
+  }
   GSR_STAGE_DONE(4);
   GSR_MARK();
 #undef GSR_STAGE_DONE
@@ -2925,8 +2969,6 @@ int gsr_forward_profile(const GsrDims* dims, const GsrView* views, const float* 
     if (hipStreamSynchronize(st) != hipSuccess) rc = GSR_ERR_LAUNCH;
     for (int i = 0; i < GSR_FWD_STAGES && rc == GSR_OK; ++i)
       if (hipEventElapsedTime(&stage_ms[i], ev[i], ev[i + 1]) != hipSuccess) rc = GSR_ERR_LAUNCH;
-    const float color_ms = stage_ms[0];  // launched first in profile mode (see forward_impl)
-    stage_ms[0] = stage_ms[1]; stage_ms[1] = color_ms;
   } else {
     for (int i = 0; i < GSR_FWD_STAGES; ++i) stage_ms[i] = 0.f;
   }

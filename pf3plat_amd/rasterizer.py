@@ -299,7 +299,7 @@ class HipBackend:
                   afterwards size the workspace at 1.25x the largest pair count seen, copy the status block asynchronously
                   and verify it at the next call, at `check_pending()`, and - for a call that is differentiated - at the
                   start of its backward.  A workspace that turns out too small poisons that call's image with NaN
-                  (k_blend_fwd) and raises at verification - it cannot pass silently."""
+                  (k_tile_fwd) and raises at verification - it cannot pass silently."""
         self._check_device(viewbuf, means, cov6, opac, colors, extra)
         self.check_pending()
         dev = viewbuf.device

@@ -39,7 +39,13 @@ def main():
     st = be.read_status(plan)
     img = plan["color"].double()
     out = f"{label:28s} fwd {best * 1e6:7.2f} us/step  image sum {img.sum().item():.6f} absmax {img.abs().max().item():.6f} finite {bool(torch.isfinite(img).all())} status {st}"
-    if len(sys.argv) > 3:
+    if os.environ.get("EXP_PROFILE"):
+        acc = {}
+        for _ in range(20):
+            for k, v in be.run_forward(plan, vb, means, cov6, opac, shs, profile=True).items():
+                acc[k] = acc.get(k, 0.0) + v / 20
+        out += " | stages us " + " ".join(f"{k}={1e3 * v:.1f}" for k, v in acc.items())
+    if len(sys.argv) > 3 and sys.argv[3]:
         from pf3plat_amd import _lib
         cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False, _lib.FLAG_BACKWARD_FOLLOWS)
         plan = be.make_plan(cfg, dev, capacity=int(plan["dims"].pair_capacity), backward=True)

@@ -13,17 +13,19 @@ def main():
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     rows = list(c.execute("select name, start, end, grid_x, grid_y from kernels order by start"))
     rows = [r for r in rows if r[0].startswith("gsr::") or "gsr::" in r[0]]
-    # passes begin at the preprocess kernel with grid_y == 1 (single-view bench config)
-    passes, cur = [], None
+    # passes begin at the colour kernel; kept: those whose binning kernel has grid_y == 1 (the single-view bench config)
+    passes, cur, single = [], None, {}
     for name, st, en, gx, gy in rows:
         short = name.split("(")[0].replace("gsr::", "").replace("void ", "")
-        if (short.startswith("k_preprocess_bin") or short.startswith("k_preprocess_count")) and gy == 1:
+        if short.startswith("k_color"):
             cur = []
             passes.append(cur)
+        if short.startswith("k_preprocess_bin") and cur is not None:
+            single[id(cur)] = gy == 1
         if cur is not None:
             k = sum(1 for x in cur if x[0].split("#")[0] == short)
             cur.append((short if k == 0 else f"{short}#{k}", st, en))
-    passes = [p for p in passes if 3 <= len(p) <= 8 and any(x[0].startswith(("k_blend_fwd", "k_tile_fwd")) for x in p)]
+    passes = [p for p in passes if single.get(id(p)) and 3 <= len(p) <= 8 and any(x[0].startswith("k_tile_fwd") for x in p)]
     passes = passes[len(passes) // 2: len(passes) // 2 + npass]
     acc = defaultdict(lambda: [0.0, 0.0, 0])
     period = []
