@@ -190,7 +190,7 @@ int gsr_backward_scale_rot(const GsrDims* dims, const GsrView* views, const floa
  * inputs, the way the operator takes them; tan-fov, background and scale get none.  Every place the forward reads a camera
  * is differentiated (EWA covariance through t = V p and J Wr, projection to pixel coordinates, view direction of the
  * harmonics, depth of the built-in extra channel); depth ordering and culling are not, as for the Gaussians.  pose_partials:
- * gsr_pose_partials_bytes(dims) bytes of scratch (one row per view and 64-Gaussian unit; reduced in a fixed order). */
+ * gsr_pose_partials_bytes(dims) bytes of scratch (four rows per view and 64-Gaussian unit; reduced in a fixed order). */
 typedef struct GsrBackwardOptions {
   const float* frames;
   int32_t num_frames;

@@ -180,7 +180,7 @@ struct Params {
   const float *dL_dcolor, *dL_dextra_img;
   float* scratch;
   float *dL_dmeans, *dL_dcov6, *dL_dopac, *dL_dcolors, *dL_dextra, *dL_dmeans2D;  // (scale_rot: dL_dcov6 is (S, N, 7))
-  float* pose_partials;  // camera gradients requested: [view][preprocess_bwd workgroup][kPoseFloats]
+  float* pose_partials;  // camera gradients requested: [view][preprocess_bwd workgroup][DPP row 0..3][kPoseFloats]
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2413,12 +2413,12 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
     }  // vis
-    if (kPose) {
-      float* row = p.pose_partials + ((size_t)v * gridDim.x + blockIdx.x) * kPoseFloats;
+    if (kPose) {  // sums over the four 16-lane DPP rows (4 DPP adds per value; a full wave sum costs 6 LDS permutes): 4 partial rows
+      float* row = p.pose_partials + (((size_t)v * gridDim.x + blockIdx.x) * 4 + (lane >> 4)) * kPoseFloats;
 #pragma unroll
       for (int k = 0; k < kPoseFloats; ++k) {
-        const float s = wave_sum(pose[k]);
-        if (lane == 0) row[k] = s;
+        const float s = row_allreduce(pose[k]);
+        if ((lane & 15) == 0) row[k] = s;
       }
     }
   }
@@ -2491,25 +2491,29 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   }
 }
 
-// Sum of the per-workgroup camera-gradient rows of one view -> dL/dview record (48 floats: viewmatrix, projmatrix, campos, 0...).
-// Fixed order: deterministic.
-__global__ __launch_bounds__(256) void k_pose_reduce(const float* partials, int rows, float* dL_dviews) {
-  __shared__ float part[4][kPoseFloats];
-  const int v = blockIdx.x, tid = threadIdx.x;
-  const float* base = partials + (size_t)v * rows * kPoseFloats;
-  float acc[kPoseFloats];
-#pragma unroll
-  for (int k = 0; k < kPoseFloats; ++k) acc[k] = 0.f;
-  for (int r = tid; r < rows; r += 256)
-#pragma unroll
-    for (int k = 0; k < kPoseFloats; ++k) acc[k] += base[(size_t)r * kPoseFloats + k];
-#pragma unroll
-  for (int k = 0; k < kPoseFloats; ++k) {
-    const float s = wave_sum(acc[k]);
-    if ((tid & 63) == 0) part[tid >> 6][k] = s;
-  }
+// Sum of camera-gradient rows, two levels, fixed order (deterministic).  Block (v, b) adds rows [b * per, (b + 1) * per) of view
+// v: 245 threads = 7 rows x 35 columns per step, so a step reads 980 consecutive bytes.  Level 1: the rows k_preprocess_bwd
+// wrote -> kPoseBlocks rows per view; level 2 (one block per view): those -> the (V, 48) output record (zeros behind [35]).
+constexpr int kPoseBlocks = 64;
+__global__ __launch_bounds__(256) void k_pose_reduce(const float* in, int rows, float* out, int out_stride, int out_rows) {
+  __shared__ float part[7][kPoseFloats];
+  const int v = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int r_begin = b * per, r_end = min(rows, r_begin + per);
+  const int k = tid % kPoseFloats, r0 = tid / kPoseFloats;
+  const float* base = in + (size_t)v * rows * kPoseFloats;
+  float acc = 0.f;
+  if (r0 < 7)
+    for (int r = r_begin + r0; r < r_end; r += 7) acc += base[(size_t)r * kPoseFloats + k];
+  if (r0 < 7) part[r0][k] = acc;
   __syncthreads();
-  if (tid < 48) dL_dviews[(size_t)v * 48 + tid] = tid < kPoseFloats ? part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid] : 0.f;
+  float* dst = out + ((size_t)v * out_rows + b) * out_stride;
+  if (tid < out_stride) {
+    float sum = 0.f;
+    if (tid < kPoseFloats)
+      for (int j = 0; j < 7; ++j) sum += part[j][tid];
+    dst[tid] = sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3029,7 +3033,10 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
     if (!pose_partials) return GSR_ERR_INVALID_ARGUMENT;
     p.pose_partials = pose_partials;
     hipLaunchKernelGGL(k_preprocess_bwd<true>, pgrid, dim3(64), shmem, st, p);
-    hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V), dim3(256), 0, st, pose_partials, (int)pgrid.x, dL_dviews);
+    const int rows1 = (int)pgrid.x * 4;
+    float* level1 = pose_partials + (size_t)V * rows1 * kPoseFloats;  // behind the rows of the first level
+    hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V, kPoseBlocks), dim3(256), 0, st, pose_partials, rows1, level1, kPoseFloats, kPoseBlocks);
+    hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V, 1), dim3(256), 0, st, level1, kPoseBlocks, dL_dviews, 48, 1);
   } else {
     hipLaunchKernelGGL(k_preprocess_bwd<false>, pgrid, dim3(64), shmem, st, p);
   }
@@ -3070,7 +3077,7 @@ int gsr_backward_scale_rot(const GsrDims* dims, const GsrView* views, const floa
 
 size_t gsr_pose_partials_bytes(const GsrDims* dims) {
   if (!dims_ok(dims)) return 0;
-  return (size_t)dims->num_views * (size_t)((dims->num_gaussians + 63) / 64) * kPoseFloats * sizeof(float);
+  return (size_t)dims->num_views * ((size_t)((dims->num_gaussians + 63) / 64) * 4 + kPoseBlocks) * kPoseFloats * sizeof(float);
 }
 
 int gsr_backward_ex(const GsrDims* dims, const GsrView* views, const float* means, const float* cov, const float* opacities,
