@@ -2494,7 +2494,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
 // Sum of camera-gradient rows, two levels, fixed order (deterministic).  Block (v, b) adds rows [b * per, (b + 1) * per) of view
 // v: 245 threads = 7 rows x 35 columns per step, so a step reads 980 consecutive bytes.  Level 1: the rows k_preprocess_bwd
 // wrote -> kPoseBlocks rows per view; level 2 (one block per view): those -> the (V, 48) output record (zeros behind [35]).
-constexpr int kPoseBlocks = 64;
+constexpr int kPoseBlocks = 256;
 __global__ __launch_bounds__(256) void k_pose_reduce(const float* in, int rows, float* out, int out_stride, int out_rows) {
   __shared__ float part[7][kPoseFloats];
   const int v = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
@@ -2503,9 +2503,16 @@ __global__ __launch_bounds__(256) void k_pose_reduce(const float* in, int rows, 
   const int k = tid % kPoseFloats, r0 = tid / kPoseFloats;
   const float* base = in + (size_t)v * rows * kPoseFloats;
   float acc = 0.f;
-  if (r0 < 7)
-    for (int r = r_begin + r0; r < r_end; r += 7) acc += base[(size_t)r * kPoseFloats + k];
-  if (r0 < 7) part[r0][k] = acc;
+  if (r0 < 7) {
+    int r = r_begin + r0;
+    for (; r + 21 < r_end; r += 28) {  // four independent loads in flight, added in a fixed order
+      const float a0 = base[(size_t)r * kPoseFloats + k], a1 = base[(size_t)(r + 7) * kPoseFloats + k];
+      const float a2 = base[(size_t)(r + 14) * kPoseFloats + k], a3 = base[(size_t)(r + 21) * kPoseFloats + k];
+      acc += a0; acc += a1; acc += a2; acc += a3;
+    }
+    for (; r < r_end; r += 7) acc += base[(size_t)r * kPoseFloats + k];
+    part[r0][k] = acc;
+  }
   __syncthreads();
   float* dst = out + ((size_t)v * out_rows + b) * out_stride;
   if (tid < out_stride) {

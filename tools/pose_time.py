@@ -1,3 +1,4 @@
+"""Measurement aid (GPU box): eager fwd + bwd step of the headline workload with and without camera gradients."""
 import os, sys, time, torch
 sys.path.insert(0, os.getcwd())
 from pf3plat_amd import synthetic, _lib

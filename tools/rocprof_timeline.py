@@ -26,7 +26,14 @@ def main():
             k = sum(1 for x in cur if x[0].split("#")[0] == short)
             cur.append((short if k == 0 else f"{short}#{k}", st, en))
     passes = [p for p in passes if single.get(id(p)) and 3 <= len(p) <= 8 and any(x[0].startswith("k_tile_fwd") for x in p)]
-    passes = passes[len(passes) // 2: len(passes) // 2 + npass]
+    # the eager back-to-back region (the timed loop): passes whose distance to the next one is within 15 % of the shortest -
+    # event-timed profile runs and the fwd + bwd loops have longer periods
+    gaps = [(b[0][1] - a[0][1]) for a, b in zip(passes[:-1], passes[1:])]
+    if gaps:
+        lim = 1.15 * min(gaps)
+        keep = [i for i, g_ in enumerate(gaps) if g_ <= lim and gaps[max(i - 1, 0)] <= lim]
+        passes = [passes[i] for i in keep]
+    passes = passes[len(passes) // 4: len(passes) // 4 + npass]
     acc = defaultdict(lambda: [0.0, 0.0, 0])
     period = []
     for a, b in zip(passes[:-1], passes[1:]):
