@@ -140,8 +140,10 @@ int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_byt
 
 /* The pair_capacity that suits a call of these dims, given the status block of an earlier (possibly overflowed) call on
  * the same inputs.  Half of the index list is cut into one fixed slot per (view, tile), the other half is a shared region
- * for lists longer than a slot: 2 x num_pairs always suffices; 2 x views x tiles x max_list additionally keeps every list
- * in its slot (no shared counter on the sort path).  Returns the larger.  Host-only arithmetic; callers add headroom. */
+ * for lists longer than a slot: 2 x num_pairs always suffices.  A slot of min(max_list, max(2 x mean list length, 256)) entries
+ * keeps all but a few outlier lists in their slots (an outlier takes a run of the shared half from one bump counter) and
+ * bounds the workspace by 4 x num_pairs however skewed the lists are (one dense tile does not size every slot).  Returns
+ * 2 x max(num_pairs, views x tiles x slot).  Host-only arithmetic; callers add headroom. */
 int64_t gsr_capacity_for(const GsrDims* dims, uint64_t num_pairs, uint32_t max_list);
 
 /* Forward: replaces upstream `_C.rasterize_gaussians` (called through

@@ -123,10 +123,10 @@ static Layout make_layout(const GsrDims& d) {
   L.o_total = o; o = align_up(o + VT * 4, 256);
   L.o_ranges = o; o = align_up(o + VT * 8, 256);
   // keys: a fixed slot per binning workgroup (all it needs unless it lists more than kStagePairs pairs), then a page pool
-  // for the longer regions and for the contiguous scratch of per-tile lists too long for the LDS sort (every pair twice)
+  // for the longer regions and for the contiguous scratch of per-tile lists too long for the LDS sort
   const size_t blocks = V * (rows > 0 ? rows : 1);
   L.key_slots = blocks * (size_t)kSlotStride;
-  L.key_pages = (2 * cap + kPage - 1) / kPage + 64;
+  L.key_pages = (cap + kPage - 1) / kPage + 64;  // (capacity = 2 x pairs, what gsr_capacity_for returns, holds every pair twice)
   L.o_keys = o; o = align_up(o + (L.key_slots + L.key_pages * kPage) * 8 + 64, 256);  // + padding: 16-byte reads may overrun a run by one key
   L.o_list = o; o = align_up(o + cap * 4, 256);
   L.o_blk = o; o = align_up(o + blocks * 4, 256);
@@ -2828,7 +2828,13 @@ int gsr_workspace_sizes(const GsrDims* dims, size_t* geom_bytes, size_t* bin_byt
 int64_t gsr_capacity_for(const GsrDims* dims, uint64_t num_pairs, uint32_t max_list) {
   if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
   const Grid g = make_grid(dims->width, dims->height);
-  const uint64_t slots = (uint64_t)dims->num_views * (uint64_t)g.T * (uint64_t)max_list;
+  // every (view, tile) owns capacity / (2 views tiles) entries of the index list; a list longer than that takes a run of the
+  // shared second half.  So the slot need not fit the ONE longest list of the call: twice the mean length (or the longest,
+  // if shorter) keeps all but a few outliers in their slots and bounds the workspace by 4 x the pairs whatever the skew.
+  const uint64_t VT = (uint64_t)dims->num_views * (uint64_t)g.T;
+  const uint64_t twice_mean = VT ? 2 * ((num_pairs + VT - 1) / VT) : 0;
+  const uint64_t slot = max_list < twice_mean ? max_list : (twice_mean > 256 ? twice_mean : (max_list < 256 ? max_list : 256));
+  const uint64_t slots = VT * slot;
   return (int64_t)(2 * (slots > num_pairs ? slots : num_pairs));
 }
 

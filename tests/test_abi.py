@@ -122,16 +122,20 @@ def test_rasterizer_argument_errors_match_upstream_messages(oracle_backend):
 
 
 def test_capacity_for_is_host_arithmetic():
-    """gsr_capacity_for: 2 x max(num_pairs, views x tiles x max_list) - half the index list is per-(view, tile) slots, half a
-    shared region for longer lists (include/gsr.h)."""
+    """gsr_capacity_for: 2 x max(num_pairs, views x tiles x slot), slot = min(max_list, max(2 x mean list, 256)) - half the index
+    list is per-(view, tile) slots, half a shared region for the longer lists (include/gsr.h)."""
     lib = _lib.load()
     be = rasterizer.HipBackend()
     cfg = rasterizer.RasterConfig(3, 1, 3, 1000, 256, 256, 4, 25, 4, False)
     dims = be._dims(cfg, 0)
-    tiles = 4 * 16 * 16  # 8x8 tiles of a 256 x 256 image
+    vt = 3 * 4 * 16 * 16  # views x 8x8 tiles of a 256 x 256 image
     assert lib.gsr_capacity_for(ctypes.byref(dims), 5_000_000, 100) == 2 * 5_000_000
-    assert lib.gsr_capacity_for(ctypes.byref(dims), 1000, 2000) == 2 * 3 * tiles * 2000
-    assert be.capacity_for(cfg, {"num_pairs": 1000, "max_list": 2000}, headroom=1.0) == 2 * 3 * tiles * (2000 + 16)
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 1000, 2000) == 2 * vt * 256  # sparse scene, one long list: the floor
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 1000, 100) == 2 * vt * 100  # every list fits the longest
+    mean = -(-3_000_000 // vt)
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 3_000_000, 50_000) == 2 * vt * 2 * mean  # skewed: twice the mean, not the outlier
+    assert lib.gsr_capacity_for(ctypes.byref(dims), 3_000_000, 50_000) <= 4 * 3_000_000 + 4 * vt
+    assert be.capacity_for(cfg, {"num_pairs": 1000, "max_list": 100}, headroom=1.0) == 2 * vt * (100 + 16)
     dims.abi_version = 99
     assert lib.gsr_capacity_for(ctypes.byref(dims), 1, 1) == -1
     # covariance helpers: bad sizes / null pointers are error codes, n == 0 is a no-op

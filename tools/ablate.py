@@ -64,7 +64,7 @@ def main():
     chunk = min(range(2048, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)  # choose_chunk(), V = 1
     rows = (n + chunk - 1) // chunk
     cap = int(plan["dims"].pair_capacity)
-    end = lay["keys"] + (rows * (8192 + 136) + ((2 * cap + 1023) // 1024 + 64) * 1024) * 8  # make_layout(): slots + page pool
+    end = lay["keys"] + (rows * (8192 + 136) + ((cap + 1023) // 1024 + 64) * 1024) * 8  # make_layout(): slots + page pool
 
     def slots(first, count):
         raw = plan["bin"][end - (first + count) * 64: end - first * 64].view(torch.int64).reshape(count, 8).flip(0).cpu().double() * 0.01

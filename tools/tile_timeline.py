@@ -51,7 +51,7 @@ def main():
     chunk = min(range(2048, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)
     rows = (n + chunk - 1) // chunk
     cap = int(plan["dims"].pair_capacity)
-    end = lay["keys"] + (rows * (8192 + 136) + ((2 * cap + 1023) // 1024 + 64) * 1024) * 8
+    end = lay["keys"] + (rows * (8192 + 136) + ((cap + 1023) // 1024 + 64) * 1024) * 8
     sl = plan["bin"][end - (8192 + T) * 64: end - 8192 * 64].view(torch.int64).reshape(T, 8).flip(0).cpu()
     ss_b = (sl[:, 0] & 0xffffffff).double() * 0.01  # per bid
     se_b = (sl[:, 6] & 0xffffffff).double() * 0.01
