@@ -69,7 +69,10 @@ extern "C" {
 /* The caller will run gsr_backward on this forward's workspaces: the forward then also zero-fills the per-(view, Gaussian)
  * screen-space gradient rows (inside `geom`, which is that much larger) while it streams the SH coefficients, and
  * gsr_backward called with the same dims and scratch == NULL accumulates into them - no separate zero-fill pass and no
- * extra launch in the backward.  A second backward over the same forward must bring its own `scratch` (the rows are used). */
+ * extra launch in the backward.  A second backward over the same forward must bring its own `scratch` (the rows are used).
+ * With harmonics (sh_coeffs > 0) the colour pass also saves d rgb / d (view direction) of every (view, Gaussian) (48 B, in
+ * `geom`), and any backward called with this flag in its dims reads those instead of the harmonics themselves (300 of the
+ * ~750 bytes per Gaussian the backward preprocess moves).  Forward and backward must therefore be called with the same flags. */
 #define GSR_FLAG_BACKWARD_FOLLOWS 0x10000
 /* Test aid: take the windowed binning path (preprocess, count, prefix, scan, emit, sort) even when the image has few enough
  * tiles for the fused one (k_preprocess_bin + gathering sort). */

@@ -83,7 +83,7 @@ __host__ __device__ inline Grid make_grid(int W, int H) {
 
 struct Layout {
   size_t geom_bytes, bin_bytes, img_bytes;
-  size_t o_rgbc, o_rows;  // in geom (o_rows: screen-space gradient rows, only with GSR_FLAG_BACKWARD_FOLLOWS)
+  size_t o_rgbc, o_rows, o_shj;  // in geom (only with GSR_FLAG_BACKWARD_FOLLOWS: o_rows screen-space gradient rows, o_shj d rgb / d direction)
   size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list, o_blk, o_blktot;  // in bin
   size_t key_slots;  // keys: one fixed slot of kStagePairs keys per binning workgroup, then ...
   size_t key_pages;  // ... a pool of pages of kPage keys (regions / scratch too long for a slot)
@@ -114,8 +114,9 @@ static Layout make_layout(const GsrDims& d) {
   const size_t cap = d.pair_capacity > 0 ? (size_t)d.pair_capacity : 0;
   L.o_rgbc = align_up(V * N * sizeof(GeomRec), 256);
   L.o_rows = L.o_rgbc + align_up(V * N * sizeof(float4), 256);
-  L.geom_bytes = L.o_rows + ((d.flags & GSR_FLAG_BACKWARD_FOLLOWS)
-                                 ? align_up(V * N * GSR_SCREEN_GRAD_FLOATS * ((d.flags & GSR_FLAG_DETERMINISTIC) ? 8 : 4), 256) : 0);
+  L.o_shj = L.o_rows + ((d.flags & GSR_FLAG_BACKWARD_FOLLOWS)
+                            ? align_up(V * N * GSR_SCREEN_GRAD_FLOATS * ((d.flags & GSR_FLAG_DETERMINISTIC) ? 8 : 4), 256) : 0);
+  L.geom_bytes = L.o_shj + (((d.flags & GSR_FLAG_BACKWARD_FOLLOWS) && d.sh_coeffs > 0) ? align_up(V * N * 3 * sizeof(float4), 256) : 0);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
   const size_t rows = (N + choose_chunk(d) - 1) / choose_chunk(d);
@@ -156,6 +157,8 @@ struct Params {
   GeomRec* geom;
   float4* rgbc;
   float4* grad_rows;  // forward with GSR_FLAG_BACKWARD_FOLLOWS: the rows the colour workgroups zero-fill (else null)
+  float4* shj;        // same flag, SH colours: d rgb / d (unit view direction) of every (view, Gaussian), 3 x float4 = rows x, y, z
+                      // (r, g, b, -): saved by the colour pass so that the backward need not read the harmonics again (else null)
   GsrStatus* status;
   uint32_t* counts;      // windowed path: u32 count matrix; fused path: the same storage as uint2 (offset, count)
   uint2* pair_mat;
@@ -768,6 +771,7 @@ constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 7
 
 // `tid` = thread within the group (0 .. kColorThreads - 1), `lds` = the group's 19 200 B; the one barrier inside is the
 // workgroup's, so every group of a workgroup must come here together - a group without a unit passes valid = false.
+template <bool kJ>
 __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool valid, float* lds, int tid) {
   const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
   const int lane = tid & 63, wave = tid >> 6;
@@ -842,6 +846,20 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float cr = 0, cg = 0, cb = 0;
+      if (kJ) {  // a backward follows: d rgb / d direction as well, from the coefficients that are in LDS right now
+        float jx[3] = {0, 0, 0}, jy[3] = {0, 0, 0}, jz[3] = {0, 0, 0};
+        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float bx, float by, float bz) {
+          if (k < M) {
+            const float s0 = sh[k * ks + 0 * cs], s1 = sh[k * ks + 1 * cs], s2 = sh[k * ks + 2 * cs];
+            cr += bk * s0; cg += bk * s1; cb += bk * s2;
+            jx[0] += bx * s0; jx[1] += bx * s1; jx[2] += bx * s2;
+            jy[0] += by * s0; jy[1] += by * s1; jy[2] += by * s2;
+            jz[0] += bz * s0; jz[1] += bz * s1; jz[2] += bz * s2;
+          }
+        });
+        float4* o = p.shj + ((size_t)v * N + i) * 3;
+        o[0] = make_float4(jx[0], jx[1], jx[2], 0.f); o[1] = make_float4(jy[0], jy[1], jy[2], 0.f); o[2] = make_float4(jz[0], jz[1], jz[2], 0.f);
+      } else
       sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
         if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
       });
@@ -860,10 +878,11 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
 // The colour pass as the FIRST launch of the forward chain (independent of the binning).  Its first workgroup also puts the
 // page counter of the key pool to zero for this call: no taker of pages (binning, sorts) runs beside this kernel, and a
 // replay of the very same call (HIP graph: same tag) must not see the pages of the previous replay as taken.
+template <bool kJ>  // kJ: a backward was announced and the colours are harmonics - also save d rgb / d direction (Params::shj)
 __global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
   __shared__ __attribute__((aligned(16))) float lds[kColorLdsFloats];
   if (blockIdx.x == 0 && threadIdx.x == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;
-  color_unit(p, blockIdx.x, true, lds, (int)threadIdx.x);
+  color_unit<kJ>(p, blockIdx.x, true, lds, (int)threadIdx.x);
 }
 
 // K1 (images of up to kTileWindow tiles): preprocess AND the whole binning of this workgroup's `chunk` Gaussians.
@@ -2174,7 +2193,9 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
 // loops over the set's views so SH is read once and every gradient is written once.
 // ------------------------------------------------------------------------------------------------
 constexpr int kPoseFloats = 35;  // dL/d viewmatrix (16), projmatrix (16), campos (3) of a view
-template <bool kPose>
+// kJ: the forward saved d rgb / d direction of every (view, Gaussian) (Params::shj, GSR_FLAG_BACKWARD_FOLLOWS): the harmonics
+// themselves are then not read here at all - 300 B per Gaussian less of the kernel's ~750.
+template <bool kPose, bool kJ>
 __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x, set = blockIdx.y;
@@ -2217,7 +2238,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     load_covariance(p, set, i, gi, rcov);
     load_row(0, sg_first);
   }
-  if (M > 0) {
+  if (M > 0 && !kJ) {
     const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
     const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
     if (ldstride == rowf && ((((uintptr_t)sh_src) & 15) == 0)) {
@@ -2242,7 +2263,11 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   }
   // With one view per set the SH gradient of coefficient k can take the LDS slot of coefficient k as soon as the mean
   // gradient has used it: one walk.  With several views the coefficients must survive all of them: two walks (below).
-  const bool one_walk = (Vs == 1);
+  const bool one_walk = (Vs == 1) || kJ;  // (kJ: the rows are free from the start - zeroed here, accumulated into over the views)
+  if (kJ && M > 0) {
+    float* dsh0 = sh_in + lane * ldstride;  // this lane's own row
+    for (int k = 0; k < rowf; ++k) dsh0[k] = 0.f;
+  }
   if (dbg) stamps[1] = __builtin_amdgcn_s_memrealtime();
   float dmean[3] = {0, 0, 0}, dcov[6] = {0, 0, 0, 0, 0, 0}, dop = 0, dcol[3] = {0, 0, 0};
   bool seen = false;
@@ -2376,6 +2401,17 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       // compile-time strides for the common layouts (see color_unit): run-time ones cost a register per LDS address
       auto sh_block = [&](auto ks_c, auto cs_c) {
         const int ks = ks_c(), cs = cs_c();
+        if (kJ) {  // direction gradient from the saved Jacobian; dL/dsh accumulated over the views into the zeroed row
+          const float4* j = p.shj + oi * 3;
+          const float4 jx = j[0], jy = j[1], jz = j[2];
+          ddx = jx.x * d0 + jx.y * d1 + jx.z * d2;
+          ddy = jy.x * d0 + jy.y * d1 + jy.z * d2;
+          ddz = jz.x * d0 + jz.y * d1 + jz.z * d2;
+          sh_visit(deg, x, y, z, [&](int k, float bk, float, float, float) {
+            if (k < M) { shw[k * ks + 0 * cs] += bk * d0; shw[k * ks + 1 * cs] += bk * d1; shw[k * ks + 2 * cs] += bk * d2; }
+          });
+          return;
+        }
         sh_visit(deg, x, y, z, [&](int k, float bk, float bx, float by, float bz) {
           if (k < M) {
             const float sd = sh[k * ks + 0 * cs] * d0 + sh[k * ks + 1 * cs] * d1 + sh[k * ks + 2 * cs] * d2;
@@ -2444,7 +2480,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   }
   if (dbg) stamps[3] = __builtin_amdgcn_s_memrealtime();
   if (M > 0 && one_walk) {
-    if (!seen) {  // this lane's Gaussian received no gradient: its row still holds the coefficients
+    if (!seen && !kJ) {  // this lane's Gaussian received no gradient: its row still holds the coefficients
       float* dsh = sh_in + lane * ldstride;
       for (int k = 0; k < rowf; ++k) dsh[k] = 0.f;
     }
@@ -2699,6 +2735,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   p.geom = static_cast<GeomRec*>(geom);
   p.rgbc = geom ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rgbc) : nullptr;
   p.grad_rows = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS)) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rows) : nullptr;
+  p.shj = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS) && d->sh_coeffs > 0) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_shj) : nullptr;
   p.status = reinterpret_cast<GsrStatus*>(b + L.o_status);
   p.counts = reinterpret_cast<uint32_t*>(b + L.o_counts);
   p.pair_mat = reinterpret_cast<uint2*>(b + L.o_counts);
@@ -2904,7 +2941,10 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   // at full occupancy), the binning, then one launch per tile for its sort AND its blend.  (Until round 2 the colour
   // workgroups rode behind the sorts in a separate sort launch: same time, the sorts and the stream do not overlap.)
   GSR_MARK();
-  if (color_blocks) hipLaunchKernelGGL(k_color, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
+  if (color_blocks) {
+    if (p.shj) hipLaunchKernelGGL(k_color<true>, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
+    else hipLaunchKernelGGL(k_color<false>, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
+  }
   GSR_STAGE_DONE(0);
   GSR_MARK();
   // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers: 2 launches);
@@ -3045,13 +3085,15 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
   if (dL_dviews) {
     if (!pose_partials) return GSR_ERR_INVALID_ARGUMENT;
     p.pose_partials = pose_partials;
-    hipLaunchKernelGGL(k_preprocess_bwd<true>, pgrid, dim3(64), shmem, st, p);
+    if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<true, true>), pgrid, dim3(64), shmem, st, p);
+    else hipLaunchKernelGGL((k_preprocess_bwd<true, false>), pgrid, dim3(64), shmem, st, p);
     const int rows1 = (int)pgrid.x * 4;
     float* level1 = pose_partials + (size_t)V * rows1 * kPoseFloats;  // behind the rows of the first level
     hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V, kPoseBlocks), dim3(256), 0, st, pose_partials, rows1, level1, kPoseFloats, kPoseBlocks);
     hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V, 1), dim3(256), 0, st, level1, kPoseBlocks, dL_dviews, 48, 1);
   } else {
-    hipLaunchKernelGGL(k_preprocess_bwd<false>, pgrid, dim3(64), shmem, st, p);
+    if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<false, true>), pgrid, dim3(64), shmem, st, p);
+    else hipLaunchKernelGGL((k_preprocess_bwd<false, false>), pgrid, dim3(64), shmem, st, p);
   }
   GSR_STAGE_DONE(1);
 #undef GSR_STAGE_DONE

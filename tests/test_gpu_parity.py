@@ -428,6 +428,29 @@ def test_pose_gradients_through_the_decoder_on_the_device():
     assert np.allclose(d_centres.numpy(), -d_means.numpy(), rtol=2e-3, atol=2e-3 * float(d_means.abs().max()))
 
 
+def test_backward_with_the_saved_direction_jacobian_equals_the_one_that_reads_the_harmonics():
+    """GSR_FLAG_BACKWARD_FOLLOWS: the colour pass saves d rgb / d direction per (view, Gaussian) and k_preprocess_bwd<., true> uses
+    it instead of reading the harmonics again; without the flag the harmonics are read (k_preprocess_bwd<., false>).  Same
+    gradients (a re-association of one sum), three views sharing a set, SH layouts (N, M, 3) and planar."""
+    from pf3plat_amd import _lib
+
+    sc = synthetic.make_scene(41, 6000, (64, 64), num_views=3, near=1.7)
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    vb = gpu_util.scene_viewbuf(sc)
+    gc = torch.rand((3, 3, 64, 64), generator=torch.Generator().manual_seed(0))
+    for planar in (False, True):
+        col = colors.permute(0, 1, 3, 2).contiguous() if planar else colors
+        base = _lib.FLAG_SH_PLANAR if planar else 0
+        a = gpu_util.run_hip(RasterConfig(3, 1, 3, 6000, 64, 64, 4, 25, 4, False, base), vb, means, cov6, opac, col, None, gc, None)
+        b = gpu_util.run_hip(RasterConfig(3, 1, 3, 6000, 64, 64, 4, 25, 4, False, base | _lib.FLAG_BACKWARD_FOLLOWS), vb, means, cov6, opac,
+                             col, None, gc, None)
+        np.testing.assert_array_equal(a["color"], b["color"])
+        for k in ("means", "cov6", "opac", "colors", "means2d"):
+            x, y = a["grads"][k].astype(np.float64), b["grads"][k].astype(np.float64)
+            assert np.linalg.norm(x - y) <= 2e-6 * np.linalg.norm(x), (planar, k)
+        assert np.abs(a["grads"]["colors"]).max() > 0 and np.abs(a["grads"]["means"]).max() > 0
+
+
 def test_debug_mode_synchronises_per_stage_and_changes_nothing():
     from pf3plat_amd import _lib
 
