@@ -846,8 +846,8 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float cr = 0, cg = 0, cb = 0;
+      float jx[3] = {0, 0, 0}, jy[3] = {0, 0, 0}, jz[3] = {0, 0, 0};
       if (kJ) {  // a backward follows: d rgb / d direction as well, from the coefficients that are in LDS right now
-        float jx[3] = {0, 0, 0}, jy[3] = {0, 0, 0}, jz[3] = {0, 0, 0};
         sh_visit(deg, dx, dy, dz, [&](int k, float bk, float bx, float by, float bz) {
           if (k < M) {
             const float s0 = sh[k * ks + 0 * cs], s1 = sh[k * ks + 1 * cs], s2 = sh[k * ks + 2 * cs];
@@ -857,14 +857,18 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
             jz[0] += bz * s0; jz[1] += bz * s1; jz[2] += bz * s2;
           }
         });
-        float4* o = p.shj + ((size_t)v * N + i) * 3;
-        o[0] = make_float4(jx[0], jx[1], jx[2], 0.f); o[1] = make_float4(jy[0], jy[1], jy[2], 0.f); o[2] = make_float4(jz[0], jz[1], jz[2], 0.f);
-      } else
-      sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
-        if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
-      });
+      } else {
+        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
+          if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
+        });
+      }
       cr += 0.5f; cg += 0.5f; cb += 0.5f;
       const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
+      if (kJ) {  // rows x, y, z of the Jacobian; the clamp mask rides in the spare slot (the backward then needs nothing else from here)
+        float4* o = p.shj + ((size_t)v * N + i) * 3;
+        o[0] = make_float4(jx[0], jx[1], jx[2], __uint_as_float(clampbits));
+        o[1] = make_float4(jy[0], jy[1], jy[2], 0.f); o[2] = make_float4(jz[0], jz[1], jz[2], 0.f);
+      }
       p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
     }
   };
@@ -2289,7 +2293,16 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
 #pragma unroll
     for (int k = 0; k < 10; ++k) vis = vis || (sg[k] != 0.f);
     uint32_t bits = 0;
-    if (vis && M > 0) bits = __float_as_uint(p.rgbc[oi].w) << 28;
+    float4 jx = make_float4(0, 0, 0, 0), jy = jx, jz = jx;  // kJ: d rgb / d direction, clamp mask in jx.w
+    if (vis && M > 0) {
+      if (kJ) {
+        const float4* j = p.shj + oi * 3;
+        jx = j[0]; jy = j[1]; jz = j[2];
+        bits = __float_as_uint(jx.w) << 28;
+      } else {
+        bits = __float_as_uint(p.rgbc[oi].w) << 28;
+      }
+    }
     if (in_range) {
       if (p.dL_dextra) p.dL_dextra[oi] = sg[9];
       if (p.dL_dmeans2D) { p.dL_dmeans2D[3 * oi + 0] = sg[0]; p.dL_dmeans2D[3 * oi + 1] = sg[1]; p.dL_dmeans2D[3 * oi + 2] = 0.f; }
@@ -2402,8 +2415,6 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       auto sh_block = [&](auto ks_c, auto cs_c) {
         const int ks = ks_c(), cs = cs_c();
         if (kJ) {  // direction gradient from the saved Jacobian; dL/dsh accumulated over the views into the zeroed row
-          const float4* j = p.shj + oi * 3;
-          const float4 jx = j[0], jy = j[1], jz = j[2];
           ddx = jx.x * d0 + jx.y * d1 + jx.z * d2;
           ddy = jy.x * d0 + jy.y * d1 + jy.z * d2;
           ddz = jz.x * d0 + jz.y * d1 + jz.z * d2;
