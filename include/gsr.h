@@ -67,7 +67,7 @@ extern "C" {
  * order the tiles finish in.  The scratch buffer is then twice as large (gsr_backward_scratch_bytes). */
 #define GSR_FLAG_DETERMINISTIC 0x80
 /* The caller will run gsr_backward on this forward's workspaces: the forward then also zero-fills the per-(view, Gaussian)
- * screen-space gradient rows (inside `geom`, which is that much larger) while it streams the SH coefficients, and
+ * screen-space gradient rows (inside `geom`, which is that much larger) from its VALU-bound geometry kernel, and
  * gsr_backward called with the same dims and scratch == NULL accumulates into them - no separate zero-fill pass and no
  * extra launch in the backward.  A second backward over the same forward must bring its own `scratch` (the rows are used).
  * With harmonics (sh_coeffs > 0) the colour pass also saves d rgb / d (view direction) of every (view, Gaussian) (48 B, in

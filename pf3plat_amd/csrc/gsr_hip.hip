@@ -156,7 +156,7 @@ struct Params {
   int32_t* radii;
   GeomRec* geom;
   float4* rgbc;
-  float4* grad_rows;  // forward with GSR_FLAG_BACKWARD_FOLLOWS: the rows the colour workgroups zero-fill (else null)
+  float4* grad_rows;  // forward with GSR_FLAG_BACKWARD_FOLLOWS: the rows the geometry kernels zero-fill (else null)
   float4* shj;        // same flag, SH colours: d rgb / d (unit view direction) of every (view, Gaussian), 3 x float4 = rows x, y, z
                       // (r, g, b, -): saved by the colour pass so that the backward need not read the harmonics again (else null)
   GsrStatus* status;
@@ -711,6 +711,15 @@ __device__ __forceinline__ void store_records_wave(GeomRec* dst, int valid, cons
   __builtin_amdgcn_wave_barrier();
 }
 
+// GSR_FLAG_BACKWARD_FOLLOWS: the backward's accumulator rows of a wave's (up to) 64 Gaussians of view v start at zero.  Done by
+// the geometry kernels - VALU-bound, their memory pipes idle - rather than by the colour pass, which lives on memory bandwidth.
+__device__ __forceinline__ void zero_rows_wave(const Params& p, int v, int first, int valid, int lane) {
+  const int row4 = (p.d.flags & GSR_FLAG_DETERMINISTIC) ? 2 * GSR_SCREEN_GRAD_FLOATS / 4 : GSR_SCREEN_GRAD_FLOATS / 4;
+  float4* rows = p.grad_rows + ((size_t)v * p.d.num_gaussians + first) * row4;
+  const int n4 = min(valid, 64) * row4;
+  for (int k = lane; k < n4; k += 64) rows[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   __shared__ float4 stage[kPreThreads / 64][256];
   const int i = blockIdx.x * kPreThreads + threadIdx.x, N = p.d.num_gaussians, v = blockIdx.y;
@@ -720,6 +729,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   if (i < N) rec = preprocess_one(p, v, i, [](int) {}, [](int, const Foot&, float) {});
   if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
     store_records_wave(p.geom + (size_t)v * N + first, N - first, rec, stage[threadIdx.x >> 6], lane);
+  if (p.grad_rows) zero_rows_wave(p, v, first, N - first, lane);
 }
 
 // Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the `chunk` Gaussians of
@@ -786,14 +796,6 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   const bool in_range = i < N;
   const size_t gi = (size_t)set * N + (in_range ? i : 0);
   const int M = p.d.sh_coeffs;
-  if (p.grad_rows && valid) {  // a backward follows: its accumulator rows of this unit, all views of the set, start at zero
-    const int row4 = (p.d.flags & GSR_FLAG_DETERMINISTIC) ? 2 * GSR_SCREEN_GRAD_FLOATS / 4 : GSR_SCREEN_GRAD_FLOATS / 4;
-    const int n4 = min(64, N - g0) * row4;
-    for (int vv = 0; vv < Vs; ++vv) {
-      float4* rows = p.grad_rows + ((size_t)(set * Vs + vv) * N + g0) * row4;
-      for (int k = tid; k < n4; k += kColorThreads) rows[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
   if (M == 0) {  // precomputed colours: copy through (no clamp)
     if (in_range && wave == 0 && valid)
       for (int vv = 0; vv < Vs; ++vv)
@@ -951,6 +953,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     }
     if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
       store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
+    if (p.grad_rows) zero_rows_wave(p, v, first, end - first, lane);
   }
   __syncthreads();
   const int nb = (int)min(nbig, (uint32_t)kBigList);
