@@ -86,7 +86,7 @@ def kernel_bytes(n, nv, r16, hw, k_sh):
     }
 
 
-def pmc_traffic(kernels, n):
+def pmc_traffic(kernels, n, mode="fwd"):
     """HBM bytes per launch of every kernel in `kernels` (name fragments) from the TCC counters, one rocprofv3 pass per
     counter (FETCH_SIZE and WRITE_SIZE do not fit one pass), each profiling a child run of this file (--traffic-child:
     a dozen eager forward + backward passes of the headline workload).  Units and the gfx950 correction are those of
@@ -109,7 +109,7 @@ def pmc_traffic(kernels, n):
             d = tempfile.mkdtemp(prefix="gsr_pmc_", dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp", PYTHONPATH=os.path.dirname(here) + os.pathsep + os.environ.get("PYTHONPATH", ""))
             subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "t", "--",
-                            sys.executable, here, "--traffic-child", "--gaussians", str(n)],
+                            sys.executable, here, "--traffic-child", mode, "--gaussians", str(n)],
                            cwd="/tmp", env=env, timeout=240, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
             vals = {k: [] for k in kernels}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gaussians", type=int, default=N_GAUSS, help=argparse.SUPPRESS)
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
-    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # the run those passes profile
+    ap.add_argument("--traffic-child", choices=("fwd", "train"), default=None, help=argparse.SUPPRESS)  # the run those passes profile
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -183,11 +183,19 @@ def main():
     def step():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
 
-    if args.traffic_child:  # profiled by pmc_traffic(): a dozen eager forward + backward passes of the headline workload
-        g_child = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(3)).to(dev)
-        for _ in range(12):
-            step()
-            be.run_backward(plan, viewbuf, means, cov6, opac, shs, None, g_child)  # (plain plan: own scratch + zero-fill)
+    if args.traffic_child:  # profiled by pmc_traffic(): a dozen eager passes of the headline workload - the forward as timed
+        if args.traffic_child == "fwd":  # (inference), or the training step as timed (forward told that a backward follows)
+            for _ in range(12):
+                step()
+        else:
+            from pf3plat_amd import _lib as _gl
+
+            g_child = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(3)).to(dev)
+            cfg_c = RasterConfig(1, 1, 1, n, H, W, 4, D_SH, 4, False, _gl.FLAG_BACKWARD_FOLLOWS)
+            plan_c = be.make_plan(cfg_c, dev, capacity=int(plan["dims"].pair_capacity), backward=True)
+            for _ in range(12):
+                be.run_forward(plan_c, viewbuf, means, cov6, opac, shs)
+                be.run_backward(plan_c, viewbuf, means, cov6, opac, shs, None, g_child)
         torch.cuda.synchronize()
         return
 
@@ -371,7 +379,15 @@ def main():
             result["roofline"]["measured_ceiling"] = f"{type(e).__name__}: {e}"
         traffic = None
         if not args.no_traffic and world == 1:
-            traffic = pmc_traffic(list(KERNELS.values()), n)
+            fwd_names = [KERNELS[k_] for k_ in ("color", "preprocess", "tiles")]
+            bwd_names = [KERNELS[k_] for k_ in ("blend_bwd", "preprocess_bwd")] + ["gsr::k_color"]
+            traffic = pmc_traffic(fwd_names, n, "fwd")
+            t_train = pmc_traffic(bwd_names, n, "train") if traffic is not None else None
+            if traffic is not None and t_train is not None:
+                result["training_forward_color_traffic"] = t_train.pop("gsr::k_color")["traffic"]  # k_color<true>: + the saved Jacobians
+                traffic.update(t_train)
+            else:
+                traffic = None
             if traffic is not None:
                 result["roofline"]["traffic"] = traffic[KERNELS[dom]]["traffic"]
                 result["roofline"]["traffic_detail"] = dict(traffic[KERNELS[dom]], note=(
@@ -480,7 +496,7 @@ def main():
                 sc8 = synthetic.make_scene(2, n, (H, W), d_sh=D_SH, num_views=8, view_offsets=offs)
                 vb8 = synthetic.scene_viewbuf(sc8).to(dev)
                 cfg8 = RasterConfig(8, 1, 8, n, H, W, 4, D_SH, 4, False)
-                plan8 = be.make_plan(cfg8, dev, capacity=be.capacity_for(cfg8, {"num_pairs": 8 * status["num_pairs"], "max_list": status["max_list"]}, headroom=1.3))
+                plan8 = be.make_plan(cfg8, dev, capacity=be.capacity_for(cfg8, {"num_pairs": 8 * status["num_pairs"], "max_list": status["max_list"]}, headroom=1.2))
                 for _ in range(5):
                     be.run_forward(plan8, vb8, means, cov6, opac, shs)
                 torch.cuda.synchronize()
