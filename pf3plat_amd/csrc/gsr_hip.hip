@@ -194,13 +194,38 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) {
-    const uint32_t o = (uint32_t)__shfl_xor((int)v, m, 64);
-    v = o > v ? o : v;
-  }
+// Inclusive prefix sum over the 64 lanes of a wave, DPP only (no LDS permutes): Hillis-Steele inside each 16-lane row
+// (row_shr 1, 2, 4, 8; lanes shifted in from outside the row read 0), then lane 15 of row 0 / 2 into rows 1 / 3
+// (row_bcast15) and lane 31 into rows 2 and 3 (row_bcast31).
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ uint32_t dpp_take_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, BOUND);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+  v += dpp_take_u32<0x111, 0xf, true>(v);   // row_shr:1
+  v += dpp_take_u32<0x112, 0xf, true>(v);   // row_shr:2
+  v += dpp_take_u32<0x114, 0xf, true>(v);   // row_shr:4
+  v += dpp_take_u32<0x118, 0xf, true>(v);   // row_shr:8
+  v += dpp_take_u32<0x142, 0xa, false>(v);  // row_bcast15 -> rows 1 and 3
+  v += dpp_take_u32<0x143, 0xc, false>(v);  // row_bcast31 -> rows 2 and 3
   return v;
+}
+// Maximum over the 64 lanes of a wave (every lane active), DPP rotations inside the 16-lane rows, then the four row results
+// through scalar registers.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row_max_u32(uint32_t v) {
+  const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+  return o > v ? o : v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  v = dpp_row_max_u32<0x128>(v);  // row_ror:8
+  v = dpp_row_max_u32<0x124>(v);  // row_ror:4
+  v = dpp_row_max_u32<0x122>(v);  // row_ror:2
+  v = dpp_row_max_u32<0x121>(v);  // row_ror:1
+  const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t a = r0 > r1 ? r0 : r1, b = r2 > r3 ? r2 : r3;
+  return a > b ? a : b;
 }
 
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only), so give
@@ -970,12 +995,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     cnt[q] = (q < per && b0 + q < T) ? hist[b0 + q] : 0u;
     sum += cnt[q];
   }
-  uint32_t incl = sum;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t x = (uint32_t)__shfl_up((int)incl, o, 64);
-    if (lane >= o) incl += x;
-  }
+  const uint32_t incl = wave_inclusive_scan_u32(sum);
   if (lane == 63) wtot[w] = incl;
   __syncthreads();  // also: every histogram counter has been read
   uint32_t basew = 0, total = 0;
@@ -1362,12 +1382,7 @@ constexpr int kSpanMax = 48;      // most keys in one depth bucket the rank fini
 // Exclusive scan over the kSortThreads per-thread values of a workgroup (wave scan + 4 wave totals through LDS).
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot /*[4] LDS*/, int tid, uint32_t& total) {
   const int lane = tid & 63, w = tid >> 6;
-  uint32_t s = v;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)s, o, 64);
-    if (lane >= o) s += t;
-  }
+  const uint32_t s = wave_inclusive_scan_u32(v);
   if (lane == 63) wave_tot[w] = s;
   __syncthreads();
   uint32_t basew = 0;
