@@ -21,6 +21,7 @@ Camera set-up (gsr_setup_views, one ~4 us launch per batch of views) happens onc
 from __future__ import annotations
 
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -327,10 +328,12 @@ def main():
         ab = algorithmic_bytes(n, nv, r16, H * W, D_SH)
         kb = kernel_bytes(n, nv, r16, H * W, D_SH)
         assert kb["color"] + kb["preprocess"] + kb["tiles"] == ab["total"]
-        # the product chain on this image size is three launches: colour, preprocess + binning, per-tile sort + blend.  The events
-        # between the stages cost the queue a few microseconds each; on this path the count/scan and emit stages are empty, so
-        # their "duration" IS that cost: it is taken off the three real stages (raw values stay in stage_ms_raw)
-        chain_stages = ("color", "preprocess", "tiles")
+        # the product chain on this image size is two launches: binning with the colour pass inside it (k_preprocess_bin<true, .>),
+        # per-tile sort + blend; three when the colour pass is a launch of its own (gsr_colour_in_binning == 0)
+        color_in_bin = bool(be.lib.gsr_colour_in_binning(ctypes.byref(plan["dims"])))
+        if color_in_bin:
+            kb["preprocess"] += kb.pop("color")
+        chain_stages = ("preprocess", "tiles") if color_in_bin else ("color", "preprocess", "tiles")
         raw_acc = dict(acc)
         # what an event boundary adds to a stage that holds a launch: the three event-timed stages minus the eager step (no
         # events), per launch.  (An EMPTY stage - count_scan / emit on this path - reads higher, ~5 us: nothing hides its cost.)
@@ -346,7 +349,8 @@ def main():
                                     "algorithmic_bytes": ab["total"], "N": n, "N_v": nv, "R16": r16}
         result["stage_ms"] = {k_: round(acc[k_], 5) for k_ in chain_stages}
         result["stage_ms_raw"] = {k_: round(raw_acc[k_], 5) for k_ in raw_acc}
-        result["stage_ms"]["note"] = ("HIP events on the launch stream around each launch of the product chain (k_color, k_preprocess_bin, "
+        result["stage_ms"]["note"] = ("HIP events on the launch stream around each launch of the product chain ("
+                                      + ("k_preprocess_bin with the colour pass inside it, " if color_in_bin else "k_color, k_preprocess_bin, ") +
                                       f"k_tile_fwd) minus the cost of an event boundary ({1e3 * gap:.1f} us per launch: the event-timed stages minus the eager "
                                       "step, so the three add up to the eager step); stage_ms_raw holds the event readings")
         # ---- on-box HBM ceilings ("fraction against both"): device copy and triad over 1 GiB arrays
@@ -379,12 +383,13 @@ def main():
             result["roofline"]["measured_ceiling"] = f"{type(e).__name__}: {e}"
         traffic = None
         if not args.no_traffic and world == 1:
-            fwd_names = [KERNELS[k_] for k_ in ("color", "preprocess", "tiles")]
-            bwd_names = [KERNELS[k_] for k_ in ("blend_bwd", "preprocess_bwd")] + ["gsr::k_color"]
+            fwd_names = [KERNELS[k_] for k_ in chain_stages]
+            front = KERNELS["preprocess"] if color_in_bin else KERNELS["color"]  # the launch that also saves the Jacobians in training
+            bwd_names = [KERNELS[k_] for k_ in ("blend_bwd", "preprocess_bwd")] + [front]
             traffic = pmc_traffic(fwd_names, n, "fwd")
             t_train = pmc_traffic(bwd_names, n, "train") if traffic is not None else None
             if traffic is not None and t_train is not None:
-                result["training_forward_color_traffic"] = t_train.pop("gsr::k_color")["traffic"]  # k_color<true>: + the saved Jacobians
+                result["training_forward_front_kernel_traffic"] = t_train.pop(front)["traffic"]  # + saved Jacobians, zero-filled rows
                 traffic.update(t_train)
             else:
                 traffic = None
@@ -446,7 +451,7 @@ def main():
              "achieved_GBps": round(kb[k_] / (times[k_] * 1e-3) / 1e9, 1), "frac": round(kb[k_] / (times[k_] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "traffic": None if traffic is None else traffic[KERNELS[k_]]["traffic"],
              "traffic_over_algorithmic": None if traffic is None else round(traffic[KERNELS[k_]]["traffic"] / kb[k_], 3)}
-            for k_ in ("color", "preprocess", "tiles", "blend_bwd", "preprocess_bwd")]
+            for k_ in chain_stages + ("blend_bwd", "preprocess_bwd")]
 
         # ---- CPU baseline (the oracle = "port"; the reference has no CPU splatting path) + parity spot check
         if world == 1 and not args.no_cpu_baseline:

@@ -280,6 +280,11 @@ int gsr_backward_profile(const GsrDims* dims, const GsrView* views, const float*
                          float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream,
                          float* stage_ms /* [GSR_BWD_STAGES] host */);
 
+/* Measurement aid: 1 when gsr_forward runs the colour pass inside the binning launch for these dims (two launches: binning +
+ * colour, per-tile sort + blend), 0 when the colour pass is a launch of its own (images of more than ~2200 8x8 tiles, more than
+ * four views per set, the windowed binning path), negative on bad dims. */
+int gsr_colour_in_binning(const GsrDims* dims);
+
 /* Debug aid for tests: byte offsets of the sub-buffers inside `bin` (status, counts, tile_total, ranges, keys,
  * point_list) and `img` (final_T, n_contrib). */
 int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8);

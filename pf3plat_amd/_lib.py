@@ -117,6 +117,8 @@ def load():
     lib.gsr_backward.argtypes = [dp] + [vp] * 19
     lib.gsr_forward_scale_rot.restype = ctypes.c_int
     lib.gsr_forward_scale_rot.argtypes = [dp, vp, vp, vp, vp, ctypes.c_int] + [vp] * 10
+    lib.gsr_colour_in_binning.restype = ctypes.c_int
+    lib.gsr_colour_in_binning.argtypes = [dp]
     lib.gsr_backward_ex.restype = ctypes.c_int
     lib.gsr_backward_ex.argtypes = [dp] + [vp] * 18 + [ctypes.POINTER(GsrBackwardOptions), vp]
     lib.gsr_pose_partials_bytes.restype = ctypes.c_size_t
@@ -148,7 +150,7 @@ EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
-    "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
+    "gsr_colour_in_binning", "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
     "gsr_image_loss", "gsr_image_loss_partials",
 )
 # gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning

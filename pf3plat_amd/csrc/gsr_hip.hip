@@ -169,7 +169,8 @@ struct Params {
   uint32_t stride;       // index-list entries owned by every (view, tile)
   uint32_t tail_off, tail_cap;  // the rest of the index list: lists longer than `stride`, bump-allocated
   uint32_t* tail_counter;
-  unsigned long long* page_counter;  // in the status block: (call tag << 32) | pages of the key pool handed out so far
+  unsigned long long* page_counter;  // in the status block: (call tag << 32) | pool pages handed out so far by the binning launch
+  unsigned long long* page_counter_tiles;  // same form, by the tile launch (its pages are the upper half of the pool)
   uint32_t call_tag;       // unique per gsr_forward call of this process: a counter left by another call reads as zero
   uint32_t sort_blocks;    // workgroups of the tile launch = views x tiles
   uint32_t color_units;    // colour units per set = ceil(N / 64)
@@ -736,6 +737,29 @@ __device__ __forceinline__ void store_records_wave(GeomRec* dst, int valid, cons
   __builtin_amdgcn_wave_barrier();
 }
 
+// The same through a 1 KB stage (sixteen records at a time): k_preprocess_bin<true, .> keeps its LDS for the colour waves' unit buffers.
+__device__ __forceinline__ void store_records_wave_1k(GeomRec* dst, int valid, const GeomRec& rec, float4* lds, int lane) {
+  const int l = lane & 15, sw = (l >> 1) & 3;
+  float4* out = reinterpret_cast<float4*>(dst);
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    if ((lane >> 4) == pass) {
+      lds[l * 4 + (0 ^ sw)] = rec.q0;
+      lds[l * 4 + (1 ^ sw)] = rec.q1;
+      lds[l * 4 + (2 ^ sw)] = rec.q2;
+      lds[l * 4 + (3 ^ sw)] = rec.q3;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rr = lane >> 2;  // record 0 .. 15 of this pass
+    const float4 x = lds[rr * 4 + ((lane & 3) ^ ((rr >> 1) & 3))];
+    if (pass * 16 + rr < valid) out[pass * 64 + lane] = x;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // GSR_FLAG_BACKWARD_FOLLOWS: the backward's accumulator rows of a wave's (up to) 64 Gaussians of view v start at zero.  Done by
 // the geometry kernels - VALU-bound, their memory pipes idle - rather than by the colour pass, which lives on memory bandwidth.
 __device__ __forceinline__ void zero_rows_wave(const Params& p, int v, int first, int valid, int lane) {
@@ -760,15 +784,19 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
 // Preprocess and count in one launch (images of up to kTileWindow 8x8 tiles): the workgroup owns the `chunk` Gaussians of
 // one row of the count matrix, histograms their pairs in LDS while it projects them and stores the row at the end -
 // k_count's result without a second pass over the records and without its launch.
-// Pages of the key pool come from a bump counter in the status block.  The counter carries the tag of the call that last
-// touched it in its upper half: a value left by any other call (or never initialised) counts as zero, so the workspace
-// needs no zeroing and nothing has to clean up.  Only the rare workgroup that outgrows its fixed slot comes here.
-__device__ __forceinline__ uint32_t take_pages(const Params& p, uint32_t n) {
-  const unsigned long long tag = (unsigned long long)p.call_tag << 32;
-  unsigned long long cur = __hip_atomic_load(p.page_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Pages of the key pool come from bump counters in the status block: one for the binning launch (lower half of the pool: regions
+// of workgroups that list more than their fixed slot holds), one for the tile launch (upper half: scratch of lists too long for
+// the LDS sort).  A counter carries the tag of the call that last touched it in its upper half: a value left by any other call
+// (or never initialised) counts as zero, so the workspace needs no zeroing.  A replay of the very same call (HIP graph: same
+// tag) must find both at zero again: each counter is put back by the OTHER launch of the chain - the binning launch resets
+// the tile launch's at its start, the tile launch the binning's - so no reset ever runs beside a taker of the same counter.
+// Only the rare workgroup that outgrows its fixed slot / the rare list longer than the LDS sort comes here.
+__device__ __forceinline__ uint32_t take_pages(unsigned long long* counter, uint32_t call_tag, uint32_t n) {
+  const unsigned long long tag = (unsigned long long)call_tag << 32;
+  unsigned long long cur = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (true) {
     const unsigned long long base = (cur >> 32) == (tag >> 32) ? cur : tag;
-    const unsigned long long seen = atomicCAS(p.page_counter, cur, base + n);
+    const unsigned long long seen = atomicCAS(counter, cur, base + n);
     if (seen == cur) return (uint32_t)base;
     cur = seen;
   }
@@ -803,6 +831,58 @@ __device__ __forceinline__ Foot foot_from_lds(const float* b, const Grid& g) {
 constexpr int kColorThreads = 256;
 constexpr int kShPre = 5;  // float4 registers per thread that hold the unit's SH rows (64 * 75 / 4 / 256 = 4.7)
 constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 75: odd)
+
+// Colour (+0.5, clamp mask; kJ: d rgb / d direction as well) of Gaussian i of `set` - this lane - for the views vbegin,
+// vbegin + vstep, ... of the set, from its SH row `sh` (LDS).  Same expression tree as the oracle: rgb bit-exact.
+template <bool kJ>
+__device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
+                                                float rmx, float rmy, float rmz) {
+  const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = p.d.sh_coeffs;
+  const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+  // coefficient k of channel c sits at k * ks + c * cs: (3, 1) for (N, M, 3), (1, M) for the planar (N, 3, M) layout.  The
+  // common layouts get compile-time strides (one base register + immediate offsets); computed per coefficient at run time
+  // the 75 LDS addresses occupied 75 registers.
+  auto eval_views = [&](auto ks_c, auto cs_c) {
+    const int ks = ks_c(), cs = cs_c();
+    for (int vv = vbegin; vv < Vs; vv += vstep) {
+      const int v = set * Vs + vv;
+      const GsrView& cam = p.views[v];
+      const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
+      float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
+      dx = dx / len; dy = dy / len; dz = dz / len;
+      float cr = 0, cg = 0, cb = 0;
+      float jx[3] = {0, 0, 0}, jy[3] = {0, 0, 0}, jz[3] = {0, 0, 0};
+      if (kJ) {  // a backward follows: d rgb / d direction as well, from the coefficients that are in LDS right now
+        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float bx, float by, float bz) {
+          if (k < M) {
+            const float s0 = sh[k * ks + 0 * cs], s1 = sh[k * ks + 1 * cs], s2 = sh[k * ks + 2 * cs];
+            cr += bk * s0; cg += bk * s1; cb += bk * s2;
+            jx[0] += bx * s0; jx[1] += bx * s1; jx[2] += bx * s2;
+            jy[0] += by * s0; jy[1] += by * s1; jy[2] += by * s2;
+            jz[0] += bz * s0; jz[1] += bz * s1; jz[2] += bz * s2;
+          }
+        });
+      } else {
+        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
+          if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
+        });
+      }
+      cr += 0.5f; cg += 0.5f; cb += 0.5f;
+      const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
+      if (kJ) {  // rows x, y, z of the Jacobian; the clamp mask rides in the spare slot (the backward then needs nothing else from here)
+        float4* o = p.shj + ((size_t)v * N + i) * 3;
+        o[0] = make_float4(jx[0], jx[1], jx[2], __uint_as_float(clampbits));
+        o[1] = make_float4(jy[0], jy[1], jy[2], 0.f); o[2] = make_float4(jz[0], jz[1], jz[2], 0.f);
+      }
+      p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
+    }
+  };
+  const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
+  if (!planar) eval_views([] { return 3; }, [] { return 1; });
+  else if (M == 25) eval_views([] { return 1; }, [] { return 25; });
+  else eval_views([] { return 1; }, [&] { return M; });
+}
 
 // `tid` = thread within the group (0 .. kColorThreads - 1), `lds` = the group's 19 200 B; the one barrier inside is the
 // workgroup's, so every group of a workgroup must come here together - a group without a unit passes valid = false.
@@ -856,63 +936,63 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   if (valid && in_range && wave < Vs) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
   __syncthreads();
   if (!in_range || !valid) return;
-  const float* sh = lds + lane * ldstride;
-  const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
   if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
-  // coefficient k of channel c sits at k * ks + c * cs: (3, 1) for (N, M, 3), (1, M) for the planar (N, 3, M) layout.  The
-  // common layouts get compile-time strides (one base register + immediate offsets); computed per coefficient at run time
-  // the 75 LDS addresses occupied 75 registers.
-  auto eval_views = [&](auto ks_c, auto cs_c) {
-    const int ks = ks_c(), cs = cs_c();
-    for (int vv = wave; vv < Vs; vv += kColorThreads / 64) {
-      const int v = set * Vs + vv;
-      const GsrView& cam = p.views[v];
-      const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
-      float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
-      const float len = sqrtf(dx * dx + dy * dy + dz * dz);
-      dx = dx / len; dy = dy / len; dz = dz / len;
-      float cr = 0, cg = 0, cb = 0;
-      float jx[3] = {0, 0, 0}, jy[3] = {0, 0, 0}, jz[3] = {0, 0, 0};
-      if (kJ) {  // a backward follows: d rgb / d direction as well, from the coefficients that are in LDS right now
-        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float bx, float by, float bz) {
-          if (k < M) {
-            const float s0 = sh[k * ks + 0 * cs], s1 = sh[k * ks + 1 * cs], s2 = sh[k * ks + 2 * cs];
-            cr += bk * s0; cg += bk * s1; cb += bk * s2;
-            jx[0] += bx * s0; jx[1] += bx * s1; jx[2] += bx * s2;
-            jy[0] += by * s0; jy[1] += by * s1; jy[2] += by * s2;
-            jz[0] += bz * s0; jz[1] += bz * s1; jz[2] += bz * s2;
-          }
-        });
-      } else {
-        sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
-          if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
-        });
-      }
-      cr += 0.5f; cg += 0.5f; cb += 0.5f;
-      const uint32_t clampbits = (cr < 0.f ? 1u : 0u) | (cg < 0.f ? 2u : 0u) | (cb < 0.f ? 4u : 0u);
-      if (kJ) {  // rows x, y, z of the Jacobian; the clamp mask rides in the spare slot (the backward then needs nothing else from here)
-        float4* o = p.shj + ((size_t)v * N + i) * 3;
-        o[0] = make_float4(jx[0], jx[1], jx[2], __uint_as_float(clampbits));
-        o[1] = make_float4(jy[0], jy[1], jy[2], 0.f); o[2] = make_float4(jz[0], jz[1], jz[2], 0.f);
-      }
-      p.rgbc[(size_t)v * N + i] = make_float4(fmaxf(cr, 0.f), fmaxf(cg, 0.f), fmaxf(cb, 0.f), __uint_as_float(clampbits));
-    }
-  };
-  const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
-  if (!planar) eval_views([] { return 3; }, [] { return 1; });
-  else if (M == 25) eval_views([] { return 1; }, [] { return 25; });
-  else eval_views([] { return 1; }, [&] { return M; });
+  color_eval_lane<kJ>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz);
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
-// The colour pass as the FIRST launch of the forward chain (independent of the binning).  Its first workgroup also puts the
-// page counter of the key pool to zero for this call: no taker of pages (binning, sorts) runs beside this kernel, and a
-// replay of the very same call (HIP graph: same tag) must not see the pages of the previous replay as taken.
+// The same unit of work by ONE wavefront (the colour waves of k_preprocess_bin): the unit's rows come in by LDS-DMA (1 KB per
+// instruction, lane l's 16 bytes land at base + 16 l; nothing passes through registers), the wave waits for them and evaluates
+// every view of the set, lane = Gaussian.  `lds`: this wave's own kColorLdsFloats floats - no barrier, no other wave involved.
+template <bool kJ>
+__device__ __forceinline__ void color_unit_wave(const Params& p, int set, int unit, float* lds, int lane) {
+  const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = p.d.sh_coeffs;
+  const int g0 = unit * 64, i = g0 + lane;
+  const bool in_range = i < N;
+  const size_t gi = (size_t)set * N + (in_range ? i : 0);
+  if (M == 0) {  // precomputed colours: copy through (no clamp)
+    if (in_range)
+      for (int vv = 0; vv < Vs; ++vv)
+        p.rgbc[(size_t)(set * Vs + vv) * N + i] = make_float4(p.colors[3 * gi], p.colors[3 * gi + 1], p.colors[3 * gi + 2], 0.f);
+    return;
+  }
+  const int rowf = 3 * M, ldstride = rowf | 1;
+  const int cnt = min(64, N - g0);
+  const float* sh_src = p.colors + ((size_t)set * N + g0) * rowf;
+  const int sh_total = cnt * rowf, sh_n4 = sh_total >> 2;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && lane == 0;
+  unsigned long long* stamp = dbg_stamps(p, 16384 + unit);
+  if (dbg) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the previous unit's LDS reads have returned before its rows are overwritten
+  if ((ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0)) {
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    for (int j = 0; 64 * j < sh_n4; ++j) {
+      const int k = 64 * j + lane;
+      if (k < sh_n4)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const float4*>(sh_src) + k, (lds_ptr_t)(reinterpret_cast<float4*>(lds) + 64 * j), 16, 0, 0);
+    }
+    for (int k = (sh_n4 << 2) + lane; k < sh_total; k += 64) lds[k] = sh_src[k];
+  } else {
+    for (int k = lane; k < sh_total; k += 64) {
+      const int row = k / rowf;
+      lds[row * ldstride + (k - row * rowf)] = sh_src[k];
+    }
+  }
+  float rmx = 0, rmy = 0, rmz = 0;
+  if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
+  if (dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  __builtin_amdgcn_s_waitcnt(0);  // the DMA writes count as vector memory operations (vmcnt); the plain LDS stores as lgkmcnt
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
+  if (in_range) color_eval_lane<kJ>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz);
+  if (dbg) stamp[3] = __builtin_amdgcn_s_memrealtime();
+}
+
+// The colour pass as a launch of its own (independent of the binning; images too large for k_preprocess_bin<true, .>).
 template <bool kJ>  // kJ: a backward was announced and the colours are harmonics - also save d rgb / d direction (Params::shj)
 __global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
   __shared__ __attribute__((aligned(16))) float lds[kColorLdsFloats];
-  if (blockIdx.x == 0 && threadIdx.x == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;
   color_unit<kJ>(p, blockIdx.x, true, lds, (int)threadIdx.x);
 }
 
@@ -929,11 +1009,29 @@ __global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
 // sort_tile<true> (k_tile_fwd) later collects a tile's list from the <= rows regions (column (v, :, t) of the pair matrix).
 // (Same-address device atomics cost ~17 ns each on this chip, one after the other:
 // a counter hit by every workgroup of a launch is a serial section, hence the fixed slots here and in the sort.)
+// kColor: the colour pass of the workgroup's own Gaussians runs INSIDE this launch - the last six of the sixteen waves
+// stream the harmonics of the chunk's 64-Gaussian units through LDS (color_unit_wave: LDS-DMA, 19 KB per wave
+// in flight) and evaluate them while the other twelve project and count.  The binning is VALU-bound with idle memory pipes,
+// the colour pass a memory stream with idle ALUs: together the phase runs at the stream's rate (90 MB -> ~16 us), the
+// separate colour launch (17 us) and its launch boundary are gone.  The busiest SIMDs still make five binning passes
+// (19 units: waves 0-6 take two) plus about one pass worth of colour arithmetic.  kJ: see color_eval_lane.
+// With V views per set the units of a row are dealt out to the row's V workgroups (one per view), each evaluating all V views.
+constexpr int kBinColorWaves = 6, kBinColorBufs = 7;  // (the seventh buffer: the binning wave with the least to do turns colour wave)
+// dynamic LDS.  Plain: [0, 64 KB) record transpose per wave (4 KB each), later the pair staging; then the T tile counters.
+// kColor: [0, 10 KB) record transpose of the ten binning waves (1 KB each); the T tile counters; seven 19 200-byte unit buffers
+// of the colour waves - the pair staging (64 KB) later takes their place.
+constexpr size_t bin_lds_bytes(int T, bool color) {
+  return color ? (size_t)10240 + (((size_t)T * 4 + 15) & ~(size_t)15) + (size_t)kBinColorBufs * kColorLdsFloats * 4
+               : (size_t)(kBinThreads / 64) * 4096 + (size_t)T * 4;
+}
+template <bool kColor, bool kJ>
 __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) {
-  extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters
-  uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kBinThreads / 64) * 256);
+  extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters;
+                                         // then (kColor) one 19 200-byte unit buffer per colour wave
+  uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kColor ? 640 : (kBinThreads / 64) * 256));
+  constexpr int kWavesA = kBinThreads / 64 - (kColor ? kBinColorWaves : 0);  // waves that project and count (phase 1)
   __shared__ float bigs[kBigList][10];
-  __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase;
+  __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase, next_unit;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T, N = p.d.num_gaussians;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
@@ -943,20 +1041,41 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   for (int k = tid; k < T; k += kBinThreads) hist[k] = 0;
   if (tid == 0) {
     nbig = 0;
+    next_unit = 0;
     if (row == 0 && v == 0) {  // only the tile launch touches these, and it runs after this kernel
       p.status->overflow = 0; p.status->max_list = 0; *p.tail_counter = 0u;
+      *p.page_counter_tiles = (unsigned long long)p.call_tag << 32;
     }
   }
   __syncthreads();
   const int end = min(N, (row + 1) * p.chunk);
-  float4* stage = dyn_stage + w * 256;
-  constexpr int kIters = kChunkMax / kBinThreads;
+  float4* stage = kColor ? dyn_stage + w * 64 : dyn_stage + w * 256;  // this wave's record-transpose area (kColor: 1 KB)
+  constexpr int kIters = (kChunkMax + kWavesA * 64 - 1) / (kWavesA * 64);
   float4 q3s[kIters];
   uint32_t inl = 0;  // bit it: this lane's wide footprint of iteration it did not fit the deferred list
   auto count = [&](int t) { atomicAdd(&hist[t], 1u); };
+  // Gaussians of this wave in iteration it (the colour waves have none: `end` for them)
+  auto first_of = [&](int it) { return w < kWavesA ? row * p.chunk + w * 64 + it * kWavesA * 64 : end; };
+  float* const colbufs = reinterpret_cast<float*>(hist + ((T + 3) & ~3));  // (kColor) the unit buffers; later the pair staging
+  // the row's units with (u - u0) = vv (mod Vs) are this workgroup's; its colour waves take them as they get free
+  auto colour_role = [&](int cbuf) {
+    float* buf = colbufs + (size_t)cbuf * kColorLdsFloats;
+    const int Vs = p.d.views_per_set, set = v / Vs, vv = v - set * Vs;
+    const int u0 = row * p.chunk / 64, u1 = (end + 63) / 64;
+    __builtin_amdgcn_s_setprio(3);
+    while (true) {
+      uint32_t k = 0;
+      if (lane == 0) k = atomicAdd(&next_unit, 1u);
+      const int u = u0 + vv + Vs * (int)__builtin_amdgcn_readfirstlane((int)k);
+      if (u >= u1) break;
+      color_unit_wave<kJ>(p, set, u, buf, lane);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  if (kColor && w >= kWavesA) colour_role(w - kWavesA);
 #pragma unroll
   for (int it = 0; it < kIters; ++it) {
-    const int first = row * p.chunk + (tid & ~63) + it * kBinThreads;
+    const int first = first_of(it);
     q3s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (first >= end) continue;  // wave-uniform
     const int i = first + lane;
@@ -976,10 +1095,13 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
       });
       q3s[it] = rec.q3;
     }
-    if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
-      store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
+    if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE)) {
+      if (kColor) store_records_wave_1k(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
+      else store_records_wave(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
+    }
     if (p.grad_rows) zero_rows_wave(p, v, first, end - first, lane);
   }
+  if (kColor && w == kWavesA - 1) colour_role(kBinColorBufs - 1);  // the binning wave with the fewest units: a seventh colour wave
   __syncthreads();
   const int nb = (int)min(nbig, (uint32_t)kBigList);
   for (int e = w; e < nb; e += kBinThreads / 64)  // wide footprints: one wave each, 64 candidate tiles per step
@@ -1011,8 +1133,8 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     uint32_t base = (uint32_t)(blk * kSlotStride);
     if (total > (uint32_t)kStagePairs) {
       const uint32_t npages = (total + kPage - 1) / kPage;
-      const uint32_t first = take_pages(p, npages);
-      base = (first <= p.key_pages && npages <= p.key_pages - first) ? p.pool_off + first * (uint32_t)kPage : 0xffffffffu;
+      const uint32_t first = take_pages(p.page_counter, p.call_tag, npages), half = p.key_pages / 2;  // lower half of the pool
+      base = (first <= half && npages <= half - first) ? p.pool_off + first * (uint32_t)kPage : 0xffffffffu;
     }
     sBase = base;
     p.blk_base[blk] = base;
@@ -1033,7 +1155,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   if (base == 0xffffffffu || total == 0) return;  // key buffer too small (the tile launch reports it) / nothing to list
   // ---- 4. the pairs, again, now to their slots
   const bool staged = total <= (uint32_t)kStagePairs;
-  unsigned long long* lds_keys = reinterpret_cast<unsigned long long*>(dyn_stage);
+  unsigned long long* lds_keys = kColor ? reinterpret_cast<unsigned long long*>(colbufs) : reinterpret_cast<unsigned long long*>(dyn_stage);
   unsigned long long* region = p.keys + base;
   auto put = [&](int gi, int t, float depth) {
     const uint32_t slot = atomicAdd(&hist[t], 1u);
@@ -1043,7 +1165,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   };
 #pragma unroll
   for (int it = 0; it < kIters; ++it) {
-    const int i = row * p.chunk + (tid & ~63) + it * kBinThreads + lane;
+    const int i = first_of(it) + lane;
     if (i >= end) continue;
     walk_pairs(p, q3s[it], i, 0, T, put, [&](int gi) {
       if (!((inl >> it) & 1u)) return;  // deferred: walked by a whole wave below
@@ -1502,8 +1624,8 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
       }
       if (ok && n > kLds) {  // contiguous scratch for the in-place global sort, from the page pool
         const uint32_t np = ((uint32_t)n + kPage - 1) / kPage;
-        const uint32_t first = take_pages(p, np);
-        if (first <= p.key_pages && np <= p.key_pages - first) scratch = p.pool_off + first * (uint32_t)kPage;
+        const uint32_t first = take_pages(p.page_counter_tiles, p.call_tag, np), half = p.key_pages / 2;  // upper half of the pool
+        if (first <= p.key_pages - half && np <= p.key_pages - half - first) scratch = p.pool_off + (half + first) * (uint32_t)kPage;
         else ok = 0;
       }
       if (!ok) p.status->overflow = 1u;
@@ -1933,6 +2055,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
   __shared__ uint32_t sInfo[4];
   const uint32_t bid = blockIdx.x;
   const uint2 rg = sort_tile<kGather, kLds>(p, bid, smem, red, sInfo);
+  if (bid == 0 && threadIdx.x == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;  // the binning launch's (take_pages)
   __syncthreads();  // the list is this workgroup's own: its stores are visible to its waves from here on; the keys are dead
   const int tg = kGather ? xcd_remap((int)bid, (int)p.sort_blocks) : (int)bid;
   const int v = tg / p.g.T;
@@ -2781,6 +2904,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   }
   p.tail_counter = reinterpret_cast<uint32_t*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[1]);
   p.page_counter = reinterpret_cast<unsigned long long*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[0]);
+  p.page_counter_tiles = reinterpret_cast<unsigned long long*>(&reinterpret_cast<GsrStatus*>(b + L.o_status)->reserved[2]);
   p.tile_total = reinterpret_cast<uint32_t*>(b + L.o_total);
   p.ranges = reinterpret_cast<uint2*>(b + L.o_ranges);
   p.keys = reinterpret_cast<unsigned long long*>(b + L.o_keys);
@@ -2876,6 +3000,20 @@ const char* gsr_build_info(void) {
 
 int gsr_last_failed_stage(void) { return g_failed_stage; }
 
+// 1 when gsr_forward runs the colour pass inside the binning launch for these dims (k_preprocess_bin<true, .>: two launches),
+// 0 when it is a launch of its own (three or more), negative on bad dims.  Measurement aid (bench.py attributes bytes to launches).
+static bool color_in_bin_for(const GsrDims& d, const Grid& g) {
+  const bool fused_bin = g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
+  // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
+  // tasks for its seven colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
+  return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= 4 &&
+         bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
+}
+int gsr_colour_in_binning(const GsrDims* dims) {
+  if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
+  return color_in_bin_for(*dims, make_grid(dims->width, dims->height)) ? 1 : 0;
+}
+
 size_t gsr_backward_scratch_bytes(const GsrDims* dims) {
   if (!dims_ok(dims)) return 0;
   const size_t rows = (size_t)dims->num_views * (size_t)dims->num_gaussians;
@@ -2966,30 +3104,36 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const bool do_color = !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH);
   p.color_units = (uint32_t)((N + 63) / 64);
   const unsigned color_blocks = do_color ? p.color_units * (unsigned)d.num_sets : 0u;
-  // One stream, three launches, each waiting for the one before: the colour pass (independent of the binning; an HBM stream
-  // at full occupancy), the binning, then one launch per tile for its sort AND its blend.  (Until round 2 the colour
-  // workgroups rode behind the sorts in a separate sort launch: same time, the sorts and the stream do not overlap.)
+  // One stream, two launches (images of up to ~2500 tiles, e.g. 400 x 400): the binning with the colour pass inside it (k_preprocess_bin<true, .>:
+  // six of its sixteen waves stream the harmonics while ten project and count), then one launch per tile for its sort AND its
+  // blend.  Larger images: the colour pass as its own first launch (k_color), then the binning chain, then the tile launch.
+  // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers);
+  // larger ones the windowed path (preprocess, count, prefix, scan, emit, then the tile launch).
+  const bool fused_bin = p.g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
+  const bool color_in_bin = color_blocks && color_in_bin_for(d, p.g);
   GSR_MARK();
-  if (color_blocks) {
+  if (color_blocks && !color_in_bin) {
     if (p.shj) hipLaunchKernelGGL(k_color<true>, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
     else hipLaunchKernelGGL(k_color<false>, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
   }
   GSR_STAGE_DONE(0);
   GSR_MARK();
-  // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers: 2 launches);
-  // larger ones the windowed path (preprocess, count, prefix, scan, emit, then the tile launch: 5-6 launches).
-  const bool fused_bin = p.g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   if (fused_bin) {
     static std::atomic<unsigned long long> lds_set{0ull};  // per device: > 64 KB of dynamic LDS has to be asked for
     int dev = 0;
     GSR_CHECK(hipGetDevice(&dev));
     if (!((lds_set.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
-      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kBinThreads / 64 * 4096 + kTileWindow * 4));
+      const int plain = (int)bin_lds_bytes(kTileWindow, false), with_color = 160 * 1024 - 10400;
+      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, plain));
+      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color));
+      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color));
       lds_set.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
     }
-    hipLaunchKernelGGL(k_preprocess_bin, dim3((unsigned)p.rows, (unsigned)V), dim3(kBinThreads),
-                       kBinThreads / 64 * 4096 + (size_t)p.g.T * 4, st, p);
+    const dim3 bgrid((unsigned)p.rows, (unsigned)V);
+    const size_t shmem = bin_lds_bytes(p.g.T, color_in_bin);
+    if (!color_in_bin) hipLaunchKernelGGL((k_preprocess_bin<false, false>), bgrid, dim3(kBinThreads), shmem, st, p);
+    else if (p.shj) hipLaunchKernelGGL((k_preprocess_bin<true, true>), bgrid, dim3(kBinThreads), shmem, st, p);
+    else hipLaunchKernelGGL((k_preprocess_bin<true, false>), bgrid, dim3(kBinThreads), shmem, st, p);
   } else {
     hipLaunchKernelGGL(k_preprocess, dim3((unsigned)((N + kPreThreads - 1) / kPreThreads), (unsigned)V), dim3(kPreThreads), 0, st, p);
   }

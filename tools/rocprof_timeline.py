@@ -17,7 +17,8 @@ def main():
     passes, cur, single = [], None, {}
     for name, st, en, gx, gy in rows:
         short = name.split("(")[0].replace("gsr::", "").replace("void ", "")
-        if short.startswith("k_color"):
+        starts = short.startswith("k_color") or (short.startswith("k_preprocess") and (cur is None or any(x[0].startswith("k_tile_fwd") for x in cur)))
+        if starts:  # a forward chain begins at its colour launch, or - colour inside the binning launch - at the binning launch
             cur = []
             passes.append(cur)
         if short.startswith("k_preprocess_bin") and cur is not None:
@@ -25,7 +26,7 @@ def main():
         if cur is not None:
             k = sum(1 for x in cur if x[0].split("#")[0] == short)
             cur.append((short if k == 0 else f"{short}#{k}", st, en))
-    passes = [p for p in passes if single.get(id(p)) and 3 <= len(p) <= 8 and any(x[0].startswith("k_tile_fwd") for x in p)]
+    passes = [p for p in passes if single.get(id(p)) and 2 <= len(p) <= 8 and any(x[0].startswith("k_tile_fwd") for x in p)]
     # the eager back-to-back region (the timed loop): passes whose distance to the next one is within 15 % of the shortest -
     # event-timed profile runs and the fwd + bwd loops have longer periods
     gaps = [(b[0][1] - a[0][1]) for a, b in zip(passes[:-1], passes[1:])]
