@@ -1572,15 +1572,17 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
     const int v = tg / T, t = tg - v * T;
     // De-phase the first resident round.  All its workgroups start together and would gather together (memory-bound, CUs
     // idle: 250 k small reads take 11 us when issued at once, 2-4 us per workgroup when spread out), then sort together
-    // (LDS-bound, memory idle).  Four groups 2 us apart let one group's gather overlap another's bucket sort (measured:
-    // forward 81.2 -> 77.0 us).  Later rounds start whenever a slot frees up and are out of phase by themselves.
+    // (LDS-bound, memory idle).  Four groups 2 us apart let one group's gather overlap another's bucket sort (none at all:
+    // forward +12 us).  The group is the workgroup's residency slot on its CU (workgroups b, b + 256, b + 512, b + 768 share
+    // a CU - HW_ID stamps, tools/tile_timeline.py): the four tiles of a CU are then out of phase with EACH OTHER, one blends
+    // while the next still sorts (grouping neighbouring CUs instead: +0.8 us).  Later rounds start whenever a slot frees up.
     if (bid < 1024u) {
 #ifndef GSR_DEPHASE_GROUPS
 #define GSR_DEPHASE_GROUPS 4
 #define GSR_DEPHASE_SLEEP 64
 #endif
 #ifndef GSR_DEPHASE_SHIFT
-#define GSR_DEPHASE_SHIFT 3
+#define GSR_DEPHASE_SHIFT 8
 #endif
       for (int q = 0; q < (int)((bid >> GSR_DEPHASE_SHIFT) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_DEPHASE_SLEEP);
     }
