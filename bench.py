@@ -352,7 +352,7 @@ def main():
         result["stage_ms"]["note"] = ("HIP events on the launch stream around each launch of the product chain ("
                                       + ("k_preprocess_bin with the colour pass inside it, " if color_in_bin else "k_color, k_preprocess_bin, ") +
                                       f"k_tile_fwd) minus the cost of an event boundary ({1e3 * gap:.1f} us per launch: the event-timed stages minus the eager "
-                                      "step, so the three add up to the eager step); stage_ms_raw holds the event readings")
+                                      "step, so the stages add up to the eager step); stage_ms_raw holds the event readings")
         # ---- on-box HBM ceilings ("fraction against both"): device copy and triad over 1 GiB arrays
         try:
             nel = 256 << 20
