@@ -63,6 +63,28 @@ def main():
             torch.cuda.synchronize()
             bb = min(bb, (time.perf_counter() - t0) / (K // 2))
         out += f" | fwd+bwd {bb * 1e6:7.2f} us  dmeans sum {plan['d_means'].double().abs().sum().item():.6e}"
+    if os.environ.get("EXP_CFG4"):  # BASELINE configs[3] shape through the plan API: 131 072 Gaussians, 3 views, colour + depth, fwd + bwd
+        from pf3plat_amd import _lib
+        sc4 = synthetic.make_scene(50, 131072, (256, 256), num_views=3)
+        m4, c4, o4, s4 = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc4))
+        vb4 = synthetic.scene_viewbuf(sc4).to(dev)
+        cfg4 = RasterConfig(3, 1, 3, 131072, 256, 256, 4, 25, 4, True, (1 << 4) | _lib.FLAG_BACKWARD_FOLLOWS)
+        p4 = be.make_plan(cfg4, dev, capacity=8 * 3 * 131072, backward=True)
+        be.run_forward(p4, vb4, m4, c4, o4, s4)
+        p4 = be.make_plan(cfg4, dev, capacity=be.capacity_for(cfg4, be.read_status(p4), headroom=1.1), backward=True)
+        g4 = torch.rand((3, 3, 256, 256), device=dev); ge4 = torch.rand((3, 256, 256), device=dev)
+        def fb4():
+            be.run_forward(p4, vb4, m4, c4, o4, s4)
+            be.run_backward(p4, vb4, m4, c4, o4, s4, None, g4, ge4)
+        for _ in range(5): fb4()
+        torch.cuda.synchronize()
+        b4 = 1e9
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for _ in range(60): fb4()
+            torch.cuda.synchronize()
+            b4 = min(b4, (time.perf_counter() - t0) / 60)
+        out += f" | cfg4 fwd+bwd {b4 * 1e6:7.2f} us"
     print(out, flush=True)
 
 
