@@ -86,7 +86,7 @@ def main():
     wrap = lambda x: x  # the blend stamps keep only the low 32 bits of the 100 MHz counter
     t0_32 = float(int(t0 * 100) & 0xffffffff) * 0.01
     print("eager timeline (us from the first binning workgroup): preprocess_bin", rel(bst[:, 0].min()), "->", rel(bst[:, 4].max()),
-          "| color", rel(cst[:, 0].min()), "->", rel(cst[:, 1].max()), "(median workgroup start", rel(torch.median(cst[:, 0])), ")",
+          "| color", rel(cst[:, 0].min()), "->", rel(cst[:, 3].max()), "(median workgroup start", rel(torch.median(cst[:, 0])), ")",
           "| sort", rel(slots(8192, 1024)[:, 0].min()), "->", rel(slots(8192, 1024)[:, 6].max()),
           "| blend", round((blend_e - t0_32).min().item(), 2), "->", round((blend_e - t0_32).max().item(), 2), flush=True)
     line("preprocess_bin phases", slots(0, rows), ["preprocess + count", "scan + matrix row", "pair walk", "copy-out"])
