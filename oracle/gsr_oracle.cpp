@@ -144,3 +144,186 @@ GSRO_DEFINE(f64, double)
 int gsro_max_threads() { return omp_get_max_threads(); }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// gsr_cpu_*: the oracle behind the SAME C signatures as the product library's gsr_forward / gsr_backward (include/gsr.h),
+// on HOST pointers ("identical-signature gsr_cpu_* for the oracle").  Still test infrastructure: a C host can
+// run its call sequence against the HIP library and against this and compare.  What the batched operator means is restated
+// here once more, view by view, exactly as the reference wrapper feeds its per-view rasterizer (cuda_splatting.py:64-71,
+// 91-126): means * scale and covariance * scale^2 as fp32 multiplies, one raster call per view, gradients of the views that
+// share a Gaussian set summed with the chain factors.  fp32, GSR_FLAG_SH_PLANAR / COV_3X3 / EXTRA_MODE understood; the
+// scale + quaternion form is not (GSR_ERR_UNSUPPORTED).  `geom` (gsr_cpu_workspace_bytes) keeps one handle per view between
+// forward and backward - gsr_cpu_release frees them; `bin` receives the status block (num_pairs = the reference's
+// num_rendered over 16x16 tiles, max_list = the longest 16x16 list; both differ from the 8x8 figures of the HIP library);
+// `img`, `scratch` and `stream` are ignored.
+// ------------------------------------------------------------------------------------------------
+#include "gsr_cpu.h"
+
+namespace {
+
+struct CpuView {
+  std::vector<float> means, cov6, colors, extra, dfdz;
+};
+
+bool cpu_dims_ok(const GsrDims* d) {
+  return d && d->abi_version == GSR_ABI_VERSION && d->num_views >= 0 && d->num_sets >= 0 && d->views_per_set >= 0 &&
+         d->num_views == d->num_sets * d->views_per_set && d->num_gaussians >= 0 && d->height > 0 && d->width > 0 &&
+         d->sh_coeffs >= 0 && d->sh_coeffs <= 25 && (d->flags & ~GSR_FLAG_VALID_MASK) == 0;
+}
+
+float extra_from_depth(int mode, float z, float nr, float fr, float& dfdz) {  // [EXT] cuda_splatting.py:238-251, as the HIP kernels evaluate it
+  const float eps = 1e-10f;
+  if (mode == GSR_EXTRA_DEPTH) { dfdz = 1.f; return z; }
+  if (mode == GSR_EXTRA_DISPARITY) { dfdz = -1.f / (z * z); return 1.f / z; }
+  if (mode == GSR_EXTRA_RELATIVE_DISPARITY) {
+    const float dn = 1.f / (nr + eps), df = 1.f / (fr + eps), d = 1.f / (z + eps), k = 1.f / (dn - df + eps);
+    dfdz = d * d * k;
+    return 1.f - (d - df) * k;
+  }
+  dfdz = 0.f;
+  return std::log(std::max(std::min(z, nr), fr));
+}
+
+// inputs of view v in the per-view rasterizer's layouts: (N,3) scaled means, (N,6) scaled covariances, (N,M,3) | (N,3) colours
+void gather_view(const GsrDims& d, const GsrView& cam, int set, const float* means, const float* cov, const float* colors,
+                 const float* extra, int v, CpuView& o) {
+  const size_t N = d.num_gaussians, M = d.sh_coeffs;
+  const bool c33 = d.flags & GSR_FLAG_COV_3X3, planar = (d.flags & GSR_FLAG_SH_PLANAR) && M > 0;
+  const int emode = (d.flags >> 4) & 7;
+  o.means.resize(3 * N); o.cov6.resize(6 * N); o.colors.resize((M ? 3 * M : 3) * N);
+  const float* m = means + (size_t)set * N * 3;
+  for (size_t k = 0; k < 3 * N; ++k) o.means[k] = m[k] * cam.scale;
+  const float* c = cov + (size_t)set * N * (c33 ? 9 : 6);
+  static const int up[6] = {0, 1, 2, 4, 5, 8};  // upper triangle of a row-major 3x3
+  for (size_t i = 0; i < N; ++i)
+    for (int k = 0; k < 6; ++k) o.cov6[6 * i + k] = (c33 ? c[9 * i + up[k]] : c[6 * i + k]) * cam.scale2;
+  const float* col = colors + (size_t)set * N * (M ? 3 * M : 3);
+  if (planar) {
+    for (size_t i = 0; i < N; ++i)
+      for (size_t k = 0; k < M; ++k)
+        for (int ch = 0; ch < 3; ++ch) o.colors[(i * M + k) * 3 + ch] = col[(i * 3 + ch) * M + k];
+  } else {
+    std::copy(col, col + o.colors.size(), o.colors.begin());
+  }
+  o.extra.clear(); o.dfdz.clear();
+  if (d.has_extra) {
+    o.extra.resize(N);
+    if (emode) {
+      o.dfdz.resize(N);
+      const float* vm = cam.viewmatrix;
+      for (size_t i = 0; i < N; ++i) {
+        const float z = (vm[2] * o.means[3 * i] + vm[6] * o.means[3 * i + 1] + vm[10] * o.means[3 * i + 2] + vm[14]) / cam.scale;
+        o.extra[i] = extra_from_depth(emode, z, cam.reserved[0], cam.reserved[1], o.dfdz[i]);
+      }
+    } else {
+      std::copy(extra + (size_t)v * N, extra + (size_t)(v + 1) * N, o.extra.begin());
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t gsr_cpu_workspace_bytes(const GsrDims* dims) { return cpu_dims_ok(dims) ? (size_t)(dims->num_views + 1) * sizeof(void*) : 0; }
+
+void gsr_cpu_release(const GsrDims* dims, void* geom) {
+  if (!cpu_dims_ok(dims) || !geom) return;
+  void** h = static_cast<void**>(geom);
+  for (int v = 0; v < dims->num_views; ++v) { delete static_cast<Handle<float>*>(h[v]); h[v] = nullptr; }
+}
+
+int gsr_cpu_forward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov, const float* opacities,
+                    const float* colors, const float* extra, float* out_color, float* out_extra, int32_t* radii, void* geom,
+                    void* bin, void* /*img*/, void* /*stream*/) {
+  if (!cpu_dims_ok(dims) || !geom || !bin || !out_color) return GSR_ERR_INVALID_ARGUMENT;
+  const GsrDims& d = *dims;
+  const size_t V = d.num_views, N = d.num_gaussians, HW = (size_t)d.height * d.width;
+  const int emode = (d.flags >> 4) & 7;
+  GsrStatus* st = static_cast<GsrStatus*>(bin);
+  *st = GsrStatus{};
+  void** h = static_cast<void**>(geom);
+  for (size_t v = 0; v < V; ++v) h[v] = nullptr;
+  if (V == 0) return GSR_OK;
+  if (N == 0) {  // upstream returns an all-zero image when there is nothing to rasterize
+    std::fill(out_color, out_color + V * 3 * HW, 0.f);
+    if (d.has_extra && out_extra) std::fill(out_extra, out_extra + V * HW, 0.f);
+    return GSR_OK;
+  }
+  if (!views || !means || !cov || !opacities || !colors || !radii || (d.has_extra && (!out_extra || (!emode && !extra))))
+    return GSR_ERR_INVALID_ARGUMENT;
+  CpuView in;
+  for (size_t v = 0; v < V; ++v) {
+    const int set = (int)(v / d.views_per_set);
+    const GsrView& cam = views[v];
+    gather_view(d, cam, set, means, cov, colors, extra, (int)v, in);
+    const int dims8[8] = {(int)N, d.height, d.width, d.sh_degree, d.sh_coeffs, d.max_sh_eval, (d.flags & GSR_FLAG_PREFILTERED) ? 1 : 0, 0};
+    h[v] = forward<float>(dims8, cam.viewmatrix, cam.projmatrix, cam.campos, cam.tanfovx, cam.tanfovy, cam.bg, cam.scale_modifier,
+                          in.means.data(), in.cov6.data(), opacities + (size_t)set * N, in.colors.data(),
+                          d.has_extra ? in.extra.data() : nullptr, nullptr, nullptr, out_color + v * 3 * HW,
+                          d.has_extra ? out_extra + v * HW : nullptr, radii + v * N, omp_get_max_threads());
+    auto* hv = static_cast<Handle<float>*>(h[v]);
+    st->num_pairs += (uint64_t)hv->s.R16;
+    for (size_t t = 0; t < hv->s.ranges.size() / 2; ++t)
+      st->max_list = std::max<uint32_t>(st->max_list, hv->s.ranges[2 * t + 1] - hv->s.ranges[2 * t]);
+  }
+  return GSR_OK;
+}
+
+int gsr_cpu_backward(const GsrDims* dims, const GsrView* views, const float* means, const float* cov, const float* /*opacities*/,
+                     const float* colors, const float* extra, const void* geom, const void* /*bin*/, const void* /*img*/,
+                     const float* dL_dcolor, const float* dL_dextra_img, void* /*scratch*/, float* dL_dmeans, float* dL_dcov,
+                     float* dL_dopacities, float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* /*stream*/) {
+  if (!cpu_dims_ok(dims) || !geom) return GSR_ERR_INVALID_ARGUMENT;
+  const GsrDims& d = *dims;
+  const size_t V = d.num_views, N = d.num_gaussians, S = d.num_sets, M = d.sh_coeffs, HW = (size_t)d.height * d.width;
+  if (V == 0 || N == 0) return GSR_OK;
+  if (!views || !means || !cov || !colors || !dL_dcolor || !dL_dmeans || !dL_dcov || !dL_dopacities || !dL_dcolors) return GSR_ERR_INVALID_ARGUMENT;
+  const bool c33 = d.flags & GSR_FLAG_COV_3X3, planar = (d.flags & GSR_FLAG_SH_PLANAR) && M > 0;
+  const int emode = (d.flags >> 4) & 7;
+  const size_t ncol = M ? 3 * M : 3, ncov = c33 ? 9 : 6;
+  std::fill(dL_dmeans, dL_dmeans + S * N * 3, 0.f);
+  std::fill(dL_dcov, dL_dcov + S * N * ncov, 0.f);
+  std::fill(dL_dopacities, dL_dopacities + S * N, 0.f);
+  std::fill(dL_dcolors, dL_dcolors + S * N * ncol, 0.f);
+  std::vector<float> gm(3 * N), gc(6 * N), go(N), gcol(ncol * N), gex(N), g2d(3 * N), zero_img(d.has_extra ? HW : 0, 0.f);
+  void* const* h = static_cast<void* const*>(geom);
+  static const int up[6] = {0, 1, 2, 4, 5, 8};
+  CpuView in;
+  for (size_t v = 0; v < V; ++v) {
+    if (!h[v]) return GSR_ERR_INVALID_ARGUMENT;
+    const size_t set = v / d.views_per_set;
+    const GsrView& cam = views[v];
+    backward<float>(h[v], dL_dcolor + v * 3 * HW, d.has_extra ? (dL_dextra_img ? dL_dextra_img + v * HW : zero_img.data()) : nullptr,
+                    gm.data(), gc.data(), go.data(), gcol.data(), d.has_extra ? gex.data() : nullptr, g2d.data(), nullptr, nullptr,
+                    nullptr, omp_get_max_threads());
+    float* om = dL_dmeans + set * N * 3;
+    for (size_t k = 0; k < 3 * N; ++k) om[k] += gm[k] * cam.scale;
+    float* oc = dL_dcov + set * N * ncov;
+    for (size_t i = 0; i < N; ++i)
+      for (int k = 0; k < 6; ++k) oc[ncov * i + (c33 ? up[k] : k)] += gc[6 * i + k] * cam.scale2;
+    for (size_t i = 0; i < N; ++i) dL_dopacities[set * N + i] += go[i];
+    float* ocol = dL_dcolors + set * N * ncol;
+    if (planar) {
+      for (size_t i = 0; i < N; ++i)
+        for (size_t k = 0; k < M; ++k)
+          for (int ch = 0; ch < 3; ++ch) ocol[(i * 3 + ch) * M + k] += gcol[(i * M + k) * 3 + ch];
+    } else {
+      for (size_t k = 0; k < ncol * N; ++k) ocol[k] += gcol[k];
+    }
+    if (d.has_extra && emode) {  // the built-in channel's f(z): dL/dz flows to the mean through row 2 of the view matrix
+      gather_view(d, cam, (int)set, means, cov, colors, extra, (int)v, in);
+      const float* vm = cam.viewmatrix;
+      for (size_t i = 0; i < N; ++i) {
+        const float gz = gex[i] * in.dfdz[i];
+        om[3 * i] += gz * vm[2]; om[3 * i + 1] += gz * vm[6]; om[3 * i + 2] += gz * vm[10];
+      }
+    } else if (d.has_extra && dL_dextra) {
+      std::copy(gex.begin(), gex.end(), dL_dextra + v * N);
+    }
+    if (dL_dmeans2D) std::copy(g2d.begin(), g2d.end(), dL_dmeans2D + v * N * 3);
+  }
+  return GSR_OK;
+}
+
+}  // extern "C"

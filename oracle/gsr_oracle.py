@@ -23,7 +23,7 @@ _lib = None
 
 def build_oracle(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
-    src = [os.path.join(_HERE, f) for f in ("gsr_oracle.cpp", "gsr_oracle.hpp", "Makefile")]
+    src = [os.path.join(_HERE, f) for f in ("gsr_oracle.cpp", "gsr_oracle.hpp", "gsr_cpu.h", "Makefile")]
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
     )
@@ -47,6 +47,16 @@ def load_oracle():
         for name in ("backward", "get_geom", "get_image_state", "get_binning", "stats", "free"):
             getattr(_lib, f"gsro_{name}_{suf}").restype = None
     _lib.gsro_max_threads.restype = ctypes.c_int
+    # the oracle behind the product library's signatures (gsr_cpu.h): host pointers, same argument lists
+    vp = ctypes.c_void_p
+    _lib.gsr_cpu_workspace_bytes.restype = ctypes.c_size_t
+    _lib.gsr_cpu_workspace_bytes.argtypes = [vp]
+    _lib.gsr_cpu_release.restype = None
+    _lib.gsr_cpu_release.argtypes = [vp, vp]
+    _lib.gsr_cpu_forward.restype = ctypes.c_int
+    _lib.gsr_cpu_forward.argtypes = [vp] * 14
+    _lib.gsr_cpu_backward.restype = ctypes.c_int
+    _lib.gsr_cpu_backward.argtypes = [vp] * 20
     return _lib
 
 
