@@ -3004,16 +3004,39 @@ int gsr_last_failed_stage(void) { return g_failed_stage; }
 
 // 1 when gsr_forward runs the colour pass inside the binning launch for these dims (k_preprocess_bin<true, .>: two launches),
 // 0 when it is a launch of its own (three or more), negative on bad dims.  Measurement aid (bench.py attributes bytes to launches).
-static bool color_in_bin_for(const GsrDims& d, const Grid& g) {
+// Per device, once: more than 64 KB of dynamic LDS has to be asked for.  The plain binning kernel needs 64 KB + the tile counters;
+// the variants with the colour pass inside want all of a CU's 160 KB - a device (or runtime) that does not grant that runs the
+// colour pass as a launch of its own instead (bit in g_color_bin_ok).
+static std::atomic<unsigned long long> g_lds_set{0ull}, g_color_bin_ok{0ull};
+static int ensure_bin_attributes(int* dev_out) {
+  int dev = 0;
+  GSR_CHECK(hipGetDevice(&dev));
+  if (dev_out) *dev_out = dev;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (g_lds_set.load(std::memory_order_acquire) & bit) return GSR_OK;
+  const int plain = (int)bin_lds_bytes(kTileWindow, false), with_color = 160 * 1024 - 10400;
+  GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, plain));
+  const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess &&
+                  hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess;
+  if (ok) g_color_bin_ok.fetch_or(bit, std::memory_order_relaxed);
+  else (void)hipGetLastError();
+  g_lds_set.fetch_or(bit, std::memory_order_release);
+  return GSR_OK;
+}
+static bool color_in_bin_for(const GsrDims& d, const Grid& g, int dev) {
   const bool fused_bin = g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
   // tasks for its seven colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
   return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= 4 &&
+         ((g_color_bin_ok.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull) &&
          bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
 }
 int gsr_colour_in_binning(const GsrDims* dims) {
   if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
-  return color_in_bin_for(*dims, make_grid(dims->width, dims->height)) ? 1 : 0;
+  int dev = 0;
+  const int rc = ensure_bin_attributes(&dev);
+  if (rc != GSR_OK) return rc;
+  return color_in_bin_for(*dims, make_grid(dims->width, dims->height), dev) ? 1 : 0;
 }
 
 size_t gsr_backward_scratch_bytes(const GsrDims* dims) {
@@ -3112,7 +3135,12 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers);
   // larger ones the windowed path (preprocess, count, prefix, scan, emit, then the tile launch).
   const bool fused_bin = p.g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
-  const bool color_in_bin = color_blocks && color_in_bin_for(d, p.g);
+  int dev = 0;
+  {
+    const int rc = ensure_bin_attributes(&dev);
+    if (rc != GSR_OK) return rc;
+  }
+  const bool color_in_bin = color_blocks && color_in_bin_for(d, p.g, dev);
   GSR_MARK();
   if (color_blocks && !color_in_bin) {
     if (p.shj) hipLaunchKernelGGL(k_color<true>, dim3(color_blocks), dim3(kColorThreads), 0, st, p);
@@ -3121,16 +3149,6 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   GSR_STAGE_DONE(0);
   GSR_MARK();
   if (fused_bin) {
-    static std::atomic<unsigned long long> lds_set{0ull};  // per device: > 64 KB of dynamic LDS has to be asked for
-    int dev = 0;
-    GSR_CHECK(hipGetDevice(&dev));
-    if (!((lds_set.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull)) {
-      const int plain = (int)bin_lds_bytes(kTileWindow, false), with_color = 160 * 1024 - 10400;
-      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, plain));
-      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color));
-      GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color));
-      lds_set.fetch_or(1ull << (dev & 63), std::memory_order_relaxed);
-    }
     const dim3 bgrid((unsigned)p.rows, (unsigned)V);
     const size_t shmem = bin_lds_bytes(p.g.T, color_in_bin);
     if (!color_in_bin) hipLaunchKernelGGL((k_preprocess_bin<false, false>), bgrid, dim3(kBinThreads), shmem, st, p);
