@@ -610,7 +610,13 @@ __device__ __forceinline__ void unstage_rows(float* dst, const float* lds, int c
   if (ldstride == rowf) {
     if ((((uintptr_t)dst) & 15) == 0) {
       const int n4 = total >> 2;
-      for (int k = lane; k < n4; k += 64) reinterpret_cast<float4*>(dst)[k] = reinterpret_cast<const float4*>(lds)[k];
+      // streaming stores: the dense SH gradient (300 B per Gaussian, written once, not read again by this library) should not
+      // push the arrays the next forward streams (the harmonics themselves) out of the Infinity Cache: fwd + bwd steps -3 us
+      typedef float f4v_ __attribute__((ext_vector_type(4)));
+      for (int k = lane; k < n4; k += 64) {
+        const float4 x = reinterpret_cast<const float4*>(lds)[k];
+        __builtin_nontemporal_store(f4v_{x.x, x.y, x.z, x.w}, reinterpret_cast<f4v_*>(dst) + k);
+      }
       for (int k = (n4 << 2) + lane; k < total; k += 64) dst[k] = lds[k];
     } else {
       for (int k = lane; k < total; k += 64) dst[k] = lds[k];
