@@ -2173,16 +2173,27 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     sG[0][lane] = g0; sG[1][lane] = g1; sG[2][lane] = g2;
     if (kExtra) sG[3][lane] = ge;
   }
-  const float hW = 0.5f * (float)g.W, hH = 0.5f * (float)g.H;
+  // workgroup-uniform: held in scalar registers (the kExtra instances are at the 128-register limit)
+  const float hW = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(0.5f * (float)g.W)));
+  const float hH = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(0.5f * (float)g.H)));
 
   const uint32_t nbat = (nmax + kBB - 1) / kBB;
   // iteration `it` works on batch nbat-1-it; ring slots are indexed by the iteration number
   auto batch_of = [&](uint32_t it) { return nbat - 1 - it; };
 
+  // the lane number formed where it is used (two instructions) rather than held in a register across the loop: the kExtra
+  // instances sit at the 128-register limit and this was the value the compiler chose to spill
+  auto lane_now = [&]() -> uint32_t {
+    if (!kExtra) return (uint32_t)lane;
+    uint32_t z = 0;
+    asm volatile("" : "+v"(z));
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+  };
   auto stage = [&](uint32_t it, float4& sg, float4& sg2, float4& sc, uint32_t id) {  // lane = entry; issues the gather
     sg = make_float4(0, 0, 0, 0); sg2 = sg; sc = sg;
-    const uint32_t idx = batch_of(it) * kBB + lane;
-    if (lane < kBB && idx < nmax) {
+    const uint32_t ln = lane_now();
+    const uint32_t idx = batch_of(it) * kBB + ln;
+    if (ln < kBB && idx < nmax) {
       const GeomRec* r = geom + id;
       float4 q0 = r->q0, q1 = r->q1;
       const float4 col = rgbc[id];
@@ -2193,8 +2204,9 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   };
   auto load_ids = [&](uint32_t it) -> uint32_t {
     if (it >= nbat) return 0u;
-    const uint32_t idx = batch_of(it) * kBB + lane;
-    return (lane < kBB && idx < nmax) ? plist[idx] : 0u;
+    const uint32_t ln = lane_now();
+    const uint32_t idx = batch_of(it) * kBB + ln;
+    return (ln < kBB && idx < nmax) ? plist[idx] : 0u;
   };
 
   float al[kBS], Gc[kBS], cgv[kBS], rr[kBS];  // this wave's segment of the batch about to be replayed
@@ -2202,9 +2214,11 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   auto eval = [&](uint32_t it) {  // stage E
     const int ring = it & 3;
     const uint32_t base = batch_of(it) * kBB + e0;
+    int es = e0;  // opaque copy: the three LDS addresses are then formed here, per batch, instead of living in three registers
+    if (kExtra) asm volatile("" : "+v"(es));  // across the whole loop (the kExtra instances spilled exactly those)
 #pragma unroll
     for (int u = 0; u < kBS; ++u) {
-      const float4 a = sGeo[ring][e0 + u], a2 = sGeo2[ring][e0 + u], c = sCol[ring][e0 + u];
+      const float4 a = sGeo[ring][es + u], a2 = sGeo2[ring][es + u], c = sCol[ring][es + u];
       const float dx = a.x - pxf, dy = a.y - pyf;
       const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p2);
@@ -2252,9 +2266,8 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       const float4 x = *reinterpret_cast<const float4*>(&sG[c][8 * pr]), y = *reinterpret_cast<const float4*>(&sG[c][8 * pr + 4]);
       o[0] = x.x; o[1] = x.y; o[2] = x.z; o[3] = x.w; o[4] = y.x; o[5] = y.y; o[6] = y.z; o[7] = y.w;
     };
-    float rg0[8], rg1[8], rg2[8], rge[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float rg0[8], rg1[8], rg2[8];
     row8(0, rg0); row8(1, rg1); row8(2, rg2);
-    if (kExtra) row8(3, rge);
     // Only the moments of q = G dL/dalpha are accumulated per pixel; opacity and conic enter after the reduction because
     // dL/dG = o dL/dalpha and dG/ddelx = ln2 (2 a2 gdx + b2 gdy), dG/ddely = ln2 (2 c2 gdy + b2 gdx) are linear in them.
     // (Two pixels per packed-fp32 instruction was tried here: 5 % fewer instructions, but the register pairs it needs push
@@ -2271,7 +2284,12 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       v6 = __builtin_fmaf(wk[k], rg0[k], v6);
       v7 = __builtin_fmaf(wk[k], rg1[k], v7);
       v8 = __builtin_fmaf(wk[k], rg2[k], v8);
-      if (kExtra) v9 = __builtin_fmaf(wk[k], rge[k], v9);
+    }
+    if (kExtra) {  // the fourth channel in a pass of its own: its row of dL/dpixel is live only here (register budget)
+      float rge[8];
+      row8(3, rge);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v9 = __builtin_fmaf(wk[k], rge[k], v9);
     }
     float Sy = dy * S0, Sxy = dy * Sx, Syy = dy * Sy;
     S0 = oct_allreduce(S0); Sx = oct_allreduce(Sx); Sy = oct_allreduce(Sy);
