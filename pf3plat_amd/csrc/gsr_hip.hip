@@ -641,20 +641,31 @@ constexpr int kPreThreads = 256;
 
 // Everything preprocess does for Gaussian i of view v; `hit(tile)` is called once per (8x8 tile, splat) pair it lists.
 // Footprints wider than the 8x8-tile mask window are handed to `big(i, foot)` (the caller walks them).
-template <class F, class B>
-__device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i, F&& hit, B&& big) {
-  const int N = p.d.num_gaussians;
+// The inputs of one Gaussian as they sit in memory (the binning launch asks for the next iteration's before it works on this one's)
+struct GaussIn {
+  float m[3], cov6[6], op;
+};
+__device__ __forceinline__ GaussIn load_gauss(const Params& p, int v, int i) {
   const int set = v / p.d.views_per_set;
+  const size_t gi = (size_t)set * p.d.num_gaussians + i;
+  GaussIn in;
+  in.m[0] = p.means[3 * gi + 0]; in.m[1] = p.means[3 * gi + 1]; in.m[2] = p.means[3 * gi + 2];
+  load_covariance(p, set, i, gi, in.cov6);
+  in.op = p.opac[gi];
+  return in;
+}
+template <class F, class B>
+__device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big) {
+  const int N = p.d.num_gaussians;
   const GsrView& cam = p.views[v];
   const Grid& g = p.g;
-  const size_t gi = (size_t)set * N + i, oi = (size_t)v * N + i;
+  const size_t oi = (size_t)v * N + i;
 
-  const float mx = p.means[3 * gi + 0] * cam.scale, my = p.means[3 * gi + 1] * cam.scale, mz = p.means[3 * gi + 2] * cam.scale;
+  const float mx = in.m[0] * cam.scale, my = in.m[1] * cam.scale, mz = in.m[2] * cam.scale;
   float cov6[6];
-  load_covariance(p, set, i, gi, cov6);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cov6[k] *= cam.scale2;
-  const float op = p.opac[gi];
+  for (int k = 0; k < 6; ++k) cov6[k] = in.cov6[k] * cam.scale2;
+  const float op = in.op;
   const float* vm = cam.viewmatrix;
   const float* pm = cam.projmatrix;
   const float pvz = vm[2] * mx + vm[6] * my + vm[10] * mz + vm[14];
@@ -781,7 +792,7 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
   const int lane = threadIdx.x & 63, first = i - lane;
   if (first >= N) return;
   GeomRec rec{};
-  if (i < N) rec = preprocess_one(p, v, i, [](int) {}, [](int, const Foot&, float) {});
+  if (i < N) rec = preprocess_one(p, v, i, load_gauss(p, v, i), [](int) {}, [](int, const Foot&, float) {});
   if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
     store_records_wave(p.geom + (size_t)v * N + first, N - first, rec, stage[threadIdx.x >> 6], lane);
   if (p.grad_rows) zero_rows_wave(p, v, first, N - first, lane);
@@ -1037,7 +1048,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kColor ? 640 : (kBinThreads / 64) * 256));
   constexpr int kWavesA = kBinThreads / 64 - (kColor ? kBinColorWaves : 0);  // waves that project and count (phase 1)
   __shared__ float bigs[kBigList][10];
-  __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase, next_unit;
+  __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase, next_unit, bin_bar;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = blockIdx.x, v = blockIdx.y;
   const int T = p.g.T, N = p.d.num_gaussians;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
@@ -1048,6 +1059,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   if (tid == 0) {
     nbig = 0;
     next_unit = 0;
+    bin_bar = 0;
     if (row == 0 && v == 0) {  // only the tile launch touches these, and it runs after this kernel
       p.status->overflow = 0; p.status->max_list = 0; *p.tail_counter = 0u;
       *p.page_counter_tiles = (unsigned long long)p.call_tag << 32;
@@ -1068,7 +1080,10 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     float* buf = colbufs + (size_t)cbuf * kColorLdsFloats;
     const int Vs = p.d.views_per_set, set = v / Vs, vv = v - set * Vs;
     const int u0 = row * p.chunk / 64, u1 = (end + 63) / 64;
-    __builtin_amdgcn_s_setprio(3);
+#ifndef GSR_COLOR_PRIO
+#define GSR_COLOR_PRIO 0
+#endif
+    __builtin_amdgcn_s_setprio(GSR_COLOR_PRIO);
     while (true) {
       uint32_t k = 0;
       if (lane == 0) k = atomicAdd(&next_unit, 1u);
@@ -1079,15 +1094,28 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     __builtin_amdgcn_s_setprio(0);
   };
   if (kColor && w >= kWavesA) colour_role(w - kWavesA);
+#ifndef GSR_PREFETCH_IN
+#define GSR_PREFETCH_IN 1
+#endif
+  // the next iteration's inputs are requested before this iteration's arithmetic: under the colour stream a trip to memory
+  // takes microseconds, and the record stores in between keep the compiler from moving the loads up by itself
+#ifndef GSR_BIN_PRIO
+#define GSR_BIN_PRIO 0
+#endif
+  if (kColor && GSR_BIN_PRIO) __builtin_amdgcn_s_setprio(GSR_BIN_PRIO);
+  GaussIn nxt{};
+  if (GSR_PREFETCH_IN && first_of(0) + lane < end) nxt = load_gauss(p, v, first_of(0) + lane);
 #pragma unroll
   for (int it = 0; it < kIters; ++it) {
     const int first = first_of(it);
     q3s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (first >= end) continue;  // wave-uniform
     const int i = first + lane;
+    const GaussIn cur = GSR_PREFETCH_IN ? nxt : (i < end ? load_gauss(p, v, i) : GaussIn{});
+    if (GSR_PREFETCH_IN && it + 1 < kIters && first_of(it + 1) + lane < end) nxt = load_gauss(p, v, first_of(it + 1) + lane);
     GeomRec rec{};
     if (i < end) {
-      rec = preprocess_one(p, v, i, count, [&](int gi, const Foot& f, float depth) {
+      rec = preprocess_one(p, v, i, cur, count, [&](int gi, const Foot& f, float depth) {
         const uint32_t slot = atomicAdd(&nbig, 1u);
         if (slot < (uint32_t)kBigList) {
           float* b = bigs[slot];
@@ -1107,7 +1135,124 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     }
     if (p.grad_rows) zero_rows_wave(p, v, first, end - first, lane);
   }
-  if (kColor && w == kWavesA - 1) colour_role(kBinColorBufs - 1);  // the binning wave with the fewest units: a seventh colour wave
+#ifndef GSR_EARLY_TAIL
+#define GSR_EARLY_TAIL 1
+#endif
+  if constexpr (kColor && GSR_EARLY_TAIL) {
+    // ---- steps 2-4 by the binning waves ALONE, under the colour stream.  The colour waves need ~25 us for the chunk's units, the
+    // binning waves (which yield the SIMDs to them) are through with the projection after ~20: they go on to the scan, the region
+    // and the pair walk at once instead of waiting at a workgroup barrier for the last unit, synchronising among themselves
+    // through an LDS counter (s_barrier is workgroup-wide).  The pair staging cannot have the unit buffers now, so a staged pair is
+    // 2 bytes - the Gaussian's index inside the chunk - in the seventh unit buffer, and the copy-out rebuilds the key from a depth
+    // table of the chunk kept in the (by then idle) transpose area: full lines leave, as before.  (Pairs stored straight from
+    // the walk - 8-byte stores - were tried: the launch then ends 5 us later, draining partial lines.)
+    constexpr int kBinW = kWavesA, kBinT = kBinW * 64;
+    static_assert((kTileWindow / kBinThreads) * kBinT >= 4096, "tile counters owned per thread");
+    static_assert(kStagePairs * 2 <= kColorLdsFloats * 4 && kChunkMax * 4 <= 10240, "staging fits a unit buffer, depths the transpose area");
+    auto arrive = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) __hip_atomic_fetch_add(&bin_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto wait_for = [&](uint32_t target) {
+      while (__hip_atomic_load(&bin_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    if (w >= kWavesA) return;  // colour waves: done (their units were taken above)
+    uint32_t bar = 0;
+    auto group_barrier = [&]() { arrive(); bar += kBinW; wait_for(bar); };
+    group_barrier();  // every pair of the small footprints is in the histogram, every record has left the transpose area
+    float* dtab = reinterpret_cast<float*>(dyn_stage);
+    const int chunk0 = row * p.chunk;
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int i = first_of(it) + lane;
+      if (i < end) dtab[i - chunk0] = q3s[it].w;
+    }
+    const int nb = (int)min(nbig, (uint32_t)kBigList);
+    for (int e = w; e < nb; e += kBinW)  // wide footprints: one wave each, 64 candidate tiles per step
+      big_walk_wave(foot_from_lds(bigs[e], p.g), p.g, lane, count);
+    group_barrier();
+    GSR_STAMP(1);
+    const int per = (T + kBinT - 1) / kBinT;
+    const int b0 = tid * per;
+    uint32_t cnt[kTileWindow / kBinThreads], sum = 0;
+#pragma unroll
+    for (int q = 0; q < kTileWindow / kBinThreads; ++q) {
+      cnt[q] = (q < per && b0 + q < T) ? hist[b0 + q] : 0u;
+      sum += cnt[q];
+    }
+    const uint32_t incl = wave_inclusive_scan_u32(sum);
+    if (lane == 63) wtot[w] = incl;
+    group_barrier();  // also: every histogram counter has been read
+    uint32_t basew = 0, total = 0;
+#pragma unroll
+    for (int k = 0; k < kBinW; ++k) {
+      const uint32_t x = wtot[k];
+      basew += (k < w) ? x : 0u;
+      total += x;
+    }
+    if (tid == 0) {
+      const size_t blk = (size_t)v * p.rows + row;
+      uint32_t base = (uint32_t)(blk * kSlotStride);
+      if (total > (uint32_t)kStagePairs) {
+        const uint32_t npages = (total + kPage - 1) / kPage;
+        const uint32_t first = take_pages(p.page_counter, p.call_tag, npages), half = p.key_pages / 2;  // lower half of the pool
+        base = (first <= half && npages <= half - first) ? p.pool_off + first * (uint32_t)kPage : 0xffffffffu;
+      }
+      sBase = base;
+      p.blk_base[blk] = base;
+      p.blk_total[blk] = total;
+    }
+    uint2* mrow = p.pair_mat + ((size_t)v * p.rows + row) * (T + 8);
+    uint32_t run = basew + incl - sum;
+#pragma unroll
+    for (int q = 0; q < kTileWindow / kBinThreads; ++q)
+      if (q < per && b0 + q < T) {
+        mrow[b0 + q] = make_uint2(run, cnt[q]);
+        hist[b0 + q] = run;  // from here on: the tile's cursor inside the region
+        run += cnt[q];
+      }
+    group_barrier();
+    GSR_STAMP(2);
+    const uint32_t base = sBase;
+    if (base == 0xffffffffu || total == 0) return;
+    const bool staged = total <= (uint32_t)kStagePairs;
+    unsigned long long* region = p.keys + base;
+    unsigned short* st16 = reinterpret_cast<unsigned short*>(colbufs + (size_t)(kBinColorBufs - 1) * kColorLdsFloats);
+    auto put = [&](int gi, int t, float depth) {
+      const uint32_t slot = atomicAdd(&hist[t], 1u);
+      if (staged) st16[slot] = (unsigned short)(gi - chunk0);
+      else region[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
+    };
+#pragma unroll
+    for (int it = 0; it < kIters; ++it) {
+      const int i = first_of(it) + lane;
+      if (i >= end) continue;
+      walk_pairs(p, q3s[it], i, 0, T, put, [&](int gi) {
+        if (!((inl >> it) & 1u)) return;  // deferred: walked by a whole wave below
+        const Foot ft = foot_of_record(p.geom + (size_t)v * N + gi, p.g);  // this wave's own store (complete since the first barrier)
+        const float depth = q3s[it].w;
+        big_walk_lane(ft, p.g, [&](int t) { put(gi, t, depth); });
+      });
+    }
+    for (int e = w; e < nb; e += kBinW) {
+      const float* b = bigs[e];
+      const int gi = __float_as_int(b[8]);
+      const float depth = b[9];
+      big_walk_wave(foot_from_lds(b, p.g), p.g, lane, [&](int t) { put(gi, t, depth); });
+    }
+    GSR_STAMP(3);
+    if (staged) {
+      group_barrier();
+      for (uint32_t k = tid; k < total; k += kBinT) {
+        const uint32_t loc = st16[k];
+        region[k] = ((unsigned long long)__float_as_uint(dtab[loc]) << 32) | (uint32_t)(chunk0 + (int)loc);
+      }
+    }
+    GSR_STAMP(4);
+    return;
+  }
+  if (kColor && !GSR_EARLY_TAIL && w == kWavesA - 1) colour_role(kBinColorBufs - 1);
   __syncthreads();
   const int nb = (int)min(nbig, (uint32_t)kBigList);
   for (int e = w; e < nb; e += kBinThreads / 64)  // wide footprints: one wave each, 64 candidate tiles per step
