@@ -1026,26 +1026,35 @@ __global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
 // sort_tile<true> (k_tile_fwd) later collects a tile's list from the <= rows regions (column (v, :, t) of the pair matrix).
 // (Same-address device atomics cost ~17 ns each on this chip, one after the other:
 // a counter hit by every workgroup of a launch is a serial section, hence the fixed slots here and in the sort.)
-// kColor: the colour pass of the workgroup's own Gaussians runs INSIDE this launch - the last six of the sixteen waves
+// kColor: the colour pass of the workgroup's own Gaussians runs INSIDE this launch - the last five of the sixteen waves
 // stream the harmonics of the chunk's 64-Gaussian units through LDS (color_unit_wave: LDS-DMA, 19 KB per wave
-// in flight) and evaluate them while the other twelve project and count.  The binning is VALU-bound with idle memory pipes,
-// the colour pass a memory stream with idle ALUs: together the phase runs at the stream's rate (90 MB -> ~16 us), the
-// separate colour launch (17 us) and its launch boundary are gone.  The busiest SIMDs still make five binning passes
-// (19 units: waves 0-6 take two) plus about one pass worth of colour arithmetic.  kJ: see color_eval_lane.
+// in flight) and evaluate them while the other eleven project and count, then scan, walk the pairs and copy them out - all of
+// it under the stream (see the body).  The binning alone is VALU-bound with idle memory pipes, the colour pass a memory stream
+// with idle ALUs: together the launch runs at the stream's rate, the separate colour launch (17 us) and its launch boundary are
+// gone.  Six / five / four colour waves: 64.2 / 63.8 / 65.7 us for the forward (eleven binning waves put at most five of the
+// chunk's 19 units on a SIMD, ten put six).  kJ: see color_eval_lane.
 // With V views per set the units of a row are dealt out to the row's V workgroups (one per view), each evaluating all V views.
-constexpr int kBinColorWaves = 6, kBinColorBufs = 7;  // (the seventh buffer: the binning wave with the least to do turns colour wave)
+#ifndef GSR_BIN_CW
+#define GSR_BIN_CW 5
+#endif
+#ifndef GSR_BIN_CB
+#define GSR_BIN_CB (GSR_BIN_CW + 1)
+#endif
+constexpr int kBinColorWaves = GSR_BIN_CW, kBinColorBufs = GSR_BIN_CB;  // unit buffers: one per colour wave + one for the staged pairs
+constexpr int kColorBinMaxTiles = 2200;  // images up to this many tiles take the colour pass inside the binning launch (measured range)
+constexpr int kBinStageBytes = (kBinThreads / 64 - kBinColorWaves) * 1024;  // kColor: 1 KB of record transpose per binning wave
 // dynamic LDS.  Plain: [0, 64 KB) record transpose per wave (4 KB each), later the pair staging; then the T tile counters.
-// kColor: [0, 10 KB) record transpose of the ten binning waves (1 KB each); the T tile counters; seven 19 200-byte unit buffers
-// of the colour waves - the pair staging (64 KB) later takes their place.
+// kColor: [0, 11 KB) record transpose of the eleven binning waves (1 KB each), later the chunk's depth table; the T tile counters;
+// five 19 200-byte unit buffers of the colour waves and a sixth for the staged pairs (2 bytes each).
 constexpr size_t bin_lds_bytes(int T, bool color) {
-  return color ? (size_t)10240 + (((size_t)T * 4 + 15) & ~(size_t)15) + (size_t)kBinColorBufs * kColorLdsFloats * 4
+  return color ? (size_t)kBinStageBytes + (((size_t)T * 4 + 15) & ~(size_t)15) + (size_t)kBinColorBufs * kColorLdsFloats * 4
                : (size_t)(kBinThreads / 64) * 4096 + (size_t)T * 4;
 }
 template <bool kColor, bool kJ>
 __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) {
   extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters;
                                          // then (kColor) one 19 200-byte unit buffer per colour wave
-  uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kColor ? 640 : (kBinThreads / 64) * 256));
+  uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kColor ? kBinStageBytes / 16 : (kBinThreads / 64) * 256));
   constexpr int kWavesA = kBinThreads / 64 - (kColor ? kBinColorWaves : 0);  // waves that project and count (phase 1)
   __shared__ float bigs[kBigList][10];
   __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase, next_unit, bin_bar;
@@ -1080,10 +1089,6 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     float* buf = colbufs + (size_t)cbuf * kColorLdsFloats;
     const int Vs = p.d.views_per_set, set = v / Vs, vv = v - set * Vs;
     const int u0 = row * p.chunk / 64, u1 = (end + 63) / 64;
-#ifndef GSR_COLOR_PRIO
-#define GSR_COLOR_PRIO 0
-#endif
-    __builtin_amdgcn_s_setprio(GSR_COLOR_PRIO);
     while (true) {
       uint32_t k = 0;
       if (lane == 0) k = atomicAdd(&next_unit, 1u);
@@ -1091,28 +1096,21 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
       if (u >= u1) break;
       color_unit_wave<kJ>(p, set, u, buf, lane);
     }
-    __builtin_amdgcn_s_setprio(0);
-  };
+  };  // (s_setprio 3 for these waves, or for the binning waves: no gain once the binning waves no longer wait for them)
   if (kColor && w >= kWavesA) colour_role(w - kWavesA);
-#ifndef GSR_PREFETCH_IN
-#define GSR_PREFETCH_IN 1
-#endif
-  // the next iteration's inputs are requested before this iteration's arithmetic: under the colour stream a trip to memory
-  // takes microseconds, and the record stores in between keep the compiler from moving the loads up by itself
-#ifndef GSR_BIN_PRIO
-#define GSR_BIN_PRIO 0
-#endif
-  if (kColor && GSR_BIN_PRIO) __builtin_amdgcn_s_setprio(GSR_BIN_PRIO);
+  // the next unit's inputs are requested before this unit's arithmetic: under the colour stream a trip to memory takes
+  // microseconds, and the record stores in between keep the compiler from moving the loads up by itself.  (Two units ahead:
+  // no further gain.  Units handed out from an LDS counter instead of in fixed order: +0.5 us)
   GaussIn nxt{};
-  if (GSR_PREFETCH_IN && first_of(0) + lane < end) nxt = load_gauss(p, v, first_of(0) + lane);
+  if (first_of(0) + lane < end) nxt = load_gauss(p, v, first_of(0) + lane);
 #pragma unroll
   for (int it = 0; it < kIters; ++it) {
     const int first = first_of(it);
     q3s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (first >= end) continue;  // wave-uniform
     const int i = first + lane;
-    const GaussIn cur = GSR_PREFETCH_IN ? nxt : (i < end ? load_gauss(p, v, i) : GaussIn{});
-    if (GSR_PREFETCH_IN && it + 1 < kIters && first_of(it + 1) + lane < end) nxt = load_gauss(p, v, first_of(it + 1) + lane);
+    const GaussIn cur = nxt;
+    if (it + 1 < kIters && first_of(it + 1) + lane < end) nxt = load_gauss(p, v, first_of(it + 1) + lane);
     GeomRec rec{};
     if (i < end) {
       rec = preprocess_one(p, v, i, cur, count, [&](int gi, const Foot& f, float depth) {
@@ -1135,20 +1133,17 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     }
     if (p.grad_rows) zero_rows_wave(p, v, first, end - first, lane);
   }
-#ifndef GSR_EARLY_TAIL
-#define GSR_EARLY_TAIL 1
-#endif
-  if constexpr (kColor && GSR_EARLY_TAIL) {
+  if constexpr (kColor) {
     // ---- steps 2-4 by the binning waves ALONE, under the colour stream.  The colour waves need ~25 us for the chunk's units, the
     // binning waves (which yield the SIMDs to them) are through with the projection after ~20: they go on to the scan, the region
     // and the pair walk at once instead of waiting at a workgroup barrier for the last unit, synchronising among themselves
     // through an LDS counter (s_barrier is workgroup-wide).  The pair staging cannot have the unit buffers now, so a staged pair is
-    // 2 bytes - the Gaussian's index inside the chunk - in the seventh unit buffer, and the copy-out rebuilds the key from a depth
+    // 2 bytes - the Gaussian's index inside the chunk - in a unit buffer of their own, and the copy-out rebuilds the key from a depth
     // table of the chunk kept in the (by then idle) transpose area: full lines leave, as before.  (Pairs stored straight from
     // the walk - 8-byte stores - were tried: the launch then ends 5 us later, draining partial lines.)
     constexpr int kBinW = kWavesA, kBinT = kBinW * 64;
-    static_assert((kTileWindow / kBinThreads) * kBinT >= 4096, "tile counters owned per thread");
-    static_assert(kStagePairs * 2 <= kColorLdsFloats * 4 && kChunkMax * 4 <= 10240, "staging fits a unit buffer, depths the transpose area");
+    static_assert((kTileWindow / kBinThreads) * kBinT >= kColorBinMaxTiles, "tile counters owned per thread");
+    static_assert(kStagePairs * 2 <= kColorLdsFloats * 4 && kChunkMax * 4 <= kBinStageBytes, "staging fits a unit buffer, depths the transpose area");
     auto arrive = [&]() {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       if (lane == 0) __hip_atomic_fetch_add(&bin_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1252,7 +1247,6 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     GSR_STAMP(4);
     return;
   }
-  if (kColor && !GSR_EARLY_TAIL && w == kWavesA - 1) colour_role(kBinColorBufs - 1);
   __syncthreads();
   const int nb = (int)min(nbig, (uint32_t)kBigList);
   for (int e = w; e < nb; e += kBinThreads / 64)  // wide footprints: one wave each, 64 candidate tiles per step
@@ -3195,10 +3189,10 @@ static int ensure_bin_attributes(int* dev_out) {
 static bool color_in_bin_for(const GsrDims& d, const Grid& g, int dev) {
   const bool fused_bin = g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
-  // tasks for its seven colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
+  // tasks for its five colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
   return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= 4 &&
          ((g_color_bin_ok.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull) &&
-         bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
+         g.T <= kColorBinMaxTiles && bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
 }
 int gsr_colour_in_binning(const GsrDims* dims) {
   if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
@@ -3299,7 +3293,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   p.color_units = (uint32_t)((N + 63) / 64);
   const unsigned color_blocks = do_color ? p.color_units * (unsigned)d.num_sets : 0u;
   // One stream, two launches (images of up to ~2500 tiles, e.g. 400 x 400): the binning with the colour pass inside it (k_preprocess_bin<true, .>:
-  // six of its sixteen waves stream the harmonics while ten project and count), then one launch per tile for its sort AND its
+  // five of its sixteen waves stream the harmonics while eleven project, count and list the pairs), then one launch per tile for its sort AND its
   // blend.  Larger images: the colour pass as its own first launch (k_color), then the binning chain, then the tile launch.
   // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers);
   // larger ones the windowed path (preprocess, count, prefix, scan, emit, then the tile launch).
