@@ -43,8 +43,8 @@ def reference_rect_stats(plan, cfg):
     """N_v and R16 (sum of 16x16 tiles touched under the reference's ceil(3 sigma) rect rule) from the projected
     records the forward left in HBM — the quantities SURVEY.md §8d's algorithmic-bytes formula is written in."""
     n = cfg.num_gaussians
-    g = plan["geom"][: n * 64].view(torch.float32).reshape(n, 16)
-    r = (plan["geom"][: n * 64].view(torch.int32).reshape(n, 16)[:, 11] & 0x0FFFFFFF)
+    g = plan["geom"][: n * 32].view(torch.float32).reshape(n, 8)  # records: x, y, conic a b c, opacity, extra, radius bits
+    r = (plan["geom"][: n * 32].view(torch.int32).reshape(n, 8)[:, 7] & 0x0FFFFFFF)
     vis = r > 0
     x, y, rf = g[:, 0], g[:, 1], r.to(torch.float32)
     gx, gy = (cfg.width + 15) // 16, (cfg.height + 15) // 16

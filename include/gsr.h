@@ -289,6 +289,11 @@ int gsr_colour_in_binning(const GsrDims* dims);
 /* Debug aid for tests: byte offsets of the sub-buffers inside `bin` (status, counts, tile_total, ranges, keys,
  * point_list) and `img` (final_T, n_contrib). */
 int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8);
+/* The same for `geom`: [0] bytes per projected record (32: x, y, conic a b c, opacity, extra channel, radius bits),
+ * [1] offset of the 16-byte footprint words of the windowed binning chain (-1 on the fused path: they never leave registers),
+ * [2] offset of the (r, g, b, clamp bits) array, [3] offset of the backward's accumulator rows (-1 without
+ * GSR_FLAG_BACKWARD_FOLLOWS). */
+int gsr_geom_layout(const GsrDims* dims, int64_t* offsets4);
 
 #ifdef __cplusplus
 }

@@ -101,6 +101,8 @@ def load():
     lib.gsr_workspace_sizes.argtypes = [dp, szp, szp, szp]
     lib.gsr_workspace_layout.restype = ctypes.c_int
     lib.gsr_workspace_layout.argtypes = [dp, i64p]
+    lib.gsr_geom_layout.restype = ctypes.c_int
+    lib.gsr_geom_layout.argtypes = [dp, i64p]
     lib.gsr_last_failed_stage.restype = ctypes.c_int
     lib.gsr_last_failed_stage.argtypes = []
     lib.gsr_backward_scratch_bytes.restype = ctypes.c_size_t
@@ -150,7 +152,7 @@ EXPORTED_SYMBOLS = (
     "gsr_abi_version", "gsr_build_info", "gsr_workspace_sizes", "gsr_workspace_layout", "gsr_forward",
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
-    "gsr_colour_in_binning", "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
+    "gsr_colour_in_binning", "gsr_geom_layout", "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
     "gsr_image_loss", "gsr_image_loss_partials",
 )
 # gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning

@@ -53,17 +53,20 @@ constexpr int kSlotStride = 8192 + 136;  // keys between the fixed slots of cons
 constexpr int kStagePairs = 8192;  // pairs a binning workgroup collects in LDS (the 64 KB record-transpose area) before one linear copy-out
 constexpr float kNear = 0.2f;     // [EXT] auxiliary.h in_frustum: p_view.z <= 0.2f culls
 
-struct __attribute__((aligned(64))) GeomRec {  // 64 B per (view, Gaussian): one record = half a cache line
+struct __attribute__((aligned(32))) GeomRec {  // 32 B per (view, Gaussian): everything the blends gather, nothing else
   float4 q0;  // x, y, conic a, conic b
-  float4 q1;  // conic c, opacity, -, -
-  float4 q2;  // -, extra, depth, bits(radius)
-  float4 q3;  // bits: hit mask lo, hit mask hi, window origin (sx0 | sy0 << 12 | big << 31), depth
+  float4 q1;  // conic c, opacity, extra channel, bits(radius)
+};
+// What preprocess_one produces: the record plus the footprint word q3 = bits(hit mask lo), bits(hit mask hi),
+// bits(window origin: sx0 | sy0 << 12 | big << 31), depth.  The mask lists the 8x8 tiles this splat must be listed in, over
+// the 8x8-tile window whose top-left tile is (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); footprints wider than 8 tiles set
+// `big` and are re-derived from the record by the binning kernels.  The fused binning launch consumes q3 from registers; only
+// the windowed chain (k_preprocess -> k_count / k_emit) keeps it in memory (Params::aux, 16 B per (view, Gaussian)).
+struct PreRec {
+  float4 q0, q1, q3;
 };
 // The view-dependent colour lives in its own array (float4 per (view, Gaussian): r, g, b, bits(clamp mask)) because it is
 // produced by the colour pass (k_color / color_unit), not by the geometry/binning kernel.
-// q3: the 8x8 tiles this splat must be listed in, as a 64-bit mask over the 8x8-tile window whose top-left tile is
-// (sx0, sy0) (bit = (sy - sy0) * 8 + (sx - sx0)); computed once in preprocess, consumed by count and emit.
-// Footprints wider than 8 tiles set `big` and are re-derived from q0/q1 by the binning kernels.
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2), aligned(8)));  // two keys, 8-byte aligned
 
@@ -83,7 +86,7 @@ __host__ __device__ inline Grid make_grid(int W, int H) {
 
 struct Layout {
   size_t geom_bytes, bin_bytes, img_bytes;
-  size_t o_rgbc, o_rows, o_shj;  // in geom (only with GSR_FLAG_BACKWARD_FOLLOWS: o_rows screen-space gradient rows, o_shj d rgb / d direction)
+  size_t o_aux, o_rgbc, o_rows, o_shj;  // o_aux: 0 = none (fused binning path)  // in geom (only with GSR_FLAG_BACKWARD_FOLLOWS: o_rows screen-space gradient rows, o_shj d rgb / d direction)
   size_t o_status, o_counts, o_total, o_ranges, o_keys, o_list, o_blk, o_blktot;  // in bin
   size_t key_slots;  // keys: one fixed slot of kStagePairs keys per binning workgroup, then ...
   size_t key_pages;  // ... a pool of pages of kPage keys (regions / scratch too long for a slot)
@@ -112,10 +115,20 @@ static Layout make_layout(const GsrDims& d) {
   const Grid g = make_grid(d.width, d.height);
   const size_t V = d.num_views, N = d.num_gaussians, VT = V * (size_t)g.T;
   const size_t cap = d.pair_capacity > 0 ? (size_t)d.pair_capacity : 0;
-  L.o_rgbc = align_up(V * N * sizeof(GeomRec), 256);
-  L.o_rows = L.o_rgbc + align_up(V * N * sizeof(float4), 256);
+  const bool windowed = g.T > kTileWindow || (d.flags & GSR_FLAG_WINDOWED_BINNING) != 0;
+  // every sub-array of `geom` starts on a 2 MiB boundary: the backward kernels gather / scatter by Gaussian index into three of
+  // them at once, and with the arrays packed at 256-byte granularity the 300 k-Gaussian training step was 2-3 us slower for
+  // some sizes of the first array than for others (measured: 143.5-144.2 us packed, 141.4-142.6 aligned)
+#ifndef GSR_GEOM_ALIGN
+#define GSR_GEOM_ALIGN 2097152
+#endif
+  constexpr size_t kGA = GSR_GEOM_ALIGN;
+  const size_t rec_bytes = align_up(V * N * sizeof(GeomRec), kGA);
+  L.o_aux = windowed ? rec_bytes : 0;
+  L.o_rgbc = rec_bytes + (windowed ? align_up(V * N * sizeof(float4), kGA) : 0);
+  L.o_rows = L.o_rgbc + align_up(V * N * sizeof(float4), kGA);
   L.o_shj = L.o_rows + ((d.flags & GSR_FLAG_BACKWARD_FOLLOWS)
-                            ? align_up(V * N * GSR_SCREEN_GRAD_FLOATS * ((d.flags & GSR_FLAG_DETERMINISTIC) ? 8 : 4), 256) : 0);
+                            ? align_up(V * N * GSR_SCREEN_GRAD_FLOATS * ((d.flags & GSR_FLAG_DETERMINISTIC) ? 8 : 4), kGA) : 0);
   L.geom_bytes = L.o_shj + (((d.flags & GSR_FLAG_BACKWARD_FOLLOWS) && d.sh_coeffs > 0) ? align_up(V * N * 3 * sizeof(float4), 256) : 0);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
@@ -155,6 +168,7 @@ struct Params {
   float* out_extra;
   int32_t* radii;
   GeomRec* geom;
+  float4* aux;  // footprint words of the windowed binning chain (null on the fused path)
   float4* rgbc;
   float4* grad_rows;  // forward with GSR_FLAG_BACKWARD_FOLLOWS: the rows the geometry kernels zero-fill (else null)
   float4* shj;        // same flag, SH colours: d rgb / d (unit view direction) of every (view, Gaussian), 3 x float4 = rows x, y, z
@@ -555,8 +569,8 @@ __device__ __forceinline__ void big_walk_wave(const Foot& ft, const Grid& g, int
 constexpr int kBigList = 256;  // deferred wide footprints per binning workgroup (more are walked in line)
 
 __device__ __forceinline__ Foot foot_of_record(const GeomRec* rec, const Grid& g) {
-  const float4 q0 = rec->q0, q1 = rec->q1, q2 = rec->q2;
-  return make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q2.w) & 0x0fffffffu), g);
+  const float4 q0 = rec->q0, q1 = rec->q1;
+  return make_foot(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, (float)(__float_as_uint(q1.w) & 0x0fffffffu), g);
 }
 // Walks the (tile) pairs of one Gaussian from its record's q3 word (hit mask, origin, depth).
 template <class F, class B>
@@ -579,7 +593,7 @@ __device__ __forceinline__ void for_each_pair(const Params& p, int v, int row, i
   const int end = min(N, (row + 1) * p.chunk);
   for (int i = row * p.chunk + tid; i < end; i += kBinThreads) {
     const GeomRec* rec = p.geom + (size_t)v * N + i;
-    const float4 q3 = rec->q3;
+    const float4 q3 = p.aux[(size_t)v * N + i];
     walk_pairs(p, q3, i, t0, t1, f, [&](int) {
       const Foot ft = foot_of_record(rec, p.g);
       big_walk_lane(ft, p.g, [&](int t) { if (t >= t0 && t < t1) f(i, t, q3.w); });
@@ -655,7 +669,7 @@ __device__ __forceinline__ GaussIn load_gauss(const Params& p, int v, int i) {
   return in;
 }
 template <class F, class B>
-__device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big) {
+__device__ __forceinline__ PreRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big) {
   const int N = p.d.num_gaussians;
   const GsrView& cam = p.views[v];
   const Grid& g = p.g;
@@ -695,7 +709,7 @@ __device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i,
   }
   const int radius = vis ? (int)my_radius : 0;
   p.radii[oi] = radius;
-  GeomRec rec;
+  PreRec rec;
   const int emode = (p.d.flags >> 4) & 7;
   float ex = 0.f;
   if (vis && p.d.has_extra) {
@@ -703,8 +717,7 @@ __device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i,
     ex = emode == 0 ? p.extra[oi] : extra_from_depth(emode, pvz / cam.scale, cam.reserved[0], cam.reserved[1], dfdz);
   }
   rec.q0 = vis ? make_float4(px, py, conA, conB) : make_float4(0, 0, 0, 0);
-  rec.q1 = vis ? make_float4(conC, op, 0.f, 0.f) : make_float4(0, 0, 0, 0);
-  rec.q2 = make_float4(0.f, ex, vis ? pvz : 0.f, __uint_as_float((uint32_t)radius));
+  rec.q1 = vis ? make_float4(conC, op, ex, __uint_as_float((uint32_t)radius)) : make_float4(0, 0, 0, 0);
   unsigned long long mask = 0ull;
   uint32_t origin = 0u;
   if (vis && !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_COUNT)) {
@@ -730,48 +743,42 @@ __device__ __forceinline__ GeomRec preprocess_one(const Params& p, int v, int i,
   return rec;
 }
 
-// The wave's 64 records are 4 KB of consecutive memory.  Written lane by lane they are 16-byte requests at a 64-byte
-// stride - a quarter of what the CU's store path carries per request, which made the record store the longest part of
-// preprocess.  Through a 4 KB per-wave LDS transpose (XOR-swizzled, 2-way conflicts on the write, none on the read)
-// every store instruction covers 1 KB of consecutive bytes instead.  `valid` = records of this wave that exist.
-__device__ __forceinline__ void store_records_wave(GeomRec* dst, int valid, const GeomRec& rec, float4* lds, int lane) {
-  const int sw = (lane >> 1) & 3;
-  lds[lane * 4 + (0 ^ sw)] = rec.q0;
-  lds[lane * 4 + (1 ^ sw)] = rec.q1;
-  lds[lane * 4 + (2 ^ sw)] = rec.q2;
-  lds[lane * 4 + (3 ^ sw)] = rec.q3;
+// The wave's 64 records are 2 KB of consecutive memory.  Written lane by lane they are 16-byte requests at a 32-byte
+// stride - half of what the CU's store path carries per request, and the record store was the longest part of preprocess
+// when it was done that way.  Through a per-wave LDS transpose (2 KB; 2-way conflicts on the write, none on the read) every
+// store instruction covers 1 KB of consecutive bytes instead.  `valid` = records of this wave that exist.
+__device__ __forceinline__ void store_records_wave(GeomRec* dst, int valid, const PreRec& rec, float4* lds, int lane) {
+  lds[lane * 2 + 0] = rec.q0;
+  lds[lane * 2 + 1] = rec.q1;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   float4* out = reinterpret_cast<float4*>(dst);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int c = k * 64 + lane, rr = c >> 2;
-    const float4 x = lds[rr * 4 + ((c & 3) ^ ((rr >> 1) & 3))];
-    if (rr < valid) out[c] = x;
+  for (int k = 0; k < 2; ++k) {
+    const int c = k * 64 + lane;
+    const float4 x = lds[c];
+    if ((c >> 1) < valid) out[c] = x;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
-// The same through a 1 KB stage (sixteen records at a time): k_preprocess_bin<true, .> keeps its LDS for the colour waves' unit buffers.
-__device__ __forceinline__ void store_records_wave_1k(GeomRec* dst, int valid, const GeomRec& rec, float4* lds, int lane) {
-  const int l = lane & 15, sw = (l >> 1) & 3;
+// The same through a 1 KB stage (thirty-two records at a time): k_preprocess_bin<true, .> keeps its LDS for the colour waves' unit buffers.
+__device__ __forceinline__ void store_records_wave_1k(GeomRec* dst, int valid, const PreRec& rec, float4* lds, int lane) {
+  const int l = lane & 31;
   float4* out = reinterpret_cast<float4*>(dst);
 #pragma unroll
-  for (int pass = 0; pass < 4; ++pass) {
-    if ((lane >> 4) == pass) {
-      lds[l * 4 + (0 ^ sw)] = rec.q0;
-      lds[l * 4 + (1 ^ sw)] = rec.q1;
-      lds[l * 4 + (2 ^ sw)] = rec.q2;
-      lds[l * 4 + (3 ^ sw)] = rec.q3;
+  for (int pass = 0; pass < 2; ++pass) {
+    if ((lane >> 5) == pass) {
+      lds[l * 2 + 0] = rec.q0;
+      lds[l * 2 + 1] = rec.q1;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int rr = lane >> 2;  // record 0 .. 15 of this pass
-    const float4 x = lds[rr * 4 + ((lane & 3) ^ ((rr >> 1) & 3))];
-    if (pass * 16 + rr < valid) out[pass * 64 + lane] = x;
+    const float4 x = lds[lane];  // record (lane >> 1) of this pass
+    if (pass * 32 + (lane >> 1) < valid) out[pass * 64 + lane] = x;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
@@ -787,14 +794,16 @@ __device__ __forceinline__ void zero_rows_wave(const Params& p, int v, int first
 }
 
 __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
-  __shared__ float4 stage[kPreThreads / 64][256];
+  __shared__ float4 stage[kPreThreads / 64][128];
   const int i = blockIdx.x * kPreThreads + threadIdx.x, N = p.d.num_gaussians, v = blockIdx.y;
   const int lane = threadIdx.x & 63, first = i - lane;
   if (first >= N) return;
-  GeomRec rec{};
+  PreRec rec{};
   if (i < N) rec = preprocess_one(p, v, i, load_gauss(p, v, i), [](int) {}, [](int, const Foot&, float) {});
-  if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE))
+  if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE)) {
     store_records_wave(p.geom + (size_t)v * N + first, N - first, rec, stage[threadIdx.x >> 6], lane);
+    if (i < N && p.aux) p.aux[(size_t)v * N + i] = rec.q3;  // 1 KB of consecutive bytes per wave as it is
+  }
   if (p.grad_rows) zero_rows_wave(p, v, first, N - first, lane);
 }
 
@@ -1111,7 +1120,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
     const int i = first + lane;
     const GaussIn cur = nxt;
     if (it + 1 < kIters && first_of(it + 1) + lane < end) nxt = load_gauss(p, v, first_of(it + 1) + lane);
-    GeomRec rec{};
+    PreRec rec{};
     if (i < end) {
       rec = preprocess_one(p, v, i, cur, count, [&](int gi, const Foot& f, float depth) {
         const uint32_t slot = atomicAdd(&nbig, 1u);
@@ -1497,7 +1506,7 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
 #pragma unroll
     for (int u = 0; u < kChunkMax / kBinThreads; ++u) {
       const int i = row * p.chunk + tid + u * kBinThreads;
-      q3r[u] = i < gend ? p.geom[(size_t)v * N + i].q3 : make_float4(0.f, 0.f, 0.f, 0.f);
+      q3r[u] = i < gend ? p.aux[(size_t)v * N + i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     unsigned long long sum = 0;
     uint32_t mx = 0;
@@ -1576,7 +1585,7 @@ __global__ __launch_bounds__(kBinThreads) void k_emit(const Params p) {
         const int gi = bigs[e];
         const GeomRec* rec = p.geom + (size_t)v * N + gi;
         const Foot ft = foot_of_record(rec, p.g);
-        const float depth = rec->q3.w;
+        const float depth = p.aux[(size_t)v * N + gi].w;
         big_walk_wave(ft, p.g, lane, [&](int t) { put(gi, t, depth); });
       }
     }
@@ -1999,7 +2008,7 @@ __device__ __forceinline__ void stage_batch(const GeomRec* geom, const float4* r
     const GeomRec* r = geom + id;
     const float4 q0 = r->q0, q1 = r->q1;
     const float4 col = rgbc[id];
-    const float ex = want_extra ? r->q2.y : 0.f;
+    const float ex = want_extra ? q1.z : 0.f;
     g = q0; g2 = make_float2(q1.x, q1.y); c = make_float4(col.x, col.y, col.z, ex);
   }
 }
@@ -2336,7 +2345,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       const GeomRec* r = geom + id;
       float4 q0 = r->q0, q1 = r->q1;
       const float4 col = rgbc[id];
-      const float ex = kExtra ? r->q2.y : 0.f;
+      const float ex = kExtra ? q1.z : 0.f;
       to_exp2_domain(q0, q1);
       sg = q0; sg2 = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f); sc = make_float4(col.x, col.y, col.z, ex);
     }
@@ -3050,6 +3059,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   const Layout L = make_layout(*d);
   char* b = static_cast<char*>(bin);
   p.geom = static_cast<GeomRec*>(geom);
+  p.aux = (geom && L.o_aux) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_aux) : nullptr;
   p.rgbc = geom ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rgbc) : nullptr;
   p.grad_rows = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS)) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rows) : nullptr;
   p.shj = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS) && d->sh_coeffs > 0) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_shj) : nullptr;
@@ -3237,6 +3247,16 @@ int gsr_workspace_layout(const GsrDims* dims, int64_t* offsets8) {
   offsets8[0] = (int64_t)L.o_status; offsets8[1] = (int64_t)L.o_counts; offsets8[2] = (int64_t)L.o_total;
   offsets8[3] = (int64_t)L.o_ranges; offsets8[4] = (int64_t)L.o_keys; offsets8[5] = (int64_t)L.o_list;
   offsets8[6] = (int64_t)L.o_finalT; offsets8[7] = (int64_t)L.o_ncontrib;
+  return GSR_OK;
+}
+
+int gsr_geom_layout(const GsrDims* dims, int64_t* offsets4) {
+  if (!dims_ok(dims) || !offsets4) return GSR_ERR_INVALID_ARGUMENT;
+  const Layout L = make_layout(*dims);
+  offsets4[0] = (int64_t)sizeof(GeomRec);
+  offsets4[1] = L.o_aux ? (int64_t)L.o_aux : -1;
+  offsets4[2] = (int64_t)L.o_rgbc;
+  offsets4[3] = (dims->flags & GSR_FLAG_BACKWARD_FOLLOWS) ? (int64_t)L.o_rows : -1;
   return GSR_OK;
 }
 

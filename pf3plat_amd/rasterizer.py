@@ -156,6 +156,13 @@ class HipBackend:
         return dict(zip(("status", "counts", "tile_total", "ranges", "keys", "point_list", "final_T", "n_contrib"),
                         [int(o) for o in offs]))
 
+    def geom_layout(self, dims: _lib.GsrDims):
+        offs = (ctypes.c_int64 * 4)()
+        rc = self.lib.gsr_geom_layout(ctypes.byref(dims), offs)
+        if rc != 0:
+            raise RuntimeError(f"gsr_geom_layout failed (code {rc})")
+        return dict(zip(("record_bytes", "aux", "rgbc", "rows"), [int(o) for o in offs]))
+
     def _check_device(self, *tensors):
         for t in tensors:
             if t is not None and not t.is_cuda:

@@ -24,15 +24,19 @@ def viewbuf_from_cams(cams, bgs, scales=None, device="cpu"):
 
 
 def decode_workspaces(backend, cfg: RasterConfig, saved):
-    """-> dict of numpy arrays: geom (V,N,12 f32 + bits), ranges (V,T,2), point_list, keys, final_T, n_contrib, status."""
+    """-> dict of numpy arrays: geom (V,N,8 f32, word 7 = radius bits), depth (V,N) or None, ranges (V,T,2), point_list, keys, final_T, n_contrib, status."""
     dims, geom, binb, img = saved
     lay = backend.workspace_layout(dims)
     V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
     sgx, sgy = 2 * ((W + 15) // 16), 2 * ((H + 15) // 16)
     T = sgx * sgy
-    g = geom[: V * N * 64].view(torch.float32).reshape(V, N, 16).cpu().numpy()
-    bits = geom[: V * N * 64].view(torch.int32).reshape(V, N, 16)[:, :, 11].cpu().numpy()
-    o_rgbc = (V * N * 64 + 255) // 256 * 256
+    gl = backend.geom_layout(dims)
+    rb = gl["record_bytes"]  # 32: x, y, conic a b c, opacity, extra, radius bits
+    g = geom[: V * N * rb].view(torch.float32).reshape(V, N, rb // 4).cpu().numpy()
+    bits = geom[: V * N * rb].view(torch.int32).reshape(V, N, rb // 4)[:, :, 7].cpu().numpy()
+    # depth: word 3 of the 16-byte footprint words, kept in memory only by the windowed binning chain
+    depth = None if gl["aux"] < 0 else geom[gl["aux"]: gl["aux"] + V * N * 16].view(torch.float32).reshape(V, N, 4)[:, :, 3].cpu().numpy()
+    o_rgbc = gl["rgbc"]
     rgbc = geom[o_rgbc: o_rgbc + V * N * 16].view(torch.float32).reshape(V, N, 4).cpu().numpy()
     cbits = geom[o_rgbc: o_rgbc + V * N * 16].view(torch.int32).reshape(V, N, 4)[:, :, 3].cpu().numpy()
     b = binb.cpu()
@@ -45,7 +49,7 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
     im = img.cpu()
     final_T = im[lay["final_T"]: lay["final_T"] + V * H * W * 4].view(torch.float32).reshape(V, H, W).numpy()
     n_contrib = im[lay["n_contrib"]: lay["n_contrib"] + V * H * W * 4].view(torch.int32).reshape(V, H, W).numpy()
-    return dict(geom=g, rgb=rgbc[:, :, :3], radius=bits & 0x0FFFFFFF, clamped=cbits & 7, ranges=ranges, point_list=plist, keys=keys,
+    return dict(geom=g, depth=depth, rgb=rgbc[:, :, :3], radius=bits & 0x0FFFFFFF, clamped=cbits & 7, ranges=ranges, point_list=plist, keys=keys,
                 final_T=final_T, n_contrib=n_contrib, num_pairs=num_pairs, overflow=int(st[8:12].view(torch.int32).item()),
                 max_list=int(st[12:16].view(torch.int32).item()), sgx=sgx, sgy=sgy, T=T)
 

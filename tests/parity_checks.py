@@ -57,8 +57,9 @@ def check_preprocess(res, cfg, v=0):
             "conic": (np.stack([hx[:, 2], hx[:, 3], hx[:, 4]], -1), geo["conic_opacity"][vis][:, :3]),
             "opacity": (hx[:, 5], geo["conic_opacity"][vis][:, 3]),
             "rgb": (ws["rgb"][v][vis], geo["rgb"][vis]),
-            "depth": (hx[:, 10], geo["depth"][vis]),
         }
+        if ws["depth"] is not None:  # (fused binning path: the depth goes from registers into the keys; check_tile_lists sees it there)
+            pairs["depth"] = (ws["depth"][v][vis], geo["depth"][vis])
         for k, (a, b) in pairs.items():
             m[k + "_rel"] = rel_l2(a, b)
             m[k + "_exact_frac"] = float((a == b).mean())

@@ -40,7 +40,7 @@ def test_workspace_sizes_and_validation():
     cfg = rasterizer.RasterConfig(1, 1, 1, 300000, 256, 256, 4, 25, 4, False)
     dims = be._dims(cfg, 2_000_000)
     g, b, i = be.workspace_sizes(dims)
-    assert g >= 300000 * 64 and i >= 2 * 256 * 256 * 4
+    assert g >= 300000 * (32 + 16) and i >= 2 * 256 * 256 * 4  # 32-byte records + 16-byte colours
     assert b >= 2_000_000 * 12  # 8-byte keys + 4-byte sorted indices per pair
     lay = be.workspace_layout(dims)
     assert lay["status"] == 0 and lay["keys"] % 256 == 0 and lay["point_list"] > lay["keys"]

@@ -63,6 +63,14 @@ def main():
             torch.cuda.synchronize()
             bb = min(bb, (time.perf_counter() - t0) / (K // 2))
         out += f" | fwd+bwd {bb * 1e6:7.2f} us  dmeans sum {plan['d_means'].double().abs().sum().item():.6e}"
+        if os.environ.get("EXP_PROFILE"):
+            fa, ba = {}, {}
+            for _ in range(20):
+                for k, v in be.run_forward(plan, vb, means, cov6, opac, shs, profile=True).items():
+                    fa[k] = fa.get(k, 0.0) + v / 20
+                for k, v in be.run_backward(plan, vb, means, cov6, opac, shs, None, g, profile=True).items():
+                    ba[k] = ba.get(k, 0.0) + v / 20
+            out += " | training stages us " + " ".join(f"{k}={1e3 * v:.1f}" for k, v in {**fa, **ba}.items())
     if os.environ.get("EXP_CFG4"):  # BASELINE configs[3] shape through the plan API: 131 072 Gaussians, 3 views, colour + depth, fwd + bwd
         from pf3plat_amd import _lib
         sc4 = synthetic.make_scene(50, 131072, (256, 256), num_views=3)
