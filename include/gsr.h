@@ -282,7 +282,7 @@ int gsr_backward_profile(const GsrDims* dims, const GsrView* views, const float*
                          float* stage_ms /* [GSR_BWD_STAGES] host */);
 
 /* Measurement aid: 1 when gsr_forward runs the colour pass inside the binning launch for these dims (two launches: binning +
- * colour, per-tile sort + blend), 0 when the colour pass is a launch of its own (images of more than ~2200 8x8 tiles, more than
+ * colour, per-tile sort + blend), 0 when the colour pass is a launch of its own (images of more than 4608 8x8 tiles, more than
  * four views per set, the windowed binning path), negative on bad dims. */
 int gsr_colour_in_binning(const GsrDims* dims);
 

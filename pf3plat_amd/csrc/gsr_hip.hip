@@ -1050,7 +1050,10 @@ __global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
 #define GSR_BIN_CB (GSR_BIN_CW + 1)
 #endif
 constexpr int kBinColorWaves = GSR_BIN_CW, kBinColorBufs = GSR_BIN_CB;  // unit buffers: one per colour wave + one for the staged pairs
-constexpr int kColorBinMaxTiles = 2200;  // images up to this many tiles take the colour pass inside the binning launch (measured range)
+#ifndef GSR_CIB_MAX_TILES
+#define GSR_CIB_MAX_TILES 4608
+#endif
+constexpr int kColorBinMaxTiles = GSR_CIB_MAX_TILES;  // (512 x 512 = 4096 tiles: 114.8 us with the colour pass inside, 118.8 as a launch of its own)  // images up to this many tiles take the colour pass inside the binning launch (measured range)
 constexpr int kBinStageBytes = (kBinThreads / 64 - kBinColorWaves) * 1024;  // kColor: 1 KB of record transpose per binning wave
 // dynamic LDS.  Plain: [0, 64 KB) record transpose per wave (4 KB each), later the pair staging; then the T tile counters.
 // kColor: [0, 11 KB) record transpose of the eleven binning waves (1 KB each), later the chunk's depth table; the T tile counters;
@@ -3200,7 +3203,10 @@ static bool color_in_bin_for(const GsrDims& d, const Grid& g, int dev) {
   const bool fused_bin = g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
   // tasks for its five colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
-  return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= 4 &&
+#ifndef GSR_CIB_MAX_VPS
+#define GSR_CIB_MAX_VPS 4
+#endif
+  return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= GSR_CIB_MAX_VPS &&
          ((g_color_bin_ok.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull) &&
          g.T <= kColorBinMaxTiles && bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
 }
@@ -3312,7 +3318,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   const bool do_color = !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH);
   p.color_units = (uint32_t)((N + 63) / 64);
   const unsigned color_blocks = do_color ? p.color_units * (unsigned)d.num_sets : 0u;
-  // One stream, two launches (images of up to ~2500 tiles, e.g. 400 x 400): the binning with the colour pass inside it (k_preprocess_bin<true, .>:
+  // One stream, two launches (images of up to 4608 tiles, e.g. 512 x 512): the binning with the colour pass inside it (k_preprocess_bin<true, .>:
   // five of its sixteen waves stream the harmonics while eleven project, count and list the pairs), then one launch per tile for its sort AND its
   // blend.  Larger images: the colour pass as its own first launch (k_color), then the binning chain, then the tile launch.
   // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers);
