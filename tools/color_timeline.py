@@ -34,3 +34,12 @@ print("binning workgroups: phase ends (us from first start):", [round((b[:, k].m
 c4 = c[:, 4]
 print("  reg-stage: loads issued after", q(c4 - c[:, 0]) if (c4 > 0).any() else "-")
 print("colour units: start", q(c[:, 0] - t0), "| issue", q(c[:, 1] - c[:, 0]), "| wait", q(c[:, 2] - c[:, 1]), "| eval", q(c[:, 3] - c[:, 2]), "| end", q(c[:, 3] - t0))
+# which binning workgroups are the slow ones: pairs listed per workgroup (row sums of the pair matrix) against the phase stamps
+T = 1024
+pm = plan["bin"][lay["counts"]: lay["counts"] + rows * (T + 8) * 8].view(torch.int32).reshape(rows, T + 8, 2)[:, :T, 1].sum(1).cpu().double()
+endt = b[:, 4] - t0
+p1 = b[:, 1] - t0
+cc = lambda x, y: round(torch.corrcoef(torch.stack([x, y]))[0, 1].item(), 3)
+print("pairs per workgroup", q(pm), "| corr(end, pairs)", cc(endt, pm), "corr(phase-1 end, pairs)", cc(p1, pm), "corr(end, row)", cc(endt, torch.arange(rows, dtype=torch.float64)))
+order = torch.argsort(endt, descending=True)[:6].tolist()
+print("slowest workgroups (row, pairs, phase-1 end, scan end, walk end, end):", [(r, int(pm[r]), round(p1[r].item(), 1), round((b[r, 2] - t0).item(), 1), round((b[r, 3] - t0).item(), 1), round(endt[r].item(), 1)) for r in order])
