@@ -44,6 +44,16 @@ def test_workspace_sizes_and_validation():
     assert b >= 2_000_000 * 12  # 8-byte keys + 4-byte sorted indices per pair
     lay = be.workspace_layout(dims)
     assert lay["status"] == 0 and lay["keys"] % 256 == 0 and lay["point_list"] > lay["keys"]
+    # geom: 32-byte records; the footprint words exist only for the windowed binning chain; sub-arrays on 2 MiB boundaries
+    gl = be.geom_layout(dims)
+    assert gl["record_bytes"] == 32 and gl["aux"] == -1 and gl["rows"] == -1
+    assert gl["rgbc"] >= 300000 * 32 and gl["rgbc"] % (2 << 20) == 0
+    wdims = be._dims(rasterizer.RasterConfig(1, 1, 1, 300000, 256, 256, 4, 25, 4, False,
+                                             _lib.FLAG_WINDOWED_BINNING | _lib.FLAG_BACKWARD_FOLLOWS), 2_000_000)
+    wl = be.geom_layout(wdims)
+    assert wl["aux"] >= 300000 * 32 and wl["rgbc"] >= wl["aux"] + 300000 * 16 and wl["rows"] >= wl["rgbc"] + 300000 * 16
+    assert all(wl[k] % (2 << 20) == 0 for k in ("aux", "rgbc", "rows"))
+    assert be.workspace_sizes(wdims)[0] >= wl["rows"] + 300000 * 48
     # bad arguments are rejected with an error code, never a crash
     bad = be._dims(cfg, 10)
     bad.abi_version = 99
