@@ -1053,7 +1053,9 @@ constexpr int kBinColorWaves = GSR_BIN_CW, kBinColorBufs = GSR_BIN_CB;  // unit 
 #ifndef GSR_CIB_MAX_TILES
 #define GSR_CIB_MAX_TILES 4608
 #endif
-constexpr int kColorBinMaxTiles = GSR_CIB_MAX_TILES;  // (512 x 512 = 4096 tiles: 114.8 us with the colour pass inside, 118.8 as a launch of its own)  // images up to this many tiles take the colour pass inside the binning launch (measured range)
+// images of up to this many tiles take the colour pass inside the binning launch (measured range: 512 x 512 = 4096 tiles take
+// 114.8 us that way, 118.8 with the colour pass as a launch of its own)
+constexpr int kColorBinMaxTiles = GSR_CIB_MAX_TILES;
 constexpr int kBinStageBytes = (kBinThreads / 64 - kBinColorWaves) * 1024;  // kColor: 1 KB of record transpose per binning wave
 // dynamic LDS.  Plain: [0, 64 KB) record transpose per wave (4 KB each), later the pair staging; then the T tile counters.
 // kColor: [0, 11 KB) record transpose of the eleven binning waves (1 KB each), later the chunk's depth table; the T tile counters;
