@@ -2225,17 +2225,20 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
 
 // ------------------------------------------------------------------------------------------------
 // B1: backward blend ([EXT] backward.cu renderCUDA; oracle blend_backward).  One workgroup of four wavefronts per 8x8 tile.
-// The reference replays the list back to front with T <- T/(1-alpha) and accum <- alpha c + (1-alpha) accum; in closed
-// form (proof in DESIGN.md 3.2), with w = alpha T and Bg = sum over DEEPER splats of w (c.g) + T_final bg.g:
-//     dL/dalpha = T (c.g) - Bg / (1 - alpha),          Bg <- Bg + w (c.g),          T <- T / (1 - alpha)
-// Both recurrences are linear in (T, Bg), so - exactly as in the forward kernel - the list is cut into batches of kBB
-// entries (walked back to front) and every batch into four SEGMENTS of 8 consecutive entries, one per wave:
+// The reference replays the list back to front with T <- T/(1-alpha) and accum <- alpha c + (1-alpha) accum.  With
+// Q = (accum . dL/dpixel) - the blended contribution of everything DEEPER than the splat, normalised by the transmittance
+// behind it; behind the last splat Q = bg . dL/dpixel - that is
+//     dL/dalpha = T (c.g - Q),          Q <- alpha (c.g) + (1 - alpha) Q,          T <- T / (1 - alpha)
+// Q's recurrence is linear in Q and T's a plain product, so - exactly as in the forward kernel - the list is cut into batches
+// of kBB entries (walked back to front) and every batch into four SEGMENTS of 8 consecutive entries, one per wave, and the only
+// division left is ONE reciprocal per segment (the product P of its (1 - alpha)); inside a segment T runs front to back by
+// products.  (Until late in round 2 the kernel carried Bg = T Q instead and paid a reciprocal of (1 - alpha) per entry.)
 //   stage E (batch it+1), lane = pixel: G = exp2(power) and alpha (both 0 unless the forward blended this splat at this
-//            pixel: not skipped and index < the pixel's last contributor), c.g and r = rcp(1-alpha) into REGISTERS, and
-//            the segment's own replay from (T, Bg) = (1, 0): the product R of its r's and its local sum B' -> LDS;
-//   stage A (batch it),   lane = pixel: every wave reads the four (R, B') pairs and forms (T, Bg) at the back end of
-//            its segment by the same chain as every other wave, then replays its 8 entries from there: w and
-//            q = G dL/dalpha go to a per-wave LDS tile (no barrier: written and read by the same wave);
+//            pixel: not skipped and index < the pixel's last contributor), c.g and 1 - alpha into REGISTERS, and the segment's
+//            own replay of Q from 0: (1 / P, P, q') -> LDS;
+//   stage A (batch it),   lane = pixel: every wave reads the four triples and forms T in front of its segment and Q at its
+//            back end by the same chain as every other wave, then runs its 8 entries - T front to back, Q back to front: w and
+//            G dL/dalpha go to a per-wave LDS tile (no barrier: written and read by the same wave);
 //   stage R (batch it),   lane = (entry 0..7, pixel row 0..7): per-splat gradients.  Each lane sums its row of 8 pixels
 //            in registers - only q, q dx, q dx^2 and w g need per-pixel work, dy is constant along a row - a 3-step DPP
 //            all-reduce over the 8 lanes of an entry finishes the sums, and two atomic instructions add 8 splats x 10
@@ -2283,7 +2286,7 @@ template <bool kExtra, bool kDet>
 __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   __shared__ __attribute__((aligned(16))) float sW[kBwdWaves][kBS][64];  // A -> R, per wave: blend weight w
   __shared__ __attribute__((aligned(16))) float sQ[kBwdWaves][kBS][64];  // A -> R, per wave: G dL/dalpha
-  __shared__ float sR[2][kBwdWaves][64], sB[2][kBwdWaves][64];           // E -> A: segment (R, B') of iteration it in [it & 1]
+  __shared__ float sR[2][kBwdWaves][64], sP[2][kBwdWaves][64], sB[2][kBwdWaves][64];  // E -> A: segment (1/P, P, q') of iteration it in [it & 1]
   __shared__ float4 sGeo[4][kBB];   // x, y, a2, b2
   __shared__ float4 sGeo2[4][kBB];  // c2, opacity, id bits, 0
   __shared__ float4 sCol[4][kBB];   // r, g, b, extra
@@ -2362,7 +2365,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     return (ln < kBB && idx < nmax) ? plist[idx] : 0u;
   };
 
-  float al[kBS], Gc[kBS], cgv[kBS], rr[kBS];  // this wave's segment of the batch about to be replayed
+  float al[kBS], Gc[kBS], cgv[kBS], om[kBS];  // this wave's segment of the batch about to be replayed (om = 1 - alpha)
   const int e0 = wave * kBS;
   auto eval = [&](uint32_t it) {  // stage E
     const int ring = it & 3;
@@ -2384,26 +2387,29 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       cg = __builtin_fmaf(c.z, g2, cg);
       if (kExtra) cg = __builtin_fmaf(c.w, ge, cg);
       cgv[u] = cg;
-      rr[u] = __builtin_amdgcn_rcpf(1.f - al[u]);
+      om[u] = 1.f - al[u];
     }
-    float Tl = 1.f, Bl = 0.f;  // the segment's replay from (1, 0), back to front
+    float Pl = 1.f, ql = 0.f;  // the segment's own product of (1 - alpha) and its replay of Q from 0, back to front
 #pragma unroll
     for (int u = kBS - 1; u >= 0; --u) {
-      Tl *= rr[u];
-      Bl = __builtin_fmaf(al[u] * Tl, cgv[u], Bl);
+      Pl *= om[u];
+      ql = __builtin_fmaf(om[u], ql, al[u] * cgv[u]);
     }
-    sR[it & 1][wave][lane] = Tl;
-    sB[it & 1][wave][lane] = Bl;
+    sR[it & 1][wave][lane] = __builtin_amdgcn_rcpf(Pl);  // the one division of the segment
+    sP[it & 1][wave][lane] = Pl;
+    sB[it & 1][wave][lane] = ql;
   };
-  auto replay = [&](float T, float B) {  // stage A: (T, B) at the back end of this wave's segment
+  auto replay = [&](float T, float q) {  // stage A: T in FRONT of this wave's segment, Q at its back end
 #pragma unroll
-    for (int u = kBS - 1; u >= 0; --u) {
-      T *= rr[u];  // transmittance in front of the splat
-      const float w = al[u] * T;
-      const float d = __builtin_fmaf(T, cgv[u], -(B * rr[u]));
-      B = __builtin_fmaf(w, cgv[u], B);
-      sW[wave][u][lane] = w;
-      sQ[wave][u][lane] = Gc[u] * d;
+    for (int u = 0; u < kBS; ++u) {  // front to back: the transmittance in front of every splat, by products only
+      sW[wave][u][lane] = al[u] * T;
+      Gc[u] *= T;
+      T *= om[u];
+    }
+#pragma unroll
+    for (int u = kBS - 1; u >= 0; --u) {  // back to front: Q, and G dL/dalpha = G T (c.g - Q)
+      sQ[wave][u][lane] = Gc[u] * (cgv[u] - q);
+      q = __builtin_fmaf(om[u], q, al[u] * cgv[u]);
     }
   };
   auto reduce = [&](uint32_t it) {  // stage R: entry e0 + er of iteration it, pixel row pr
@@ -2486,21 +2492,26 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   eval(0);
   __syncthreads();
   const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
-  float Tb = T_final;                                                         // (T, Bg) at the back end of the batch:
-  float Bb = T_final * (cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2);  // the same in all four waves
+  float Tb = T_final;                                              // (T, Q) at the back end of the batch: the same in all four
+  float Qb = cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2;    // waves (behind the last splat Q = Bg / T_final = bg.g)
   for (uint32_t it = 0; it < nbat; ++it) {
-    const float R0 = sR[it & 1][0][lane], R1 = sR[it & 1][1][lane], R2 = sR[it & 1][2][lane], R3 = sR[it & 1][3][lane];
-    const float B0 = sB[it & 1][0][lane], B1 = sB[it & 1][1][lane], B2 = sB[it & 1][2][lane], B3 = sB[it & 1][3][lane];
     const bool do_stage = (wave == (int)((it + 2) & 3)) && (it + 2 < nbat);
     if (do_stage) stage(it + 2, sg, sg2, sc, id_next);  // global gather in flight
     if (wave == (int)((it + 3) & 3)) id_next = load_ids(it + 3);
-    // back to front: wave 3's segment is the deepest.  The same chain in every wave.
-    const float t3 = Tb, b3 = Bb;
-    const float t2 = t3 * R3, b2 = __builtin_fmaf(t3, B3, b3);
-    const float t1 = t2 * R2, b1 = __builtin_fmaf(t2, B2, b2);
-    const float t0 = t1 * R1, b0 = __builtin_fmaf(t1, B1, b1);
-    Tb = t0 * R0; Bb = __builtin_fmaf(t0, B0, b0);
-    replay(wave == 3 ? t3 : wave == 2 ? t2 : wave == 1 ? t1 : t0, wave == 3 ? b3 : wave == 2 ? b2 : wave == 1 ? b1 : b0);
+    // back to front: wave 3's segment is the deepest.  The same chain in every wave: (t, q) = transmittance and Q at the BACK end
+    // of segment k; the front of segment k is the back of segment k - 1.  One segment's three values at a time (register budget).
+    float t = Tb, q = Qb, Tf = 0.f, Qk = 0.f;
+#pragma unroll
+    for (int k = kBwdWaves - 1; k >= 0; --k) {
+      const float Rk = sR[it & 1][k][lane], Pk = sP[it & 1][k][lane], Bk = sB[it & 1][k][lane];
+      Qk = wave == k ? q : Qk;
+      t *= Rk;
+      Tf = wave == k ? t : Tf;
+      q = __builtin_fmaf(Pk, q, Bk);
+      asm volatile("" ::: "memory");
+    }
+    Tb = t; Qb = q;
+    replay(Tf, Qk);
     reduce(it);
     if (it + 1 < nbat) eval(it + 1);
     if (do_stage && lane < kBB) {
