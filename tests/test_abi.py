@@ -153,3 +153,46 @@ def test_capacity_for_is_host_arithmetic():
     assert lib.gsr_cov_from_scale_rot(0, None, None, ctypes.c_float(1.0), None, None) == 0
     assert lib.gsr_cov_from_scale_rot(4, None, None, ctypes.c_float(1.0), None, None) == -1
     assert lib.gsr_cov_from_scale_rot_backward(4, None, None, ctypes.c_float(1.0), None, None, None, None) == -1
+
+
+def test_geom_sub_arrays_never_overlap_and_fit_the_reported_size():
+    """Host-side layout arithmetic over random shapes and flags: records, (windowed) footprint words, colours, (announced
+    backward) accumulator rows and saved Jacobians follow each other without overlap inside gsr_workspace_sizes' geom bytes."""
+    import numpy as np
+
+    be = rasterizer.HipBackend()
+    rng = np.random.default_rng(11)
+    for _ in range(200):
+        sets = int(rng.integers(1, 4))
+        vps = int(rng.integers(1, 5))
+        v = sets * vps
+        n = int(rng.choice([1, 63, 1000, 131072, 300000, 1_000_000]))
+        h, w = int(rng.integers(1, 1200)), int(rng.integers(1, 1200))
+        k = int(rng.choice([0, 1, 4, 9, 16, 25]))
+        flags = 0
+        if rng.random() < 0.3:
+            flags |= _lib.FLAG_WINDOWED_BINNING
+        if rng.random() < 0.5:
+            flags |= _lib.FLAG_BACKWARD_FOLLOWS
+        deg = {0: 0, 1: 0, 4: 1, 9: 2, 16: 3, 25: 4}[k]
+        cfg = rasterizer.RasterConfig(v, sets, vps, n, h, w, deg, k, 4, False, flags)
+        dims = be._dims(cfg, 4 * n + 1024)
+        g = be.workspace_sizes(dims)[0]
+        gl = be.geom_layout(dims)
+        t8 = 4 * ((w + 15) // 16) * ((h + 15) // 16)
+        windowed = bool(flags & _lib.FLAG_WINDOWED_BINNING) or t8 > 8192
+        assert gl["record_bytes"] == 32
+        end = v * n * 32
+        if windowed:
+            assert gl["aux"] >= end
+            end = gl["aux"] + v * n * 16
+        else:
+            assert gl["aux"] == -1
+        assert gl["rgbc"] >= end
+        end = gl["rgbc"] + v * n * 16
+        if flags & _lib.FLAG_BACKWARD_FOLLOWS:
+            assert gl["rows"] >= end
+            end = gl["rows"] + v * n * 48 + (v * n * 48 if k > 0 else 0)  # rows, then d rgb / d direction
+        else:
+            assert gl["rows"] == -1
+        assert g >= end, (cfg, g, end, gl)
