@@ -41,7 +41,7 @@ extern "C" {
 #define GSR_ERR_INVALID_ARGUMENT (-1)
 #define GSR_ERR_LAUNCH (-2)
 #define GSR_ERR_UNSUPPORTED (-3)
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 /* GsrDims.flags input-layout bits: the arrays PF3plat's `Gaussians` record carries (src/model/types.py:7-18) can be passed
  * as they are, with no re-layout copy (the reference wrapper makes two per call: cuda_splatting.py:75 and :115,123). */
 #define GSR_FLAG_SH_PLANAR 0x4  /* colors are (num_sets, N, 3, M) "harmonics" instead of (num_sets, N, M, 3); grads likewise */

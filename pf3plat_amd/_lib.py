@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "gsr_hip.hip")
 HEADER = os.path.join(REPO_ROOT, "include", "gsr.h")
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")  # (override: tools/ablate.py's measurement build)
-GSR_ABI_VERSION = 1
+GSR_ABI_VERSION = 2  # bump with include/gsr.h whenever a struct, a workspace layout or a signature changes
 SCREEN_GRAD_FLOATS = 12
 FLAG_PREFILTERED = 0x1  # accepted and ignored, as upstream with prefiltered = False
 FLAG_DEBUG = 0x2  # upstream's `debug`: synchronise + check after every stage

@@ -3194,7 +3194,7 @@ extern "C" {
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 const char* gsr_build_info(void) {
-  return "gsr_hip gfx950 wave64 tile8x8 binning+colour tile-sort+segment-blend single-stream abi1";
+  return "gsr_hip gfx950 wave64 tile8x8 binning+colour tile-sort+segment-blend single-stream abi2";
 }
 
 int gsr_last_failed_stage(void) { return g_failed_stage; }

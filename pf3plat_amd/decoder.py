@@ -86,6 +86,7 @@ class DecoderSplattingCUDA(Decoder):
         result = render_depth_cuda(
             extrinsics.reshape(b * v, 4, 4), intrinsics.reshape(b * v, 3, 3), near.reshape(b * v), far.reshape(b * v),
             image_shape, gaussians.means, gaussians.covariances, gaussians.opacities, mode=mode,
+            gaussian_scales=gaussians.scales, gaussian_rotations=gaussians.rotations, frames=gaussians.frames,
         )
         h, w = image_shape
         return result.reshape(b, v, h, w)

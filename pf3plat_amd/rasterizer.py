@@ -128,6 +128,7 @@ class HipBackend:
         return g.value, b.value, i.value
 
     def cov_from_scale_rot(self, scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
+        self._check_device(scales, rotations)
         n = scales.shape[0]
         out = torch.empty((n, 6), dtype=torch.float32, device=scales.device)
         stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
@@ -470,14 +471,6 @@ def get_backend():
     return _BACKEND
 
 
-def set_backend(backend):
-    """Install another backend object (same forward/backward/mark_visible methods).  Test hook only:
-    tests/ use it to drive the host-side wrappers on CPU tensors; the product never calls it."""
-    global _BACKEND
-    old, _BACKEND = _BACKEND, backend
-    return old
-
-
 # --------------------------------------------------------------------------------------------------
 # autograd
 # --------------------------------------------------------------------------------------------------
@@ -637,8 +630,6 @@ class _CovFromScaleRot(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, scales: Tensor, rotations: Tensor, scale_modifier: float, backend):
-        if not (scales.is_cuda and rotations.is_cuda):
-            raise RuntimeError("pf3plat_amd rasterizer: tensors must be on a ROCm device (there is no CPU fallback path)")
         scales, rotations = scales.contiguous().float(), rotations.contiguous().float()
         ctx.save_for_backward(scales, rotations)
         ctx.mod, ctx.backend = float(scale_modifier), backend
@@ -652,21 +643,7 @@ class _CovFromScaleRot(torch.autograd.Function):
 
 
 def _cov3d_from_scale_rotation(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
-    backend = get_backend()
-    if hasattr(backend, "cov_from_scale_rot"):
-        return _CovFromScaleRot.apply(scales, rotations, scale_modifier, backend)
-    return _cov3d_from_scale_rotation_torch(scales, rotations, scale_modifier)
-
-
-def _cov3d_from_scale_rotation_torch(scales: Tensor, rotations: Tensor, scale_modifier: float) -> Tensor:
-    """The same arithmetic as differentiable torch ops (used by the CPU-side tests, which drive the wrappers with the oracle)."""
-    r, x, y, z = rotations.unbind(-1)
-    rm = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                      2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                      2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)), -1).reshape(-1, 3, 3)
-    sc = scales * scale_modifier
-    sigma = rm @ torch.diag_embed(sc * sc) @ rm.transpose(-1, -2)
-    return torch.stack((sigma[:, 0, 0], sigma[:, 0, 1], sigma[:, 0, 2], sigma[:, 1, 1], sigma[:, 1, 2], sigma[:, 2, 2]), -1)
+    return _CovFromScaleRot.apply(scales, rotations, scale_modifier, get_backend())
 
 
 class GaussianRasterizer(nn.Module):

@@ -1,13 +1,30 @@
 """Rotation of spherical-harmonics coefficients: `rotate_sh(sh_coefficients, rotations)` with the
-signature of the reference's src/misc/sh_rotation.py:10-36 - coefficients expressed in a local frame come back expressed in
-the frame `rotations` maps to (the encoder uses it with the camera-to-world rotation of a Gaussian's source view).
+signature of the reference's src/misc/sh_rotation.py:10-36 (the encoder's adapter calls it with the camera-to-world rotation
+of a Gaussian's source view, gaussian_adapter.py:90-92).
 
-The reference builds its per-band rotation matrices from e3nn's Wigner-D functions, in e3nn's harmonic basis; e3nn is not
-available here, so that exact convention could not be compared.  This implementation works in the basis
-the rasterizer EVALUATES (the polynomial real harmonics of csrc/gsr_hip.hip `sh_visit` / oracle `sh_basis`, signs included):
-for every band l the (2l+1) x (2l+1) matrix D_l(R) with  sum_k (D_l c)_k Y_k(d) = sum_k c_k Y_k(R^T d)  for all directions d
-is obtained exactly (to rounding) by matching both sides on a fixed set of well-spread directions.  Rendering a rotated
-scene with rotated coefficients then gives the image of the unrotated one (tests/test_sh_rotation.py)."""
+Two conventions, selected by `basis`:
+
+* ``"e3nn"`` (default - what the REFERENCE computes).  The reference multiplies band l by e3nn's
+  `wigner_D(l, *matrix_to_angles(R))`, the representation matrix in E3NN's real harmonic basis, although the rasterizer then
+  evaluates the coefficients in ITS basis (the reference's own ply_export.py:75-77 calls the axes "swizzled").  Weights trained
+  with the reference therefore only reproduce the reference's colours if that same matrix is applied.  e3nn is not installed
+  here, so the matrix is rebuilt from e3nn's published conventions instead of imported:
+    - e3nn's real harmonics Y_e are the standard real harmonics W WITHOUT Condon-Shortley phase (all leading coefficients
+      positive: `sh_1 = (x, y, z)`, `sh_2_0 = sqrt(15) x z`, ..., `sh_2_4 = sqrt(15)/2 (z^2 - x^2)`) with the y axis as polar
+      axis:  Y_e(x, y, z) = W(z, x, y)  (component order m = -l..l);
+    - `D(R) Y_e(d) = Y_e(R d)` is the matrix `wigner_D(l, *matrix_to_angles(R))` (e3nn's equivariance statement).
+  The rasterizer's basis B (csrc/gsr_hip.hip `sh_visit`) is W WITH the phase: B_lm = (-1)^m W_lm.  Hence, with the permutation
+  P: (x, y, z) -> (z, x, y) and S = diag((-1)^m):   D_e3nn(R) = S D_B(P R P^T) S,   D_B being the exact representation matrix in
+  the rasterizer's basis that the "rasterizer" mode builds.  **Unpinned**: no e3nn output could be recorded in this container;
+  tests/test_sh_rotation.py checks the consequences that can be checked without it (band 1 equals R itself in (x, y, z) order as
+  e3nn documents for its l = 1 irrep, the equivariance identity against e3nn's generated polynomial forms for l <= 3, the group
+  law, orthogonality).
+* ``"rasterizer"``: rotation in the basis the rasterizer evaluates, i.e. the physically consistent one: rendering a rotated
+  scene with coefficients rotated this way gives the image of the unrotated scene (tests/test_sh_rotation.py).  Use it for
+  scenes that were NOT trained through the reference's adapter (external .ply files, synthetic data).
+
+For every band l the (2l+1) x (2l+1) matrix D_B(R) with  D_B(R) B(d) = B(R d)  for all directions d is obtained exactly (to
+rounding) by matching both sides on a fixed set of well-spread directions."""
 from __future__ import annotations
 
 from functools import lru_cache
@@ -67,14 +84,42 @@ def band_rotations(rotations: Tensor, degree: int) -> list:
     return [pinv[l].to(rot.device) @ basis[..., l * l:(l + 1) * (l + 1)] for l in range(degree + 1)]
 
 
-def rotate_sh(sh_coefficients: Tensor, rotations: Tensor) -> Tensor:
-    """sh_coefficients (*#batch, n), n = (degree + 1)^2 <= 25; rotations (*#batch, 3, 3) -> (*batch, n)."""
+_P_E3NN = ((0.0, 0.0, 1.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0))  # (x, y, z) -> (z, x, y): e3nn's polar axis is y
+
+
+def _phase_signs(l: int, device) -> Tensor:
+    """(-1)^m for m = -l..l: the Condon-Shortley phase the rasterizer's basis carries and e3nn's does not."""
+    m = torch.arange(-l, l + 1, device=device)
+    return 1.0 - 2.0 * (m % 2).to(torch.float64)
+
+
+def e3nn_band_rotations(rotations: Tensor, degree: int) -> list:
+    """(..., 3, 3) -> [ (..., 2l+1, 2l+1) ]: what e3nn's `wigner_D(l, *matrix_to_angles(R))` returns (module docstring)."""
+    p = torch.tensor(_P_E3NN, dtype=torch.float64, device=rotations.device)
+    mats = band_rotations(p @ rotations.to(torch.float64) @ p.T, degree)
+    out = []
+    for l, m in enumerate(mats):
+        sg = _phase_signs(l, rotations.device)
+        out.append(sg[:, None] * m * sg[None, :])
+    return out
+
+
+def rotate_sh(sh_coefficients: Tensor, rotations: Tensor, basis: str = "e3nn") -> Tensor:
+    """sh_coefficients (*#batch, n), n = (degree + 1)^2 <= 25; rotations (*#batch, 3, 3) -> (*batch, n).
+    basis: "e3nn" = the matrices the reference applies (src/misc/sh_rotation.py:24-34), "rasterizer" = the rotation in the basis
+    the rasterizer evaluates (see the module docstring)."""
     n = sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
     if (degree + 1) ** 2 != n or degree > 4:
         raise ValueError(f"{n} coefficients: expected (degree + 1)^2 with degree <= 4")
+    if basis not in ("e3nn", "rasterizer"):
+        raise ValueError(f"basis must be 'e3nn' or 'rasterizer', got {basis!r}")
     if not torch.allclose(torch.det(rotations), rotations.new_tensor(1)):  # (the reference falls back to no rotation, :21-22)
         return sh_coefficients.broadcast_to((*torch.broadcast_shapes(sh_coefficients.shape[:-1], rotations.shape[:-2]), n))
-    mats = band_rotations(rotations, degree)
+    mats = e3nn_band_rotations(rotations, degree) if basis == "e3nn" else band_rotations(rotations, degree)
     out = [(mats[l].to(sh_coefficients.dtype) @ sh_coefficients[..., l * l:(l + 1) * (l + 1), None]).squeeze(-1) for l in range(degree + 1)]
     return torch.cat(out, dim=-1)
+
+
+def rotate_sh_rasterizer_basis(sh_coefficients: Tensor, rotations: Tensor) -> Tensor:
+    return rotate_sh(sh_coefficients, rotations, basis="rasterizer")

@@ -32,6 +32,31 @@ def _viewbuf(extrinsics, intrinsics, near, far, background_color, scale_invarian
     return views_from_cameras(extrinsics, intrinsics, near, far, background_color, scale_invariant, pose_gradients)
 
 
+def depth_fake_color(extrinsics: Tensor, near: Tensor, far: Tensor, gaussian_means: Tensor, mode: DepthRenderingMode) -> Tensor:
+    """The scalar the reference's depth render blends, as differentiable torch ops (cuda_splatting.py:238-251,
+    conversions.py:17-27): camera-space z of every mean in UN-normalised units, mapped by `mode`.  extrinsics (V, 4, 4),
+    near / far (V,), gaussian_means (S, G, 3) with V = S x views_per_set (set-major) -> (V, G).  The kernels evaluate the same
+    f(z) themselves (GSR_FLAG_EXTRA_MODE); this torch form is used when `extrinsics` requires grad, because the reference's
+    graph sends a gradient to the camera through `extrinsics.inverse()` here - the one place a camera gets any."""
+    v, s = extrinsics.shape[0], gaussian_means.shape[0]
+    row = extrinsics.inverse()[:, 2, :]  # world -> camera z
+    m = gaussian_means if v == s else gaussian_means.repeat_interleave(v // s, dim=0)
+    z = (m * row[:, None, :3]).sum(-1) + row[:, None, 3]
+    if mode == "disparity":
+        return 1 / z
+    if mode == "relative_disparity":
+        eps = 1e-10
+        disp_near, disp_far = 1 / (near[:, None] + eps), 1 / (far[:, None] + eps)
+        return 1 - (1 / (z + eps) - disp_far) / (disp_near - disp_far + eps)
+    if mode == "log":  # (the reference's min(near).max(far) is the constant log(far): kept)
+        return z.minimum(near[:, None]).maximum(far[:, None]).log()
+    return z
+
+
+def _camera_wants_depth_gradient(extrinsics: Tensor) -> bool:
+    return torch.is_grad_enabled() and extrinsics.requires_grad
+
+
 def render_cuda(
     extrinsics: Tensor,  # (batch, 4, 4) camera-to-world
     intrinsics: Tensor,  # (batch, 3, 3) normalised
@@ -104,13 +129,18 @@ def render_depth_cuda(
     gaussian_opacities: Tensor,
     scale_invariant: bool = True,
     mode: DepthRenderingMode = "depth",
+    gaussian_scales: Optional[Tensor] = None,  # } instead of gaussian_covariances (pass None there): the adapter's
+    gaussian_rotations: Optional[Tensor] = None,  # } scale + quaternion (x, y, z, w) form, covariance built in the kernels
+    frames: Optional[Tensor] = None,
 ) -> Tensor:  # (batch, height, width)
     """Depth image = sum_i f(z_i) alpha_i T_i (reference :226-269).  The reference renders f(z) as a
     3-channel precomputed colour and averages the channels; the three channels are identical, so it
-    is blended here once, as the extra channel of a colour-less pass, with f(z) (`depth_fake_color`
-    below states it in torch) evaluated inside the kernels.  Gaussians receive the same gradients as in
-    the reference; the (unused) gradient the reference's torch graph sends to `extrinsics` through
-    `extrinsics.inverse()` is not produced.
+    is blended here once, as the extra channel of a colour-less pass, with f(z) evaluated inside the
+    kernels.  Gaussians receive the same gradients as in the reference.  When `extrinsics` requires grad
+    the reference's torch graph also sends a gradient to the camera through `extrinsics.inverse()`
+    (:239-242; in training the extrinsics come from the encoder, model_wrapper.py:148-150): f(z) is then
+    formed by `depth_fake_color` in torch and blended as an explicit extra channel, so that autograd
+    carries exactly that gradient (means and camera); otherwise no torch op touches the Gaussians.
 
     `gaussian_*` may hold ONE copy of the Gaussians per scene while the cameras hold `views_per_scene` views per scene
     (batch = scenes x views_per_scene, scene-major): the views of a scene then share that copy, as in `render_views`."""
@@ -122,9 +152,18 @@ def render_depth_cuda(
     viewbuf = _viewbuf(extrinsics, intrinsics, near, far, torch.zeros(3, dtype=torch.float32, device=dev), scale_invariant)
     # no colour is wanted: one shared zero colour row per set costs nothing to blend next to the depth channel
     zero_rgb = torch.zeros((1, 1, 3), dtype=torch.float32, device=dev).expand(sets, g, 3)
+    if _camera_wants_depth_gradient(extrinsics):
+        channel = dict(extra=depth_fake_color(extrinsics, near, far, gaussian_means, mode))
+    else:
+        channel = dict(extra_mode=mode)
+    if gaussian_covariances is None:
+        cov = dict(scale_rot=True, frames=frames)
+        gaussian_covariances = torch.cat((gaussian_scales, gaussian_rotations), dim=-1)
+    else:
+        cov = dict(cov_3x3=True)
     _, depth, _ = rasterize_views(
         gaussian_means, gaussian_covariances, gaussian_opacities, zero_rgb, viewbuf,
-        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=b // max(sets, 1), extra_mode=mode, cov_3x3=True)
+        image_shape=image_shape, sh_degree=0, use_sh=False, views_per_set=b // max(sets, 1), **channel, **cov)
     return depth
 
 
@@ -156,16 +195,21 @@ def render_views(
     _, _, _, n = gaussian_sh_coefficients.shape
     degree = isqrt(n) - 1
     viewbuf = _viewbuf(ext, intr, nr, fr, background_color.reshape(3), scale_invariant, pose_gradients)
+    # the depth channel: f(z) inside the kernels - unless the camera requires grad and the caller did not ask for the full pose
+    # gradient: then the reference's own graph (depth -> extrinsics.inverse(), cuda_splatting.py:239-242) is reproduced in torch
+    if depth_mode is not None and not pose_gradients and _camera_wants_depth_gradient(extrinsics):
+        channel = dict(extra=depth_fake_color(ext, nr, fr, gaussian_means, depth_mode))
+    else:
+        channel = dict(extra_mode=depth_mode)
     if gaussian_covariances is None:  # scale + quaternion records, as the encoder's adapter emits them
         records = torch.cat((gaussian_scales, gaussian_rotations), dim=-1)
         color, depth, _ = rasterize_views(
             gaussian_means, records, gaussian_opacities, gaussian_sh_coefficients, viewbuf, image_shape=image_shape,
-            sh_degree=degree, use_sh=True, views_per_set=v, extra_mode=depth_mode, sh_planar=True, scale_rot=True, frames=frames)
+            sh_degree=degree, use_sh=True, views_per_set=v, sh_planar=True, scale_rot=True, frames=frames, **channel)
     else:
         color, depth, _ = rasterize_views(
             gaussian_means, gaussian_covariances, gaussian_opacities, gaussian_sh_coefficients, viewbuf,
-            image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, extra_mode=depth_mode, sh_planar=True,
-            cov_3x3=True)
+            image_shape=image_shape, sh_degree=degree, use_sh=True, views_per_set=v, sh_planar=True, cov_3x3=True, **channel)
     h, w = image_shape
     color = color.reshape(s, v, 3, h, w)
     if depth is not None:

@@ -23,6 +23,12 @@ class Gaussians:
     rotations: Optional[Tensor] = None  # (scene, gaussian, 4) quaternions x, y, z, w
     frames: Optional[Tensor] = None  # (scene, F, 3, 3) world rotation of each of the F equal consecutive groups of Gaussians
 
+    def clone(self) -> "Gaussians":
+        """A deep copy (reference src/model/types.py:12-18), the optional fields included when present."""
+        c = lambda t: None if t is None else t.clone()
+        return Gaussians(means=self.means.clone(), covariances=c(self.covariances), harmonics=self.harmonics.clone(),
+                         opacities=self.opacities.clone(), scales=c(self.scales), rotations=c(self.rotations), frames=c(self.frames))
+
 
 @dataclass
 class DecoderOutput:

@@ -22,13 +22,13 @@ def oracle_lib():
 @pytest.fixture()
 def oracle_backend():
     """Install the oracle-backed test backend behind pf3plat_amd's wrappers (CPU tensors)."""
-    from pf3plat_amd import rasterizer
     from tests.oracle_backend import OracleBackend
+    from tests.util import install_backend
 
     be = OracleBackend()
-    old = rasterizer.set_backend(be)
+    old = install_backend(be)
     yield be
-    rasterizer.set_backend(old)
+    install_backend(old)
 
 
 def pytest_terminal_summary(terminalreporter, exitstatus, config):

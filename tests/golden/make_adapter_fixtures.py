@@ -76,6 +76,28 @@ def main():
     for k in ("means", "covariances", "scales", "rotations", "harmonics", "opacities"):
         out["B_out_" + k] = getattr(res, k).numpy()
     out["B_sh_mask"] = adapter.sh_mask.numpy()
+    # case C: the ENCODER's call shapes (encoder_costvolume.py:529-540): cameras (b, v, 1, 1, 1, ., .), coordinates (b, v, r, srf, 1, 2),
+    # depths (b, v, r, 1, 1), opacities (b, v, r, srf, spp), raw (b, v, r, srf, 1, c); 3 source views, 6 x 8 rays, 2 surfaces, 2 samples
+    b, v, h, w, srf, spp = 1, 3, 6, 8, 2, 2
+    r = h * w
+    ang = torch.tensor([0.25, -0.1, -0.35])
+    ext = torch.eye(4).repeat(b, v, 1, 1)
+    ext[0, :, 0, 0] = torch.cos(ang); ext[0, :, 0, 2] = torch.sin(ang)
+    ext[0, :, 2, 0] = -torch.sin(ang); ext[0, :, 2, 2] = torch.cos(ang)
+    ext[0, :, :3, 3] = torch.tensor([[-0.5, 0.1, 0.0], [0.0, 0.0, 0.1], [0.4, -0.05, 0.2]])
+    intr = torch.eye(3).repeat(b, v, 1, 1)
+    intr[..., 0, 0], intr[..., 1, 1], intr[..., 0, 2], intr[..., 1, 2] = 0.8, 0.95, 0.5, 0.5
+    ys, xs = torch.meshgrid((torch.arange(h) + 0.5) / h, (torch.arange(w) + 0.5) / w, indexing="ij")
+    coords = (torch.stack((xs, ys), -1).reshape(1, 1, r, 1, 1, 2) + 0.01 * torch.randn((b, v, r, srf, 1, 2), generator=g)).contiguous()
+    depths = torch.rand((b, v, r, 1, 1), generator=g) * 9 + 1
+    opac = torch.rand((b, v, r, srf, spp), generator=g)
+    raw = torch.randn((b, v, r, srf, 1, 7 + 3 * d_sh), generator=g)
+    res = adapter.forward(ext[:, :, None, None, None], intr[:, :, None, None, None], coords, depths, opac, raw, (h, w))
+    for k, t in dict(ext=ext, intr=intr, coords=coords, depths=depths, opac=opac, raw=raw).items():
+        out["C_in_" + k] = t.numpy()
+    out["C_hw"] = np.array([h, w])
+    for k in ("means", "covariances", "scales", "rotations", "harmonics", "opacities"):
+        out["C_out_" + k] = getattr(res, k).numpy()
     np.savez_compressed(OUT, **out)
     print({k: v.shape for k, v in out.items()})
 

@@ -183,6 +183,25 @@ class OracleBackend:
                                                        self._np(far), self._np(background), float(fov_degrees))
         return torch.from_numpy(rec), {k: torch.from_numpy(np.asarray(v)) for k, v in moved.items()}
 
+    # ---- upstream's scales= / rotations= call form ([EXT] computeCov3D; quaternions r, x, y, z, not normalised), torch CPU ops
+    @staticmethod
+    def _cov6(scales, rotations, scale_modifier):
+        r, x, y, z = rotations.unbind(-1)
+        rm = torch.stack((1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                          2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                          2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)), -1).reshape(-1, 3, 3)
+        sc = scales * scale_modifier
+        sigma = rm @ torch.diag_embed(sc * sc) @ rm.transpose(-1, -2)
+        return torch.stack((sigma[:, 0, 0], sigma[:, 0, 1], sigma[:, 0, 2], sigma[:, 1, 1], sigma[:, 1, 2], sigma[:, 2, 2]), -1)
+
+    def cov_from_scale_rot(self, scales, rotations, scale_modifier):
+        return self._cov6(scales.detach(), rotations.detach(), scale_modifier)
+
+    def cov_from_scale_rot_backward(self, scales, rotations, scale_modifier, d_cov6):
+        with torch.enable_grad():
+            s, r = scales.detach().requires_grad_(True), rotations.detach().requires_grad_(True)
+            return torch.autograd.grad(self._cov6(s, r, scale_modifier), (s, r), d_cov6)
+
     def mark_visible(self, cfg, viewbuf, means):
         out = torch.zeros((cfg.num_sets, cfg.num_gaussians), dtype=torch.bool)
         for s in range(cfg.num_sets):

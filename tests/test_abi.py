@@ -8,6 +8,7 @@ import pytest
 import torch
 
 from pf3plat_amd import _lib, rasterizer
+from tests.util import install_backend
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -100,7 +101,7 @@ def test_no_cpu_fallback_path():
     import pf3plat_amd
     from pf3plat_amd import synthetic
 
-    old = rasterizer.set_backend(None)  # make sure the real backend is what gets constructed
+    old = install_backend(None)  # make sure the real backend is what gets constructed
     try:
         sc = synthetic.make_scene(1, 32, (16, 16))
         g = sc.gaussians
@@ -109,7 +110,7 @@ def test_no_cpu_fallback_path():
                                     g.means, g.covariances, g.harmonics, g.opacities)
         assert isinstance(rasterizer.get_backend(), rasterizer.HipBackend)
     finally:
-        rasterizer.set_backend(old)
+        install_backend(old)
     import sys
 
     src = "".join(open(os.path.join(ROOT, "pf3plat_amd", f)).read() for f in os.listdir(os.path.join(ROOT, "pf3plat_amd")) if f.endswith(".py"))

@@ -17,7 +17,7 @@ from oracle import adapter as oracle_adapter
 from pf3plat_amd import synthetic
 from pf3plat_amd.adapter import GaussianAdapter, GaussianAdapterCfg
 from pf3plat_amd.types import Gaussians
-from tests.util import rel_l2
+from tests.util import install_backend, rel_l2
 
 FIX = np.load(os.path.join(os.path.dirname(__file__), "golden", "adapter_fixtures.npz"))
 t = lambda k: torch.tensor(FIX[k])
@@ -67,6 +67,33 @@ def test_adapter_matches_reference_gaussian_adapter():
     assert not torch.allclose(rot.harmonics[..., 1:], out.harmonics[..., 1:].detach(), atol=1e-3)
 
 
+def test_adapter_accepts_the_encoders_call_shapes():
+    """The reference encoder calls the adapter with extra batch dims behind the view axis (encoder_costvolume.py:529-540: cameras
+    'b v () () () i j', depths 'b v r 1 1', opacities 'b v r srf spp') and keeps the first and last source view of the result
+    (:556-573).  Fixture case C holds what the reference's adapter returns for such a call (3 views, 48 rays, 2 surfaces, 2
+    samples; the reference leaves the sample axis of means / covariances at 1 - values are compared under broadcasting)."""
+    lo, hi, deg = FIX["B_cfg"]
+    ad = GaussianAdapter(GaussianAdapterCfg(float(lo), float(hi), int(deg)), rotate_sh=None)
+    hw = tuple(int(x) for x in FIX["C_hw"])
+    ext, intr = t("C_in_ext")[:, :, None, None, None], t("C_in_intr")[:, :, None, None, None]
+    out = ad.forward(ext, intr, t("C_in_coords"), t("C_in_depths"), t("C_in_opac"), t("C_in_raw"), hw)
+    full = FIX["C_in_opac"].shape
+    assert out.frames.shape == (1, 3, 3, 3) and out.means.shape == (*full, 3) and out.harmonics.shape == (*full, 3, 25)
+    for name, got in (("means", out.means), ("scales", out.scales), ("rotations", out.rotations), ("harmonics", out.harmonics),
+                      ("opacities", out.opacities), ("covariances", out.covariances)):
+        want = np.broadcast_to(FIX["C_out_" + name], got.shape)
+        np.testing.assert_allclose(got.numpy(), want, rtol=2e-5, atol=1e-6 if name == "covariances" else 2e-7, err_msg=name)
+    # what the encoder hands to the decoder: views (0, -1), everything behind the scene axis flattened view-major
+    g = out.for_decoder(views=(0, -1))
+    n = 2 * 48 * 2 * 2
+    assert g.means.shape == (1, n, 3) and g.harmonics.shape == (1, n, 3, 25) and g.opacities.shape == (1, n) and g.frames.shape == (1, 2, 3, 3)
+    np.testing.assert_allclose(g.means.numpy(), np.broadcast_to(FIX["C_out_means"], (*full, 3))[:, (0, -1)].reshape(1, n, 3), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(g.frames.numpy(), FIX["C_in_ext"][:, (0, -1), :3, :3])
+    assert out.for_decoder().means.shape == (1, 3 * 48 * 4, 3)
+    with pytest.raises(ValueError, match="one camera per"):  # a camera per ray cannot become per-view frames
+        ad.forward(ext.expand(1, 3, 48, 1, 1, 4, 4), intr, t("C_in_coords"), t("C_in_depths"), t("C_in_opac"), t("C_in_raw"), hw)
+
+
 def _render(dec, g, sc, device="cpu"):
     mv = lambda x: x.to(device)
     return dec.forward(g, mv(sc.extrinsics), mv(sc.intrinsics), mv(sc.near), mv(sc.far), (24, 32), depth_mode="depth")
@@ -108,7 +135,7 @@ def test_hip_scale_rotation_form_matches_the_oracle_forward_and_backward():
     sc, w, wd = _scene_and_weights()
     res = {}
     for dev in ("cuda:0", "cpu"):
-        old = rasterizer.set_backend(OracleBackend(threads=8)) if dev == "cpu" else None
+        old = install_backend(OracleBackend(threads=8)) if dev == "cpu" else None
         try:
             ad, out, raw = _adapted()
             g = out.for_decoder()
@@ -119,7 +146,7 @@ def test_hip_scale_rotation_form_matches_the_oracle_forward_and_backward():
             res[dev] = (o.color.detach().cpu().numpy(), o.depth.detach().cpu().numpy(), raw.grad.numpy())
         finally:
             if dev == "cpu":
-                rasterizer.set_backend(old)
+                install_backend(old)
     for k, name in enumerate(("colour", "depth", "d_raw")):
         assert rel_l2(res["cuda:0"][k], res["cpu"][k]) < 1e-4, name
     assert np.abs(res["cpu"][2][..., :7]).max() > 0  # scale and quaternion features did receive gradient

@@ -43,8 +43,9 @@ def _worker(rank, world, port, n_views, out_dir):
         from pf3plat_amd import rasterizer, synthetic
         from pf3plat_amd.types import Gaussians
         from tests.oracle_backend import OracleBackend
+        from tests.util import install_backend
 
-        rasterizer.set_backend(OracleBackend())
+        install_backend(OracleBackend())
         sc = synthetic.make_scene(7, 200, (16, 16), num_views=n_views)
         b, e = shard_range(n_views, rank, world)
         g = sc.gaussians
@@ -80,8 +81,9 @@ def test_two_rank_gloo_sharded_render_matches_single_process(tmp_path, n_views):
     from pf3plat_amd import rasterizer, synthetic
     from pf3plat_amd.types import Gaussians
     from tests.oracle_backend import OracleBackend
+    from tests.util import install_backend
 
-    old = rasterizer.set_backend(OracleBackend())
+    old = install_backend(OracleBackend())
     try:
         sc = synthetic.make_scene(7, 200, (16, 16), num_views=n_views)
         g = sc.gaussians
@@ -90,7 +92,7 @@ def test_two_rank_gloo_sharded_render_matches_single_process(tmp_path, n_views):
         w = torch.rand((n_views, 3, 16, 16), generator=torch.Generator().manual_seed(5))
         (out.color[0] * w).sum().backward()
     finally:
-        rasterizer.set_backend(old)
+        install_backend(old)
     np.testing.assert_allclose(got["views"], out.color[0].detach().numpy(), rtol=1e-6, atol=1e-7)
     for i, x in enumerate(leaves):
         np.testing.assert_allclose(got[f"g{i}"], x.grad.numpy(), rtol=2e-4, atol=1e-6)

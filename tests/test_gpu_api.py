@@ -9,18 +9,18 @@ import pf3plat_amd
 from pf3plat_amd import rasterizer, synthetic
 from pf3plat_amd.types import Gaussians
 from tests.oracle_backend import OracleBackend
-from tests.util import rel_l2
+from tests.util import install_backend, rel_l2
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
 def _with_oracle(fn):
-    old = rasterizer.set_backend(OracleBackend(threads=8))
+    old = install_backend(OracleBackend(threads=8))
     try:
         return fn()
     finally:
-        rasterizer.set_backend(old)
+        install_backend(old)
 
 
 def _leafs(sc, device):

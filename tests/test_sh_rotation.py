@@ -1,11 +1,17 @@
-"""SURVEY.md 8f-4 `rotate_sh`: in the basis the rasterizer evaluates, rotating the coefficients is the same as rotating the
+"""SURVEY.md 8f-4 `rotate_sh`.  basis="rasterizer": in the basis the rasterizer evaluates, rotating the coefficients is the same as rotating the
 argument; the bands do not mix, rotations compose, and a rotated scene rendered with rotated coefficients gives the image of
-the unrotated one (oracle rasterizer)."""
+the unrotated one (oracle rasterizer).  basis="e3nn" (the default: the matrices the reference applies,
+src/misc/sh_rotation.py:24-34): rebuilt from e3nn's conventions, checked against what can be checked without e3nn."""
 import numpy as np
 import torch
 
 from oracle import OracleRasterizer
-from pf3plat_amd.sh_rotation import band_rotations, rotate_sh, sh_basis
+from functools import partial
+
+from pf3plat_amd import sh_rotation
+from pf3plat_amd.sh_rotation import band_rotations, e3nn_band_rotations, sh_basis
+
+rotate_sh = partial(sh_rotation.rotate_sh, basis="rasterizer")
 from tests.util import make_camera, random_small_scene
 
 
@@ -73,3 +79,41 @@ def test_rotated_scene_with_rotated_coefficients_renders_the_same_image():
     c2w[:3, :3], c2w[:3, 3] = r, t
     moved = render(sc["means"] @ r.T + t, cov6_r, shs_r, c2w)
     np.testing.assert_allclose(moved, base, atol=2e-6)
+
+
+def _e3nn_harmonics(d):
+    """e3nn's real harmonics for l = 1..3 as its generated code states them (o3/_spherical_harmonics.py, 'component'
+    normalisation; the per-band constant does not matter for the representation matrices): polar axis y."""
+    x, y, z = d.unbind(-1)
+    s1 = [x, y, z]
+    s20, s21, s23, s24 = 15 ** 0.5 * x * z, 15 ** 0.5 * x * y, 15 ** 0.5 * y * z, 0.5 * 15 ** 0.5 * (z * z - x * x)
+    s22 = 5 ** 0.5 * (y * y - 0.5 * (x * x + z * z))
+    s2 = [s20, s21, s22, s23, s24]
+    s3 = [(1 / 6) * 42 ** 0.5 * (s20 * z + s24 * x), 7 ** 0.5 * s20 * y, (1 / 8) * 168 ** 0.5 * (4 * y * y - (x * x + z * z)) * x,
+          0.5 * 7 ** 0.5 * y * (2 * y * y - 3 * (x * x + z * z)), (1 / 8) * 168 ** 0.5 * z * (4 * y * y - (x * x + z * z)),
+          7 ** 0.5 * s24 * y, (1 / 6) * 42 ** 0.5 * (s24 * z - s20 * x)]
+    return [torch.stack(b, -1) for b in (s1, s2, s3)]
+
+
+def test_e3nn_convention_band_matrices():
+    """What the reference multiplies the coefficients with: D_l(R) of e3nn's real basis.  Without e3nn: (i) its l = 1 irrep is the
+    vector representation in (x, y, z) order, so band 1 must be R itself; (ii) D_l(R) Y(d) = Y(R d) for e3nn's own polynomial
+    forms, l <= 3; (iii) group law and orthogonality for all bands; (iv) it is NOT the rasterizer-basis rotation for l >= 1."""
+    g = torch.Generator().manual_seed(1)
+    d = torch.nn.functional.normalize(torch.randn((50, 3), generator=g, dtype=torch.float64), dim=-1)
+    a, b = _rot(11), _rot(12)
+    ma, mb, mab = e3nn_band_rotations(a, 4), e3nn_band_rotations(b, 4), e3nn_band_rotations(a @ b, 4)
+    np.testing.assert_allclose(ma[0].numpy(), np.ones((1, 1)), atol=1e-12)
+    np.testing.assert_allclose(ma[1].numpy(), a.numpy(), atol=1e-10)
+    for l, (y, yr) in enumerate(zip(_e3nn_harmonics(d), _e3nn_harmonics(d @ a.T)), start=1):
+        np.testing.assert_allclose((y @ ma[l].T).numpy(), yr.numpy(), atol=1e-9, err_msg=f"band {l}")
+    for l in range(5):
+        np.testing.assert_allclose((ma[l] @ mb[l]).numpy(), mab[l].numpy(), atol=1e-9)
+        np.testing.assert_allclose((ma[l] @ ma[l].T).numpy(), np.eye(2 * l + 1), atol=1e-9)
+    c = torch.randn((4, 3, 25), generator=g, dtype=torch.float64)
+    ref, ras = sh_rotation.rotate_sh(c, a), rotate_sh(c, a)
+    np.testing.assert_allclose(ref[..., 0].numpy(), c[..., 0].numpy(), atol=1e-12)
+    assert not np.allclose(ref[..., 1:4].numpy(), ras[..., 1:4].numpy(), atol=1e-3)
+    np.testing.assert_allclose(ref[..., 1:4].numpy(), (c[..., 1:4] @ a.T).numpy(), atol=1e-10)  # band 1: plain R c
+    # a matrix that is not a rotation: the reference substitutes the identity (sh_rotation.py:21-22)
+    np.testing.assert_allclose(sh_rotation.rotate_sh(c, 2.0 * a).numpy(), c.numpy())

@@ -163,3 +163,72 @@ def test_render_depth_shares_one_gaussian_copy_between_the_views_of_a_scene(orac
     dec = pf3plat_amd.DecoderSplattingCUDA()
     d = dec.render_depth(g, sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 16), mode="disparity")
     assert torch.equal(d[0], shared) and len(oracle_backend.calls) == 1 and len(oracle_backend.calls[0]) == 3
+
+
+@pytest.mark.parametrize("mode", ["depth", "relative_disparity"])
+def test_depth_render_sends_the_references_gradient_to_extrinsics(oracle_backend, mode):
+    """The reference's depth render reaches `extrinsics` through `extrinsics.inverse()` (cuda_splatting.py:239-242) - the one place a
+    camera gets a gradient, and in training the extrinsics do require grad (model_wrapper.py:148-150).  Both entry points
+    (`render_depth_cuda`, the fused `DecoderSplattingCUDA.forward(depth_mode=)`) must produce it, equal to a literal restatement
+    of the reference's graph: f(z) as a torch tensor, rendered as a precomputed colour, channels averaged."""
+    from pf3plat_amd.geometry import depth_to_relative_disparity, homogenize_points
+
+    sc = synthetic.make_scene(8, 120, (16, 16), num_views=2, near=1.4)
+    g = sc.gaussians
+    w = torch.rand((2, 16, 16), generator=torch.Generator().manual_seed(3))
+    ext0, intr, nr, fr = sc.extrinsics[0], sc.intrinsics[0], sc.near[0], sc.far[0]
+
+    def leaves():
+        return ext0.clone().requires_grad_(True), g.means.clone().requires_grad_(True)
+
+    # (a) the reference's structure: Gaussians repeated per view, fake colour by torch ops, 3 equal channels, mean over them
+    ext, means = leaves()
+    rep = lambda t: t.expand(2, *t.shape[1:])
+    z = torch.einsum("bij,bgj->bgi", ext.inverse(), homogenize_points(rep(means)))[..., 2]
+    fake = depth_to_relative_disparity(z, nr[:, None], fr[:, None]) if mode == "relative_disparity" else z
+    img = pf3plat_amd.render_cuda(ext.detach(), intr, nr, fr, (16, 16), torch.zeros((2, 3)), rep(means), rep(g.covariances),
+                                  fake[..., None, None].expand(-1, -1, 3, 1), rep(g.opacities), use_sh=False).mean(dim=1)
+    (img * w).sum().backward()
+    want = (img.detach(), ext.grad.clone(), means.grad.clone())
+    assert want[1][:, :3].abs().sum() > 0
+    # (b) render_depth_cuda, Gaussians shared between the two views
+    ext, means = leaves()
+    d = pf3plat_amd.render_depth_cuda(ext, intr, nr, fr, (16, 16), means, g.covariances, g.opacities, mode=mode)
+    (d * w).sum().backward()
+    assert rel_l2(d.detach().numpy(), want[0].numpy()) < 1e-6
+    assert rel_l2(ext.grad.numpy(), want[1].numpy()) < 2e-5 and rel_l2(means.grad.numpy(), want[2].numpy()) < 2e-5
+    # (c) the decoder's fused colour + depth pass
+    ext, means = leaves()
+    out = pf3plat_amd.DecoderSplattingCUDA().forward(Gaussians(means, g.covariances, g.harmonics, g.opacities), ext[None], sc.intrinsics,
+                                                     sc.near, sc.far, (16, 16), depth_mode=mode)
+    (out.depth[0] * w).sum().backward()
+    assert rel_l2(ext.grad.numpy(), want[1].numpy()) < 2e-5 and rel_l2(means.grad.numpy(), want[2].numpy()) < 2e-5
+    # without a camera that requires grad the kernels evaluate f(z) themselves: same image, same Gaussian gradient
+    means2 = g.means.clone().requires_grad_(True)
+    d2 = pf3plat_amd.render_depth_cuda(ext0, intr, nr, fr, (16, 16), means2, g.covariances, g.opacities, mode=mode)
+    (d2 * w).sum().backward()
+    assert rel_l2(d2.detach().numpy(), want[0].numpy()) < 1e-6 and rel_l2(means2.grad.numpy(), want[2].numpy()) < 5e-5
+
+
+def test_render_depth_takes_the_adapters_scale_rotation_form(oracle_backend):
+    """Gaussians as the adapter emits them (covariances None; scales, quaternions, frames) through `render_depth` and
+    `render_depth_cuda` == the same Gaussians with materialised covariances (this raised AttributeError)."""
+    from oracle import adapter as oracle_adapter
+
+    sc = synthetic.make_scene(9, 96, (16, 16), num_views=2, near=1.3)
+    gen = torch.Generator().manual_seed(4)
+    scales = 0.05 + 0.2 * torch.rand((1, 96, 3), generator=gen)
+    quats = torch.randn((1, 96, 4), generator=gen)
+    frames = torch.linalg.qr(torch.randn((1, 2, 3, 3), generator=gen))[0]
+    cov = oracle_adapter.covariance_from_scale_rotation(torch.cat((scales, quats), -1), frames)
+    g = sc.gaussians
+    dec = pf3plat_amd.DecoderSplattingCUDA()
+    a = (sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 16))
+    d_cov = dec.render_depth(Gaussians(g.means, cov, g.harmonics, g.opacities), *a, mode="disparity")
+    adapted = Gaussians(g.means, None, g.harmonics, g.opacities, scales=scales, rotations=quats, frames=frames)
+    d_sr = dec.render_depth(adapted, *a, mode="disparity")
+    assert d_sr.shape == (1, 2, 16, 16) and rel_l2(d_sr.numpy(), d_cov.numpy()) < 1e-5
+    c = adapted.clone()
+    assert c.covariances is None and torch.equal(c.scales, scales) and c.scales is not scales and torch.equal(c.frames, frames)
+    c2 = Gaussians(g.means, cov, g.harmonics, g.opacities).clone()
+    assert c2.scales is None and torch.equal(c2.covariances, cov) and c2.covariances is not cov

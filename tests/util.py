@@ -10,6 +10,16 @@ import torch
 from oracle import cameras
 
 
+def install_backend(backend):
+    """Slide another backend object (tests/oracle_backend.OracleBackend; None = let the package build its own HIP backend) under
+    pf3plat_amd's host wrappers and return the one that was there.  The package itself offers no such switch: this pokes the
+    module global that `pf3plat_amd.rasterizer.get_backend()` caches, from the test side only."""
+    from pf3plat_amd import rasterizer
+
+    old, rasterizer._BACKEND = rasterizer._BACKEND, backend
+    return old
+
+
 def make_camera(c2w=None, fx=0.86, fy=0.86, cx=0.5, cy=0.5, near=1.0, far=100.0, dtype=np.float64):
     """Returns dict(viewmatrix, projmatrix, campos, tanfovx, tanfovy) as numpy (transposed matrices), built by the oracle's
     camera arithmetic (oracle/cameras.py; no scale-invariant rescale)."""
