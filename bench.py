@@ -133,12 +133,30 @@ def pmc_traffic(kernels, n, mode="fwd"):
                 "write_size_raw_bytes": raw[k]["WRITE_SIZE"]} for k in kernels}
 
 
+def device_clocks():
+    """{"sclk": MHz, "mclk": MHz} of GPU 0 as rocm-smi reports them right now (None if it cannot be asked)."""
+    import re
+    import subprocess
+
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks"], capture_output=True, text=True, timeout=20).stdout
+        found = {k: re.search(rf"{k} clock level: \S+ \((\d+)Mhz\)", out) for k in ("sclk", "mclk")}
+        return {k: int(m.group(1)) for k, m in found.items() if m} or None
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-graph", action="store_true", help="eager launches only (no HIP-graph replay)")
+    ap.add_argument("--graph", action="store_true", help="also time a HIP-graph replay of the step (reported beside the eager headline, never as it)")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)  # (round-2 spelling; eager-only is the default now)
+    ap.add_argument("--preheat-ms", type=float, default=300.0,
+                    help="untimed: run the step for this long before the W warm-up steps so that the shader clock has ramped "
+                         "(a 20-step window after 50 ms of idle is 10-15 %% slow on MI355X: tools/clock_probe.py)")
+    ap.add_argument("--headline-only", action="store_true", help="stop after the timed region (for rocprofv3 runs of the headline loop alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gaussians", type=int, default=N_GAUSS, help=argparse.SUPPRESS)
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
@@ -201,6 +219,12 @@ def main():
         return
 
     def barrier():
+        # the host learns of the device going idle by polling an event (a blocking synchronize sleeps, and its wake-up alone is
+        # 30-60 us: 2-3 us per step of a 20-step window), then the synchronize + barrier + synchronize the contract asks for
+        ev = torch.cuda.Event()
+        ev.record()
+        while not ev.query():
+            pass
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -208,7 +232,7 @@ def main():
 
     # ---- optional HIP-graph capture of one step (a plain chain of three kernel launches on one stream)
     graph = None
-    if not args.no_graph:
+    if args.graph and not args.no_graph:
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -237,7 +261,10 @@ def main():
     # gather is exposed.  Every view is rendered straight into its slot of `views` (no copy).
     n_chunks = min(8, max(1, K // 8)) if world > 1 else 0
     bounds = [round(c * K / n_chunks) for c in range(n_chunks + 1)] if n_chunks else []
-    all_views = torch.empty((world, K, 3, H, W), dtype=torch.float32, device=dev) if (world > 1 and backend == "nccl") else None
+    # one (world, chunk, 3, H, W) destination per chunk: all_gather_into_tensor writes rank r's chunk at [r] (no list of slices,
+    # which the RCCL backend would serve through a flat temporary and a copy)
+    all_views = ([torch.empty((world, bounds[c + 1] - bounds[c], 3, H, W), dtype=torch.float32, device=dev) for c in range(n_chunks)]
+                 if (world > 1 and backend == "nccl") else None)
 
     def timed(fn, k, keep_views):
         barrier()
@@ -249,8 +276,7 @@ def main():
                 be.run_forward(plan, viewbuf, means, cov6, opac, shs, out_color=views[i:i + 1])
                 if all_views is not None and i + 1 == bounds[nxt]:
                     i0, i1 = bounds[nxt - 1], bounds[nxt]
-                    outs = [all_views[r, i0:i1] for r in range(world)]
-                    handles.append(dist.all_gather(outs, views[i0:i1], async_op=True))
+                    handles.append(dist.all_gather_into_tensor(all_views[nxt - 1], views[i0:i1], async_op=True))
                     nxt += 1
             else:
                 fn()
@@ -258,7 +284,7 @@ def main():
             if all_views is not None:
                 for h in handles:
                     h.wait()
-                gathered.append(all_views.reshape(world * K, 3, H, W))
+                gathered.append(all_views)  # chunk c, rank r, step j of the chunk = view bounds[c] + j of rank r
             else:
                 gathered.append(gather_views(views))  # functional path (gloo): one gather of (world * K, 3, H, W)
         barrier()
@@ -268,17 +294,37 @@ def main():
     if world > 1:
         graph = None
     run = (graph.replay if graph is not None else step)
-    for _ in range(Wm):
-        run()
+    # untimed set-up: bring the shader clock up.  MI355X drops to a low-power state within milliseconds of idle (the set-up above
+    # ends in blocking reads) and needs a few hundred steps to come back: tools/clock_probe.py measured 71 us/step for the first 20
+    # steps after 50 ms of idle against 62 us in steady state.  The W warm-up steps follow as the contract says.
     if all_views is not None:  # untimed: first use of the collective (communicator channels, kernel load)
-        i0, i1 = bounds[0], bounds[1]
-        dist.all_gather([all_views[r, i0:i1] for r in range(world)], views[i0:i1])
-    dt = timed(run, K, world > 1)
-    eager_dt = None
-    if graph is not None:
-        for _ in range(min(Wm, 5)):
+        dist.all_gather_into_tensor(all_views[0], views[bounds[0]:bounds[1]])
+    clocks = None
+    preheat_steps = 0
+    if args.preheat_ms > 0:
+        if rank == 0:  # the clocks under load, sampled while ~0.1 s of steps sit in the queue (rocm-smi takes about that long)
+            for _ in range(1500):
+                step()
+            clocks = device_clocks()
+            preheat_steps += 1500
+        torch.cuda.synchronize()
+        t_pre = time.perf_counter()
+        for _ in range(100):
             step()
-        eager_dt = timed(step, K, False)
+        torch.cuda.synchronize()
+        per_step = max((time.perf_counter() - t_pre) / 100, 1e-6)
+        # one uninterrupted queue of steps, then straight into the warm-up (no idle gap: the clock falls back within milliseconds)
+        preheat_steps += 100 + int(args.preheat_ms * 1e-3 / per_step)
+        for _ in range(int(args.preheat_ms * 1e-3 / per_step)):
+            step()
+    for _ in range(Wm):
+        step()
+    dt = timed(step, K, world > 1)  # the headline: eager launches
+    graph_dt = None
+    if graph is not None:  # --graph: the same protocol over replays of the captured step, reported beside the headline
+        for _ in range(min(Wm, 5)):
+            graph.replay()
+        graph_dt = timed(graph.replay, K, False)
     ranks_seen = 1
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -289,13 +335,8 @@ def main():
         ranks_seen = int(round(float(ones.item())))
     status = be.read_status(plan)
     assert not status["overflow"], status
-    # both launch modes ran the same W + K protocol; the headline is the faster one and says which it is
-    launch_mode = "hip_graph_replay" if graph is not None else "eager"
-    graph_dt = None
-    if eager_dt is not None:
-        graph_dt = dt
-        if eager_dt < dt:
-            dt, launch_mode = eager_dt, "eager"
+    launch_mode = "eager"
+    eager_dt = dt
 
     result = {
         "metric": "rendered views/sec, 300k Gaussians @ 256x256 (fwd raster); bwd ms and HBM GB/s vs roofline alongside",
@@ -312,9 +353,20 @@ def main():
     if world > 1:
         result["rccl_ranks"] = ranks_seen
         result["dist_backend"] = backend
-    if eager_dt is not None:
-        result["eager_ms_per_step"] = 1e3 * eager_dt / K
+    result["config"]["preheat"] = (f"{preheat_steps} untimed steps (~{args.preheat_ms:.0f} ms) before the {Wm} warm-up steps: MI355X leaves its "
+                                   "low-power state only after some hundred steps (tools/clock_probe.py; profiles/r03_clock_probe.txt)")
+    if clocks is not None:
+        result["config"]["clocks_under_load_mhz"] = clocks
+    result["eager_ms_per_step"] = 1e3 * eager_dt / K
+    if graph_dt is not None:
         result["graph_ms_per_step"] = 1e3 * graph_dt / K
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps(result))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     if rank == 0:
         # ---- per-stage HIP-event timing of the same chain (events on the launch stream), after the timed region
@@ -347,6 +399,45 @@ def main():
         result["roofline_chain"] = {"bound": "hbm", "achieved": ab["total"] / (dt / K) / 1e9,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab["total"] / (dt / K) / 1e9 / HBM_PEAK_GBS,
                                     "algorithmic_bytes": ab["total"], "N": n, "N_v": nv, "R16": r16}
+        # ---- the same loop over FOUR resident scenes, round-robin (seeds 2..5: 4 x 106 MB of inputs > the 256 MiB Infinity
+        # Cache): every step streams its inputs from HBM, the pattern of a training loop that sees a new scene every step
+        # (reference src/model/model_wrapper.py:140-156).  The headline loop above renders ONE scene over and over and finds
+        # part of its 90 MB of harmonics in the Infinity Cache; this is the honest HBM figure.
+        if world == 1:
+            try:
+                rr = [(means, cov6, opac, shs)]
+                for seed in (3, 4, 5):
+                    sc_k = synthetic.make_scene(seed, n, (H, W), d_sh=D_SH)
+                    rr.append(tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc_k)))
+                stats_rr, caps = [], []
+                for a_ in rr:  # one workspace for the four: sized for the largest pair count
+                    be.run_forward(plan, viewbuf, *a_)
+                    st_k = be.read_status(plan)
+                    assert not st_k["overflow"], st_k
+                    stats_rr.append(reference_rect_stats(plan, cfg))
+                    caps.append(be.capacity_for(cfg, st_k, headroom=1.1))
+                plan_rr = be.make_plan(cfg, dev, capacity=max(caps), backward=False)
+                for i in range(max(Wm, 8)):
+                    be.run_forward(plan_rr, viewbuf, *rr[i % 4])
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(K):
+                    be.run_forward(plan_rr, viewbuf, *rr[i % 4])
+                barrier()
+                dt_rr = time.perf_counter() - t0
+                assert not be.read_status(plan_rr)["overflow"]
+                ab_rr = sum(algorithmic_bytes(n, nv_k, r16_k, H * W, D_SH)["total"] for nv_k, r16_k in stats_rr) / 4.0
+                result["roofline_chain_cold"] = {
+                    "bound": "hbm", "ms_per_step": 1e3 * dt_rr / K, "views_per_s": K / dt_rr,
+                    "achieved": ab_rr / (dt_rr / K) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ab_rr / (dt_rr / K) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": ab_rr,
+                    "note": "same protocol, four distinct resident scenes round-robin (424 MB of inputs > 256 MiB Infinity Cache): "
+                            "inputs come from HBM every step; `roofline_chain` is the single-scene (cache-warm) BASELINE loop"}
+                result["roofline_chain"]["note"] = ("single scene re-rendered every step (BASELINE configs[1]): part of its inputs is served "
+                                                    "by the 256 MiB Infinity Cache; see roofline_chain_cold")
+                del rr, plan_rr
+            except Exception as e:  # must never take the headline down
+                result["roofline_chain_cold"] = f"{type(e).__name__}: {e}"
         result["stage_ms"] = {k_: round(acc[k_], 5) for k_ in chain_stages}
         result["stage_ms_raw"] = {k_: round(raw_acc[k_], 5) for k_ in raw_acc}
         result["stage_ms"]["note"] = ("HIP events on the launch stream around each launch of the product chain ("

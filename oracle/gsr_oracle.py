@@ -24,6 +24,7 @@ _lib = None
 def build_oracle(force: bool = False) -> str:
     """Compile the oracle with gcc (a few seconds).  Building the checker is not using it."""
     src = [os.path.join(_HERE, f) for f in ("gsr_oracle.cpp", "gsr_oracle.hpp", "gsr_cpu.h", "Makefile")]
+    src.append(os.path.join(os.path.dirname(_HERE), "include", "gsr.h"))  # the twin's signatures and GSR_ABI_VERSION live there
     stale = (not os.path.exists(_LIB_PATH)) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
     )

@@ -17,7 +17,7 @@ from tests.util import rel_l2
 
 
 def _dims(cfg, capacity=0):
-    return _lib.GsrDims(1, cfg.num_views, cfg.num_sets, cfg.views_per_set, cfg.num_gaussians, cfg.height, cfg.width, cfg.sh_degree,
+    return _lib.GsrDims(_lib.GSR_ABI_VERSION, cfg.num_views, cfg.num_sets, cfg.views_per_set, cfg.num_gaussians, cfg.height, cfg.width, cfg.sh_degree,
                         cfg.sh_coeffs, cfg.max_sh_eval, int(cfg.has_extra), cfg.flags, capacity)
 
 
