@@ -1999,6 +1999,9 @@ constexpr int kFwdWaves = 4;
 #ifndef GSR_KFS
 #define GSR_KFS 8
 #endif
+#ifndef GSR_BLEND_ORDER
+#define GSR_BLEND_ORDER 1
+#endif
 constexpr int kFS = GSR_KFS;                  // entries per wave per batch (even)
 constexpr int kFB = kFS * kFwdWaves;          // 32 list entries per batch
 constexpr int kFwdThreads = 64 * kFwdWaves;   // 256
@@ -2066,6 +2069,7 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
   const int e0 = wave * kFS;
 
   const f2 px2 = {pxf, pxf}, py2 = {pyf, pyf};
+  f2 om[kFS / 2];                               // 1 - alpha of the same entries (kept: stage A needs both)
   auto eval = [&](uint32_t b) {  // stage E, two entries per step (v_pk_*_f32: same rounding per component as scalar code)
     const int gb = b & 3;
     f2 P2 = {1.f, 1.f};
@@ -2080,30 +2084,59 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
       const float alpha0 = fminf(0.99f, ao.x), alpha1 = fminf(0.99f, ao.y);
       const bool keep0 = !(p2.x > 0.f) && !(alpha0 < 1.0f / 255.0f), keep1 = !(p2.y > 0.f) && !(alpha1 < 1.0f / 255.0f);
       al[u >> 1] = f2{keep0 ? alpha0 : 0.f, keep1 ? alpha1 : 0.f};
-      P2 *= f2{1.f, 1.f} - al[u >> 1];
+      om[u >> 1] = f2{1.f, 1.f} - al[u >> 1];
+      P2 *= om[u >> 1];
     }
     sP[b & 1][wave][lane] = P2.x * P2.y;
   };
   f2 CR = {0.f, 0.f}, CG = {0.f, 0.f}, CB = {0.f, 0.f}, CE = {0.f, 0.f};  // colour sums over even / odd entries
-  auto accum = [&](uint32_t b, float Tf) {  // stage A; Tf = transmittance at the start of this wave's segment
+  // Stage A; Tf = transmittance at the start of this wave's segment.  A pixel's loop has stopped <=> T (1 - alpha) < 1e-4, and T
+  // only falls: within the entries a wave sees, "alive" is a PREFIX.  So a pixel that is dead on entry (Tf < 1e-4: it died at an
+  // earlier entry) is given T = 0 - every weight of the segment is then 0 by itself - and only a segment INSIDE which some pixel
+  // of the tile dies needs the per-entry tests (weights masked from the dying entry on, the last transmittance that passed, the
+  // number of entries gone through); for the others - all 8 entries alive, or none - one test per lane settles all three.
+  auto accum = [&](uint32_t b, float Tf) {
     const int cb = b & 3;
+    const bool alive_in = !(Tf < 0.0001f);
+    float T = alive_in ? Tf : 0.f;
+    float Tn[kFS];
+    f2 w[kFS / 2];
 #pragma unroll
     for (int u = 0; u < kFS; u += 2) {
-      const f2 om = f2{1.f, 1.f} - al[u >> 1];
-      const float Tn0 = Tf * om.x, Tn1 = Tn0 * om.y;
-      const bool alive0 = !(Tn0 < 0.0001f), alive1 = !(Tn1 < 0.0001f);
-      const f2 wr = al[u >> 1] * f2{Tf, Tn0};
-      const f2 w = {alive0 ? wr.x : 0.f, alive1 ? wr.y : 0.f};
-      Tmin = alive0 ? Tn0 : Tmin;
-      Tmin = alive1 ? Tn1 : Tmin;
-      Tf = Tn1;
-      const float4 rg = sRG[cb][(e0 + u) >> 1], be = sBE[cb][(e0 + u) >> 1];
-      CR = __builtin_elementwise_fma(f2{rg.x, rg.y}, w, CR);
-      CG = __builtin_elementwise_fma(f2{rg.z, rg.w}, w, CG);
-      CB = __builtin_elementwise_fma(f2{be.x, be.y}, w, CB);
-      if (kExtra) CE = __builtin_elementwise_fma(f2{be.z, be.w}, w, CE);
-      last += (uint32_t)alive0 + (uint32_t)alive1;  // entries this pixel's loop went through (a prefix of the list)
+      Tn[u] = T * om[u >> 1].x;
+      Tn[u + 1] = Tn[u] * om[u >> 1].y;
+      w[u >> 1] = al[u >> 1] * f2{T, Tn[u]};
+      T = Tn[u + 1];
     }
+    const bool alive_out = !(T < 0.0001f);
+    if (__any(alive_in && !alive_out)) {  // wave-uniform: some pixel's loop stops inside this segment
+#pragma unroll
+      for (int u = 0; u < kFS; u += 2) {
+        const bool alive0 = !(Tn[u] < 0.0001f), alive1 = !(Tn[u + 1] < 0.0001f);
+        w[u >> 1] = f2{alive0 ? w[u >> 1].x : 0.f, alive1 ? w[u >> 1].y : 0.f};
+        Tmin = alive0 ? Tn[u] : Tmin;
+        Tmin = alive1 ? Tn[u + 1] : Tmin;
+        last += (uint32_t)alive0 + (uint32_t)alive1;  // entries this pixel's loop went through (a prefix of the list)
+      }
+    } else {
+      Tmin = alive_out ? T : Tmin;
+      last += alive_out ? (uint32_t)kFS : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < kFS; u += 2) {
+      const float4 rg = sRG[cb][(e0 + u) >> 1], be = sBE[cb][(e0 + u) >> 1];
+      CR = __builtin_elementwise_fma(f2{rg.x, rg.y}, w[u >> 1], CR);
+      CG = __builtin_elementwise_fma(f2{rg.z, rg.w}, w[u >> 1], CG);
+      CB = __builtin_elementwise_fma(f2{be.x, be.y}, w[u >> 1], CB);
+      if (kExtra) CE = __builtin_elementwise_fma(f2{be.z, be.w}, w[u >> 1], CE);
+    }
+#if GSR_BLEND_ORDER
+    // keep stage A where it is written: its sums are not needed before the next iteration, and left alone the compiler sinks this
+    // arithmetic below stage E - the old and the new alphas of the segment are then alive together and the loop pays sixteen
+    // register copies per iteration for it
+    asm volatile("" : "+v"(CR), "+v"(CG), "+v"(CB), "+v"(Tmin), "+v"(last));
+    if (kExtra) asm volatile("" : "+v"(CE));
+#endif
   };
   auto put_records = [&](int sb, float4 q, float2 q2, const float4& c) {  // lane = entry of the batch
     q.z = (-0.5f * kLog2e) * q.z; q.w = (-kLog2e) * q.w; q2.x = (-0.5f * kLog2e) * q2.x;  // to_exp2_domain
