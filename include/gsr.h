@@ -218,6 +218,16 @@ int gsr_last_failed_stage(void);
  * GSR_FLAG_DETERMINISTIC). */
 size_t gsr_backward_scratch_bytes(const GsrDims* dims);
 
+/* One camera record from the fields of upstream's GaussianRasterizationSettings, in ONE launch: the set-up of the per-view
+ * API (the reference builds a settings object per view, cuda_splatting.py:99-112, and this library's own Python layer used to
+ * assemble the record with a dozen small tensor ops).  viewmatrix / projmatrix: 16 contiguous device floats each, transposed as
+ * the reference passes them; campos: 3 device floats `campos_stride` floats apart (the reference hands over extrinsics[i, :3, 3],
+ * stride 4); bg: 3 device floats; tan-fov: host values, or - when the settings hold tensors, as render_cuda_orthographic's do
+ * (:195-196) - one device float each (non-NULL pointer wins).  scale = 1 (the per-view API gets pre-scaled Gaussians). */
+int gsr_pack_view(const float* viewmatrix, const float* projmatrix, const float* campos, int campos_stride, const float* bg,
+                  float tanfovx, float tanfovy, const float* tanfovx_dev, const float* tanfovy_dev, float scale_modifier,
+                  GsrView* out, void* stream);
+
 /* Camera set-up in one launch: fills views[0..num_views) from camera-to-world extrinsics (V,4,4), normalised intrinsics
  * (V,3,3), near/far (V) and a background colour (background_stride 3: one per view; 0: one shared) - the arithmetic of the
  * reference wrapper at cuda_splatting.py:64-71 and :80-87 (get_fov of projection.py:233-247, get_projection_matrix of

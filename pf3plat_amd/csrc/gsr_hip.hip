@@ -3068,6 +3068,23 @@ __global__ void k_setup_views_ortho(int V, const float* ext, const float* width,
   }
 }
 
+// One record of the per-view API (gsr_pack_view): thread k writes float k.
+__global__ __launch_bounds__(64) void k_pack_view(const float* vm, const float* pm, const float* campos, int cstride, const float* bg,
+                                                  float tx, float ty, const float* txd, const float* tyd, float smod, float* out) {
+  const int k = threadIdx.x;
+  if (k >= 48) return;
+  float v = 0.f;
+  if (k < 16) v = vm[k];
+  else if (k < 32) v = pm[k - 16];
+  else if (k < 35) v = campos[(size_t)(k - 32) * cstride];
+  else if (k == 35) v = txd ? *txd : tx;
+  else if (k == 36) v = tyd ? *tyd : ty;
+  else if (k < 40) v = bg[k - 37];
+  else if (k < 42) v = 1.f;  // scale, scale^2
+  else if (k == 42) v = smod;
+  out[k] = v;
+}
+
 __global__ __launch_bounds__(256) void k_mark_visible(const Params p, uint8_t* present) {
   const int set = blockIdx.y;
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -3628,6 +3645,16 @@ int gsr_setup_views_orthographic(int num_views, const float* extrinsics, const f
   if (!extrinsics || !width || !height || !near_ || !far_ || !background || !views) return GSR_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_setup_views_ortho, dim3((unsigned)((num_views + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream_),
                      num_views, extrinsics, width, height, near_, far_, background, background_stride, fov_degrees, views, dump);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_pack_view(const float* viewmatrix, const float* projmatrix, const float* campos, int campos_stride, const float* bg,
+                  float tanfovx, float tanfovy, const float* tanfovx_dev, const float* tanfovy_dev, float scale_modifier,
+                  GsrView* out, void* stream_) {
+  if (!viewmatrix || !projmatrix || !campos || !bg || !out || campos_stride < 1) return GSR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_pack_view, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream_), viewmatrix, projmatrix, campos,
+                     campos_stride, bg, tanfovx, tanfovy, tanfovx_dev, tanfovy_dev, scale_modifier, reinterpret_cast<float*>(out));
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
 }

@@ -13,6 +13,7 @@ There is no CPU path here: tensors must live on a ROCm device and the HIP librar
 from __future__ import annotations
 
 import ctypes
+import struct
 from dataclasses import dataclass
 from typing import NamedTuple, Optional
 
@@ -102,6 +103,8 @@ class HipBackend:
         self.sync_policy = "sync"  # or "lazy" (opt-in, inference / benchmarks): see forward()
         self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
         self.pending = []  # (pinned status copy, event, shape key, cfg, workspace id) of lazy forwards not yet verified
+        self._status_host = None
+        self.workspace_cache = {}  # (cfg, capacity, device, stream) -> (geom, bin, img) of forwards that nothing differentiates
         self.last_status = None
 
     def _rc(self, rc: int, what: str, stages=None):
@@ -149,6 +152,41 @@ class HipBackend:
             raise RuntimeError(f"gsr_cov_from_scale_rot_backward failed with code {rc}")
         return d_s, d_r
 
+    def pack_view(self, rs, device) -> Tensor:
+        """The (1, 48) camera record of one `GaussianRasterizationSettings` in ONE launch (gsr_pack_view): the matrices, the
+        camera centre (read through its stride: the reference passes `extrinsics[i, :3, 3]`, stride 4) and the background stay
+        where they are on the device; the tan-fovs travel as launch arguments (floats, as the reference passes them) or as
+        device pointers (tensors, as its orthographic wrapper passes them)."""
+        f32 = torch.float32
+
+        def dev_f32(t, shape=None):
+            t = t.to(device=device, dtype=f32)
+            return t if t.is_contiguous() else t.contiguous()
+
+        vm, pm, bg = dev_f32(rs.viewmatrix), dev_f32(rs.projmatrix), dev_f32(rs.bg)
+        cp = rs.campos.to(device=device, dtype=f32)
+        if cp.dim() != 1 or cp.shape[0] != 3:
+            cp = cp.reshape(3)
+        self._check_device(vm, pm, bg, cp)
+        tx = ty = 0.0
+        txd = tyd = None
+        if torch.is_tensor(rs.tanfovx):
+            txd = rs.tanfovx.reshape(-1)[:1].to(device=device, dtype=f32)
+        else:
+            tx = float(rs.tanfovx)
+        if torch.is_tensor(rs.tanfovy):
+            tyd = rs.tanfovy.reshape(-1)[:1].to(device=device, dtype=f32)
+        else:
+            ty = float(rs.tanfovy)
+        out = torch.empty((1, VIEW_FLOATS), dtype=f32, device=device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        with torch.cuda.device(device):
+            rc = self.lib.gsr_pack_view(_ptr(vm), _ptr(pm), _ptr(cp), int(cp.stride(0)), _ptr(bg), tx, ty, _ptr(txd), _ptr(tyd),
+                                        float(rs.scale_modifier), _ptr(out), stream)
+        if rc != 0:
+            raise RuntimeError(f"gsr_pack_view failed with code {rc}")
+        return out
+
     def workspace_layout(self, dims: _lib.GsrDims):
         offs = (ctypes.c_int64 * 8)()
         rc = self.lib.gsr_workspace_layout(ctypes.byref(dims), offs)
@@ -188,18 +226,31 @@ class HipBackend:
         return cfg.num_views * max(8 * cfg.num_gaussians, 1 << 18)
 
     # ---- plans: outputs + workspaces allocated once, launch chains enqueued many times (bench / HIP-graph capture)
-    def make_plan(self, cfg: RasterConfig, device, capacity: int, backward: bool = False, colors_shape=None) -> dict:
+    def make_plan(self, cfg: RasterConfig, device, capacity: int, backward: bool = False, colors_shape=None,
+                  reuse_workspaces: bool = False) -> dict:
+        """reuse_workspaces: the three workspaces (not the outputs) come from a per-(shape, stream) cache - for forwards that no
+        backward can follow and whose status block is read before the next call (the per-view inference loop: three
+        allocations and a workspace-size query per view less)."""
         v, h, w, n, s = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians, cfg.num_sets
         f32, u8 = torch.float32, torch.uint8
         dims = self._dims(cfg, capacity)
-        gb, bb, ib = self.workspace_sizes(dims)
+        ws = None
+        if reuse_workspaces:
+            key = (cfg, int(capacity), str(device), torch.cuda.current_stream(device).cuda_stream)
+            ws = self.workspace_cache.get(key)
+        if ws is None:
+            gb, bb, ib = self.workspace_sizes(dims)
+            ws = (torch.empty(gb, dtype=u8, device=device), torch.empty(bb, dtype=u8, device=device), torch.empty(ib, dtype=u8, device=device))
+            if reuse_workspaces:
+                if len(self.workspace_cache) >= 8:
+                    self.workspace_cache.clear()
+                self.workspace_cache[key] = ws
         plan = dict(
             cfg=cfg, dims=dims, device=device,
             color=torch.empty((v, 3, h, w), dtype=f32, device=device),
             extra_img=torch.empty((v, h, w), dtype=f32, device=device) if cfg.has_extra else None,
             radii=torch.empty((v, n), dtype=torch.int32, device=device),
-            geom=torch.empty(gb, dtype=u8, device=device), bin=torch.empty(bb, dtype=u8, device=device),
-            img=torch.empty(ib, dtype=u8, device=device),
+            geom=ws[0], bin=ws[1], img=ws[2],
         )
         if backward:
             if colors_shape is None:
@@ -289,12 +340,14 @@ class HipBackend:
         self._rc(rc, "gsr_backward", _lib.BWD_STAGES)
         return None if ms is None else dict(zip(_lib.BWD_STAGES, [float(x) for x in ms]))
 
-    @staticmethod
-    def read_status(plan: dict) -> dict:
-        """Blocking read of the status block of the plan's last forward."""
-        st = plan["bin"][:16].cpu()
-        return {"num_pairs": int(st[:8].view(torch.int64).item()), "overflow": int(st[8:12].view(torch.int32).item()),
-                "max_list": int(st[12:16].view(torch.int32).item())}
+    def read_status(self, plan: dict) -> dict:
+        """Blocking read of the status block of the plan's last forward (16 bytes into a pinned buffer kept for the purpose)."""
+        host = self._status_host
+        if host is None:
+            host = self._status_host = torch.empty(16, dtype=torch.uint8, pin_memory=True)
+        host.copy_(plan["bin"][:16])  # blocking device-to-host copy: the one sync of the default policy
+        num_pairs, overflow, max_list = struct.unpack("<qii", host.numpy().tobytes())
+        return {"num_pairs": int(num_pairs), "overflow": int(overflow), "max_list": int(max_list)}
 
     # ---- autograd-facing calls: fresh outputs/workspaces per call, kept alive for backward
     def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None,
@@ -316,7 +369,7 @@ class HipBackend:
         lazy = (self.sync_policy == "lazy" and capacity is None and key in self.capacity_hint) or self.defer_status
         cap = self._default_capacity(cfg) if capacity is None else int(capacity)
         for attempt in range(3):
-            plan = self.make_plan(cfg, dev, cap)
+            plan = self.make_plan(cfg, dev, cap, reuse_workspaces=not (cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) and not lazy)
             self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
             saved = (plan["dims"], plan["geom"], plan["bin"], plan["img"])
             out = (plan["color"], plan["extra_img"], plan["radii"], saved)
@@ -576,6 +629,9 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     has_extra = extra is not None or extra_mode is not None
     cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags,
                        bool(scale_rot))
+    if not (flags & _lib.FLAG_BACKWARD_FOLLOWS):  # nothing here can be differentiated: no autograd node, no saved workspaces
+        color, extra_img, radii, _ = get_backend().forward(cfg, viewbuf.contiguous(), means, cov6, opacities, colors, extra, frames=frames)
+        return color, (extra_img if has_extra else None), radii
     color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg,
                                                     frames)
     return color, (extra_img if has_extra else None), radii
@@ -654,15 +710,7 @@ class GaussianRasterizer(nn.Module):
         self.raster_settings = raster_settings
 
     def _viewbuf(self, device) -> Tensor:
-        rs = self.raster_settings
-
-        def scalar(x):
-            if torch.is_tensor(x):
-                return x.reshape(-1)[:1].to(device=device, dtype=torch.float32)
-            return torch.tensor([float(x)], dtype=torch.float32, device=device)
-
-        return pack_views(rs.viewmatrix.to(device)[None], rs.projmatrix.to(device)[None], rs.campos.to(device)[None],
-                          scalar(rs.tanfovx), scalar(rs.tanfovy), rs.bg.to(device)[None], None, float(rs.scale_modifier))
+        return get_backend().pack_view(self.raster_settings, device)
 
     def markVisible(self, positions: Tensor) -> Tensor:
         with torch.no_grad():

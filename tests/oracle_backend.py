@@ -202,6 +202,13 @@ class OracleBackend:
             s, r = scales.detach().requires_grad_(True), rotations.detach().requires_grad_(True)
             return torch.autograd.grad(self._cov6(s, r, scale_modifier), (s, r), d_cov6)
 
+    def pack_view(self, rs, device):
+        from pf3plat_amd.rasterizer import pack_views
+
+        sc = lambda x: x.reshape(-1)[:1].float() if torch.is_tensor(x) else torch.tensor([float(x)])
+        return pack_views(rs.viewmatrix[None], rs.projmatrix[None], rs.campos[None], sc(rs.tanfovx), sc(rs.tanfovy), rs.bg[None], None,
+                          float(rs.scale_modifier))
+
     def mark_visible(self, cfg, viewbuf, means):
         out = torch.zeros((cfg.num_sets, cfg.num_gaussians), dtype=torch.bool)
         for s in range(cfg.num_sets):

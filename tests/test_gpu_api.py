@@ -273,3 +273,54 @@ def test_setup_views_kernels_match_the_oracle_camera_arithmetic():
         np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-4, atol=1e-4 * np.abs(want).max())
         for k in ("extrinsics", "fov_x", "fov_y", "near", "far"):
             np.testing.assert_allclose(dump[k].cpu().numpy(), wdump[k], rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_reference_unchanged_decoder_path_at_config4_size():
+    """BASELINE configs[3] at its real size (G = 131 072, 3 target views) rendered EXACTLY as the reference's decoder does it
+    (tests/reference_style.py: V-fold `repeat`, torch pre-scale, per-view settings object with `.item()` floats, a fresh
+    `GaussianRasterizer` per view through the `diff_gaussian_rasterization` module name, strided `campos`, default `sync`
+    policy): HIP against the same Python driven by the oracle, forward and backward, and against the fused decoder."""
+    from tests.reference_style import reference_style_decoder_forward
+
+    n, hw = 131072, (256, 256)
+    sc = synthetic.make_scene(50, n, hw, num_views=3)
+    w = torch.rand((1, 3, 3, *hw), generator=torch.Generator().manual_seed(4))
+    bgc = torch.tensor([0.1, 0.2, 0.3])
+
+    def run(device):
+        leaves = _leafs(sc, device)
+        t = lambda x: x.to(device)
+        img = reference_style_decoder_forward(Gaussians(*leaves), t(sc.extrinsics), t(sc.intrinsics), t(sc.near), t(sc.far), hw, t(bgc))
+        (img * t(w)).sum().backward()
+        return img.detach().cpu().numpy(), leaves
+
+    assert rasterizer.get_backend().sync_policy == "sync"
+    gi, gl = run(DEV)
+    oi, ol = _with_oracle(lambda: run("cpu"))
+    assert gi.shape == (1, 3, 3, *hw) and rel_l2(gi, oi) < 1e-4
+    _cmp_grads(gl, ol)
+    # and the fused decoder (one launch chain, no repeat) renders the same three views
+    fl = _leafs(sc, DEV)
+    dec = pf3plat_amd.DecoderSplattingCUDA(dataset_cfg=pf3plat_amd.decoder.DatasetCfgLike(tuple(bgc.tolist()))).to(DEV)
+    out = dec.forward(Gaussians(*fl), sc.extrinsics.to(DEV), sc.intrinsics.to(DEV), sc.near.to(DEV), sc.far.to(DEV), hw)
+    (out.color * w.to(DEV)).sum().backward()
+    assert rel_l2(out.color.detach().cpu().numpy(), gi) < 2e-6
+    _cmp_grads(fl, gl, tol=2e-5)
+
+
+def test_pack_view_matches_the_torch_assembly_of_the_record():
+    """gsr_pack_view (one launch per settings object) == pack_views (the torch assembly): strided campos, float and tensor tan-fovs."""
+    from pf3plat_amd.rasterizer import GaussianRasterizationSettings, pack_views
+
+    g = torch.Generator().manual_seed(3)
+    ext = torch.randn((4, 4), generator=g).to(DEV)
+    vm, pm, bg = torch.randn((4, 4), generator=g).to(DEV), torch.randn((4, 4), generator=g).to(DEV), torch.rand(3, generator=g).to(DEV)
+    campos = ext[:3, 3]
+    assert campos.stride(0) == 4
+    be = rasterizer.get_backend()
+    for tx, ty in ((0.61, 0.47), (torch.tensor([0.61], device=DEV), torch.tensor(0.47, device=DEV))):
+        rs = GaussianRasterizationSettings(32, 48, tx, ty, bg, 1.5, vm, pm, 3, campos, False, False)
+        rec = be.pack_view(rs, torch.device(DEV))
+        f = lambda x: x.reshape(-1)[:1].float() if torch.is_tensor(x) else torch.tensor([x], device=DEV)
+        want = pack_views(vm[None], pm[None], campos[None], f(tx), f(ty), bg[None], None, 1.5)
+        assert rec.shape == (1, 48) and torch.equal(rec, want)

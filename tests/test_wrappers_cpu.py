@@ -10,32 +10,8 @@ from pf3plat_amd import synthetic
 from pf3plat_amd.rasterizer import GaussianRasterizationSettings, GaussianRasterizer
 from pf3plat_amd.geometry import get_fov, get_projection_matrix
 from pf3plat_amd.types import Gaussians
+from tests.reference_style import reference_style_decoder_forward, reference_style_render
 from tests.util import rel_l2
-
-
-def reference_style_render(ext, intr, near, far, hw, bg, means, cov, sh, op, scale_invariant=True):
-    """Per-view Python loop with explicit torch pre-scaling, exactly the reference's structure."""
-    if scale_invariant:
-        scale = 1 / near
-        ext = ext.clone()
-        ext[..., :3, 3] = ext[..., :3, 3] * scale[:, None]
-        cov = cov * (scale[:, None, None, None] ** 2)
-        means = means * scale[:, None, None]
-        near, far = near * scale, far * scale
-    shs = sh.permute(0, 1, 3, 2).contiguous()
-    fov_x, fov_y = get_fov(intr).unbind(-1)
-    proj = get_projection_matrix(near, far, fov_x, fov_y).transpose(-1, -2)
-    view = ext.inverse().transpose(-1, -2)
-    full = view @ proj
-    row, col = torch.triu_indices(3, 3)
-    imgs = []
-    for i in range(ext.shape[0]):
-        s = GaussianRasterizationSettings(hw[0], hw[1], (0.5 * fov_x[i]).tan().item(), (0.5 * fov_y[i]).tan().item(), bg[i], 1.0,
-                                          view[i], full[i], int(round(sh.shape[-1] ** 0.5)) - 1, ext[i, :3, 3], False, False)
-        img, _ = GaussianRasterizer(s)(means3D=means[i], means2D=torch.zeros_like(means[i], requires_grad=True), shs=shs[i],
-                                       opacities=op[i, ..., None], cov3D_precomp=cov[i][:, row, col])
-        imgs.append(img)
-    return torch.stack(imgs)
 
 
 def _leaves(sc, b):
@@ -71,11 +47,10 @@ def test_fused_decoder_equals_repeat_then_render(oracle_backend):
     (out.color * w).sum().backward()
     assert out.depth is None
     b = _leaves(sc, 1)
-    rep = [x.expand(3, *x.shape[1:]) for x in b]
-    bg = torch.tensor([[0.2, 0.1, 0.0]] * 3)
-    img = reference_style_render(sc.extrinsics[0], sc.intrinsics[0], sc.near[0], sc.far[0], (16, 24), bg, *rep)
-    (img[None] * w).sum().backward()
-    assert rel_l2(out.color.detach().numpy(), img[None].detach().numpy()) < 1e-6
+    img = reference_style_decoder_forward(Gaussians(*b), sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 24),
+                                          torch.tensor([0.2, 0.1, 0.0]))
+    (img * w).sum().backward()
+    assert rel_l2(out.color.detach().numpy(), img.detach().numpy()) < 1e-6
     for x, y, name in zip(a, b, ("means", "cov", "sh", "opac")):
         assert rel_l2(x.grad.numpy(), y.grad.numpy()) < 2e-5, name
 
