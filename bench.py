@@ -690,6 +690,28 @@ def main():
                     "fused_decoder_fwd_ms_per_view": 1e3 * t_fused_sync / 3, "fused_decoder_fwd_bwd_ms": 1e3 * t_fused_fb,
                     "operator_per_view_over_fused_per_view": (t_drop - t_wrapper_only) / t_fused_sync,
                 }
+                # ---- a larger image (the reference's test_splatter.py renders 512 x 512; evaluation runs go higher): one 1024 x 1024
+                # view of the headline scene = 16 384 tiles, through the fused binning launch (up to 20 480 tiles) and through the
+                # six-launch windowed chain forced onto the same image (what images above 20 480 tiles take)
+                sc_l = synthetic.make_scene(2, n, (1024, 1024), d_sh=D_SH)
+                in_l = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc_l))
+                vb_l = synthetic.scene_viewbuf(sc_l).to(dev)
+                large = {}
+                for name_l, fl in (("fused", 0), ("windowed", _gl.FLAG_WINDOWED_BINNING)):
+                    cfg_l = RasterConfig(1, 1, 1, n, 1024, 1024, 4, D_SH, 4, False, fl)
+                    plan_l = be.make_plan(cfg_l, dev, capacity=16 * n)
+                    be.run_forward(plan_l, vb_l, *in_l)
+                    st_l = be.read_status(plan_l)
+                    plan_l = be.make_plan(cfg_l, dev, capacity=be.capacity_for(cfg_l, st_l, headroom=1.1))
+                    t_l = bench_call(lambda: be.run_forward(plan_l, vb_l, *in_l), 40)
+                    assert not be.read_status(plan_l)["overflow"]
+                    nv_l, r16_l = reference_rect_stats(plan_l, cfg_l)
+                    ab_l = algorithmic_bytes(n, nv_l, r16_l, 1024 * 1024, D_SH)["total"]
+                    large[name_l] = {"us_per_view": 1e6 * t_l, "algorithmic_bytes": ab_l, "GBps": ab_l / t_l / 1e9,
+                                     "frac": ab_l / t_l / 1e9 / HBM_PEAK_GBS, "num_pairs_8x8": st_l["num_pairs"]}
+                    del plan_l
+                result["large_image_1024x1024"] = large
+                del in_l, vb_l, sc_l
                 # the training step of configs[2] with camera gradients requested (gsr_backward_ex)
                 d_views = torch.empty((1, 48), dtype=torch.float32, device=dev)
 

@@ -274,7 +274,7 @@ int gsr_image_loss(int num_images, int height, int width, const float* predictio
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.
  * Forward stages, in launch order: 0 the colour pass when it is a launch of its own (gsr_colour_in_binning == 0; otherwise
- * empty: it runs inside stage 1) 1 preprocess (geometry, hit masks and - images of up to 8192 tiles - the whole binning)
+ * empty: it runs inside stage 1) 1 preprocess (geometry, hit masks and - images of up to 20 480 tiles - the whole binning)
  * 2 count + tile scans and 3 emit (windowed binning path only: empty, i.e. one event gap each, otherwise) 4 the tile launch
  * (per tile: gather + sort of its list, then its blend).
  * Backward stages: 0 blend backward 1 preprocess backward. */

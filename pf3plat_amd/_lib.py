@@ -157,7 +157,7 @@ EXPORTED_SYMBOLS = (
     "gsr_colour_in_binning", "gsr_geom_layout", "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
     "gsr_image_loss", "gsr_image_loss_partials", "gsr_pack_view",
 )
-# gsr_forward_profile's stages.  On images of up to 8192 tiles (the fused binning path) "preprocess" is the whole binning
+# gsr_forward_profile's stages.  On images of up to 20 480 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).
 FWD_STAGES = ("color", "preprocess", "count_scan", "emit", "tiles")
 FWD_DEBUG_STAGES = ("colour", "preprocess/binning", "count + scans", "emit", "per-tile sort + blend")

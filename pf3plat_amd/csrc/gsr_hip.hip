@@ -44,7 +44,15 @@ constexpr int kChunkMax = 2048;   // most Gaussians per binning workgroup (= one
 constexpr int kChunkMin = 1024;
 constexpr int kCUs = 256;
 constexpr int kBinThreads = 1024; // threads of a binning workgroup (count / emit)
-constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup (32 KiB)
+constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup of the WINDOWED chain (32 KiB, static)
+#ifndef GSR_FUSED_MAX_TILES
+#define GSR_FUSED_MAX_TILES 20480
+#endif
+// most tiles of an image that takes the fused binning launch (k_preprocess_bin: its per-tile counters are dynamic LDS, T x 4 bytes
+// next to the 64 KB record-transpose / pair-staging area and ~10 KB of static LDS); larger images take the windowed chain.
+// (Round 2 stopped at 8192; one 1024 x 1024 view of the 300 k scene: 236 us through the windowed chain, 187 us this way.)
+constexpr int kFusedMaxTiles = GSR_FUSED_MAX_TILES;
+static_assert(kFusedMaxTiles % 1024 == 0 && kFusedMaxTiles >= kTileWindow && 65536 + kFusedMaxTiles * 4 + 10400 <= 160 * 1024, "LDS of the fused binning launch");
 constexpr int kSortThreads = 256; // threads cooperating on one tile's sort
 constexpr int kPage = 1024;        // pairs per page of the key buffer: a binning workgroup's private region is whole pages
 constexpr int kSlotStride = 8192 + 136;  // keys between the fixed slots of consecutive binning workgroups: NOT a multiple of the memory
@@ -115,7 +123,7 @@ static Layout make_layout(const GsrDims& d) {
   const Grid g = make_grid(d.width, d.height);
   const size_t V = d.num_views, N = d.num_gaussians, VT = V * (size_t)g.T;
   const size_t cap = d.pair_capacity > 0 ? (size_t)d.pair_capacity : 0;
-  const bool windowed = g.T > kTileWindow || (d.flags & GSR_FLAG_WINDOWED_BINNING) != 0;
+  const bool windowed = g.T > kFusedMaxTiles || (d.flags & GSR_FLAG_WINDOWED_BINNING) != 0;
   // every sub-array of `geom` starts on a 2 MiB boundary: the backward kernels gather / scatter by Gaussian index into three of
   // them at once, and with the arrays packed at 256-byte granularity the 300 k-Gaussian training step was 2-3 us slower for
   // some sizes of the first array than for others (measured: 143.5-144.2 us packed, 141.4-142.6 aligned)
@@ -1268,11 +1276,11 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   __syncthreads();
   GSR_STAMP(1);
   // ---- 2. exclusive scan of the histogram over the tiles (thread t owns `per` consecutive tiles)
-  const int per = (T + kBinThreads - 1) / kBinThreads;  // <= kTileWindow / kBinThreads
+  const int per = (T + kBinThreads - 1) / kBinThreads;  // <= kFusedMaxTiles / kBinThreads
   const int b0 = tid * per;
-  uint32_t cnt[kTileWindow / kBinThreads], sum = 0;
+  uint32_t cnt[kFusedMaxTiles / kBinThreads], sum = 0;
 #pragma unroll
-  for (int q = 0; q < kTileWindow / kBinThreads; ++q) {
+  for (int q = 0; q < kFusedMaxTiles / kBinThreads; ++q) {
     cnt[q] = (q < per && b0 + q < T) ? hist[b0 + q] : 0u;
     sum += cnt[q];
   }
@@ -1302,7 +1310,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   uint2* mrow = p.pair_mat + ((size_t)v * p.rows + row) * (T + 8);  // + 8: a column must not sit on one memory channel
   uint32_t run = basew + incl - sum;
 #pragma unroll
-  for (int q = 0; q < kTileWindow / kBinThreads; ++q)
+  for (int q = 0; q < kFusedMaxTiles / kBinThreads; ++q)
     if (q < per && b0 + q < T) {
       mrow[b0 + q] = make_uint2(run, cnt[q]);
       hist[b0 + q] = run;  // from here on: the tile's cursor inside the region
@@ -3261,7 +3269,7 @@ static int ensure_bin_attributes(int* dev_out) {
   if (dev_out) *dev_out = dev;
   const unsigned long long bit = 1ull << (dev & 63);
   if (g_lds_set.load(std::memory_order_acquire) & bit) return GSR_OK;
-  const int plain = (int)bin_lds_bytes(kTileWindow, false), with_color = 160 * 1024 - 10400;
+  const int plain = (int)bin_lds_bytes(kFusedMaxTiles, false), with_color = 160 * 1024 - 10400;
   GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, plain));
   const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess &&
                   hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess;
@@ -3271,7 +3279,7 @@ static int ensure_bin_attributes(int* dev_out) {
   return GSR_OK;
 }
 static bool color_in_bin_for(const GsrDims& d, const Grid& g, int dev) {
-  const bool fused_bin = g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
+  const bool fused_bin = g.T <= kFusedMaxTiles && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
   // tasks for its five colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
 #ifndef GSR_CIB_MAX_VPS
@@ -3394,7 +3402,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   // blend.  Larger images: the colour pass as its own first launch (k_color), then the binning chain, then the tile launch.
   // Binning: images of up to kTileWindow tiles take the fused path (k_preprocess_bin, the tile launch gathers);
   // larger ones the windowed path (preprocess, count, prefix, scan, emit, then the tile launch).
-  const bool fused_bin = p.g.T <= kTileWindow && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
+  const bool fused_bin = p.g.T <= kFusedMaxTiles && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
   int dev = 0;
   {
     const int rc = ensure_bin_attributes(&dev);

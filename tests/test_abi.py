@@ -181,7 +181,7 @@ def test_geom_sub_arrays_never_overlap_and_fit_the_reported_size():
         g = be.workspace_sizes(dims)[0]
         gl = be.geom_layout(dims)
         t8 = 4 * ((w + 15) // 16) * ((h + 15) // 16)
-        windowed = bool(flags & _lib.FLAG_WINDOWED_BINNING) or t8 > 8192
+        windowed = bool(flags & _lib.FLAG_WINDOWED_BINNING) or t8 > 20480
         assert gl["record_bytes"] == 32
         end = v * n * 32
         if windowed:

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _scene_case(seed, n, hw, views=1, use_sh=True, with_extra=True, grads=True, d_sh=25, scale_invariant=True, near=1.0,
-                view_offsets=None, extra_mode=0):
+                view_offsets=None, extra_mode=0, flags=0):
     sc = synthetic.make_scene(seed, n, hw, num_views=views, d_sh=d_sh, near=near, view_offsets=view_offsets)
     means, cov6, opac, colors = gpu_util.scene_tensors(sc, use_sh)
     vb = gpu_util.scene_viewbuf(sc, scale_invariant)
@@ -22,7 +22,7 @@ def _scene_case(seed, n, hw, views=1, use_sh=True, with_extra=True, grads=True, 
     rng = np.random.default_rng(seed)
     extra = torch.tensor(rng.uniform(0.5, 2.0, (views, n)).astype(np.float32)) if (with_extra and not extra_mode) else None
     deg = int(round(d_sh ** 0.5)) - 1
-    cfg = RasterConfig(views, 1, views, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, extra_mode << 4)
+    cfg = RasterConfig(views, 1, views, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, (extra_mode << 4) | flags)
     gc = torch.tensor(rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32)) if grads else None
     ge = torch.tensor(rng.uniform(0, 1, (views, h, w)).astype(np.float32)) if (grads and with_extra) else None
     return cfg, gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge)
@@ -505,12 +505,41 @@ def test_forward_chain_replays_from_a_hip_graph():
 
 
 # ------------------------------------------------------------------ launch-path coverage: every binning variant the host code can pick
-def test_image_with_more_than_8192_tiles_uses_windowed_count_and_separate_scan():
-    """776 x 776 => 98 x 98 = 9604 8x8 tiles > the 8192-tile LDS window: k_preprocess + k_count (two windows) + k_tile_scan +
-    k_emit<false> instead of the fused kernels."""
-    cfg, res = _scene_case(21, 3000, (776, 776), with_extra=False)
-    assert cfg.height * cfg.width // 64 > 8192
-    _all_checks(cfg, res, max_tiles=128)
+def test_image_with_more_tiles_than_the_fused_binning_takes_uses_windowed_count_and_separate_scan():
+    """1456 x 1000 => 182 x 126 = 22 932 8x8 tiles > the 20 480 the fused binning launch histograms in LDS: k_preprocess + k_count
+    (three 8192-tile windows) + k_tile_prefix + k_tile_scan + k_emit<false> + the contiguous tile launch.  A scene dense enough
+    that no single flipped pixel decides a gradient row: strict (1e-4 over ALL pixels and ALL rows, nothing set aside)."""
+    cfg, res = _scene_case(21, 60000, (1000, 1456), with_extra=False)
+    assert 4 * ((cfg.height + 15) // 16) * ((cfg.width + 15) // 16) > 20480
+    assert res["hip"]["ws"]["depth"] is not None  # the footprint words are kept only by the windowed chain
+    _all_checks(cfg, res, max_tiles=128, strict=True)
+
+
+def test_300k_gaussians_at_1024x1024_fused_binning_above_8192_tiles():
+    """16 384 tiles: above the 8192-tile window of round 2, now inside the fused binning launch (per-tile counters in dynamic
+    LDS up to 20 480 tiles; colour pass as a launch of its own).  Headline Gaussian count, forward + backward, strict."""
+    cfg, res = _scene_case(2, 300000, (1024, 1024), with_extra=False)
+    assert res["hip"]["ws"]["depth"] is None  # fused path: no footprint words in memory
+    _all_checks(cfg, res, max_tiles=64, strict=True)
+    assert res["hip"]["status"]["num_pairs"] > 1_000_000
+
+
+def test_windowed_chain_at_scale_300k_gaussians_1024x1024():
+    """The six-launch windowed chain (k_color, k_preprocess, k_count over two windows, k_tile_prefix, k_tile_scan / k_emit, contiguous
+    tile launch) forced on the same 300 k / 1024 x 1024 case: strict against the oracle, and the same per-tile lists and the same
+    image as the fused path."""
+    from pf3plat_amd import _lib
+
+    cfg_w, res_w = _scene_case(2, 300000, (1024, 1024), with_extra=False, flags=_lib.FLAG_WINDOWED_BINNING)
+    assert res_w["hip"]["ws"]["depth"] is not None
+    _all_checks(cfg_w, res_w, max_tiles=64, strict=True)
+    cfg_f, res_f = _scene_case(2, 300000, (1024, 1024), with_extra=False, grads=False)
+    wa, wb = res_f["hip"]["ws"], res_w["hip"]["ws"]
+    assert wa["num_pairs"] == wb["num_pairs"] and wa["max_list"] == wb["max_list"]
+    np.testing.assert_array_equal(res_f["hip"]["color"], res_w["hip"]["color"])
+    for t in range(0, wa["T"], 97):
+        (a0, a1), (b0, b1) = wa["ranges"][0, t], wb["ranges"][0, t]
+        np.testing.assert_array_equal(wa["point_list"][a0:a1], wb["point_list"][b0:b1])
 
 
 def test_windowed_binning_path_on_a_small_image_matches_the_fused_one():

@@ -35,5 +35,6 @@ n = 300000
 offs = torch.randn(8, generator=torch.Generator().manual_seed(8)).mul(0.05).tolist()
 out = [run("8x256^2", RasterConfig(8, 1, 8, n, 256, 256, 4, 25, 4, False), synthetic.make_scene(2, n, (256, 256), d_sh=25, num_views=8, view_offsets=offs)),
        run("1x512^2", RasterConfig(1, 1, 1, n, 512, 512, 4, 25, 4, False), synthetic.make_scene(2, n, (512, 512), d_sh=25)),
+       run("1x1024^2", RasterConfig(1, 1, 1, n, 1024, 1024, 4, 25, 4, False), synthetic.make_scene(2, n, (1024, 1024), d_sh=25)),
        run("3x256^2/131k", RasterConfig(3, 1, 3, 131072, 256, 256, 4, 25, 4, False), synthetic.make_scene(50, 131072, (256, 256), d_sh=25, num_views=3))]
 print(f"{sys.argv[1]:10s} " + " | ".join(out))
