@@ -156,6 +156,9 @@ def main():
     ap.add_argument("--preheat-ms", type=float, default=300.0,
                     help="untimed: run the step for this long before the W warm-up steps so that the shader clock has ramped "
                          "(a 20-step window after 50 ms of idle is 10-15 %% slow on MI355X: tools/clock_probe.py)")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE configs[4] as the timed workload instead of configs[1]: one DL3DV-shaped scene per GPU (seed 50 + rank, "
+                         "131 072 Gaussians, 2 context -> 1 target view), ONE fused all-gather of the rendered views at the end")
     ap.add_argument("--headline-only", action="store_true", help="stop after the timed region (for rocprofv3 runs of the headline loop alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gaussians", type=int, default=N_GAUSS, help=argparse.SUPPRESS)
@@ -187,7 +190,10 @@ def main():
     from pf3plat_amd.rasterizer import HipBackend, RasterConfig
 
     K, Wm, n = args.steps, args.warmup, args.gaussians
-    scene = synthetic.make_scene(2 + rank, n, (H, W), d_sh=D_SH)
+    seed0 = 2
+    if args.config5:  # reference assets/evaluation_index_dl3dv_10view.json: 2 context views (2 x 256 x 256 Gaussians) -> 1 target
+        n, seed0 = 131072, 50
+    scene = synthetic.make_scene(seed0 + rank, n, (H, W), d_sh=D_SH)
     means, cov6, opac, shs = (t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(scene))
     viewbuf = synthetic.scene_viewbuf(scene).to(dev)
     cfg = RasterConfig(1, 1, 1, n, H, W, 4, D_SH, 4, False)
@@ -259,7 +265,7 @@ def main():
     # The exchange is cut into up to 8 chunks of consecutive steps; a chunk's all-gather is issued (async, RCCL's own
     # stream) as soon as its last view is enqueued and overlaps the rendering of the next chunk - only the last chunk's
     # gather is exposed.  Every view is rendered straight into its slot of `views` (no copy).
-    n_chunks = min(8, max(1, K // 8)) if world > 1 else 0
+    n_chunks = (1 if args.config5 else min(8, max(1, K // 8))) if world > 1 else 0
     bounds = [round(c * K / n_chunks) for c in range(n_chunks + 1)] if n_chunks else []
     # one (world, chunk, 3, H, W) destination per chunk: all_gather_into_tensor writes rank r's chunk at [r] (no list of slices,
     # which the RCCL backend would serve through a flat temporary and a copy)
@@ -337,14 +343,66 @@ def main():
     assert not status["overflow"], status
     launch_mode = "eager"
     eager_dt = dt
+    gather_check = None
+    if world > 1:
+        # what arrived: rank r's LAST rendered view must sit at [r] of the gathered tensor (every rank renders its own scene, so
+        # the checksums differ and a permuted or stale slot shows)
+        box = [None] * world
+        dist.all_gather_object(box, float(views[K - 1].double().sum().item()))
+        sums = [torch.tensor([x], dtype=torch.float64) for x in box]
+        got = []
+        for r in range(world):
+            if all_views is not None:
+                got.append(float(all_views[-1][r, -1].double().sum().item()))
+            else:
+                got.append(float(gathered[-1].reshape(world, K, 3, H, W)[r, K - 1].double().sum().item()))
+        want = [float(t.item()) for t in sums]
+        gather_check = {"ok": all(abs(a - b) <= 1e-6 * max(1.0, abs(b)) for a, b in zip(got, want)) and len(set(round(x, 3) for x in want)) == world,
+                        "last_view_checksum_per_rank": want, "gathered_slot_checksums": got}
+
+    def config5_leg():
+        """BASELINE configs[4] next to the weak-scaled headline: 8 scenes of 131 072 Gaussians (seed 50 + rank), one target view each,
+        K views per rank rendered into one buffer, ONE fused all_gather_into_tensor at the end (reference parallelism: one scene per
+        GPU, src/main.py:109).  Same protocol (W warm-ups, K timed, barriers, MAX over ranks)."""
+        n5 = 131072
+        sc5 = synthetic.make_scene(50 + rank, n5, (H, W), d_sh=D_SH)
+        in5 = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc5))
+        vb5 = synthetic.scene_viewbuf(sc5).to(dev)
+        cfg5 = RasterConfig(1, 1, 1, n5, H, W, 4, D_SH, 4, False)
+        p5 = be.make_plan(cfg5, dev, capacity=8 * n5)
+        be.run_forward(p5, vb5, *in5)
+        p5 = be.make_plan(cfg5, dev, capacity=be.capacity_for(cfg5, be.read_status(p5), headroom=1.1))
+        v5 = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev)
+        out5 = torch.empty((world, K, 3, H, W), dtype=torch.float32, device=dev) if backend == "nccl" else None
+        for _ in range(max(Wm, 5) + 200):
+            be.run_forward(p5, vb5, *in5)
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K):
+            be.run_forward(p5, vb5, *in5, out_color=v5[i:i + 1])
+        if out5 is not None:
+            dist.all_gather_into_tensor(out5, v5)
+        else:
+            gather_views(v5)
+        barrier()
+        dt5 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(dt5, op=dist.ReduceOp.MAX)
+        assert not be.read_status(p5)["overflow"]
+        return {"workload": f"configs[4]: {world} scenes x {n5} Gaussians (seed 50 + rank), 1 target view each per step, one fused "
+                            f"all_gather_into_tensor of the {K} x {world} views at the end",
+                "views_per_s": world * K / float(dt5.item()), "ms_per_step": 1e3 * float(dt5.item()) / K}
+
+    config5 = config5_leg() if (world > 1 and not args.config5) else None
 
     result = {
         "metric": "rendered views/sec, 300k Gaussians @ 256x256 (fwd raster); bwd ms and HBM GB/s vs roofline alongside",
         "value": world * K / dt, "unit": "views/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": 1e3 * dt / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"configs[1]: {n} Gaussians (SH degree 4, 25 coeffs), 1 view {H}x{W}, fwd-only raster, "
-                               "one scene per GPU (seed 2+rank), inputs resident in HBM",
+        "config": {"workload": (f"configs[4]: one DL3DV-shaped scene per GPU (seed 50+rank, {n} Gaussians, SH degree 4), 1 target view {H}x{W}, "
+                                "fwd-only raster, inputs resident in HBM" if args.config5 else
+                                f"configs[1]: {n} Gaussians (SH degree 4, 25 coeffs), 1 view {H}x{W}, fwd-only raster, "
+                                "one scene per GPU (seed 2+rank), inputs resident in HBM"),
                    "launch": launch_mode,
                    "parallelism": f"views sharded 1 scene/GPU x{world}" + (f", RCCL all-gather of the {K} x {world} rendered views in {n_chunks} batches overlapped with rendering, the last one at the end" if world > 1 else ""),
                    "camera_setup": "excluded (gsr_setup_views runs once before the loop; ~4 us per batch of views)",
@@ -353,6 +411,9 @@ def main():
     if world > 1:
         result["rccl_ranks"] = ranks_seen
         result["dist_backend"] = backend
+        result["gather_check"] = gather_check
+        if config5 is not None:
+            result["config5"] = config5
     result["config"]["preheat"] = (f"{preheat_steps} untimed steps (~{args.preheat_ms:.0f} ms) before the {Wm} warm-up steps: MI355X leaves its "
                                    "low-power state only after some hundred steps (tools/clock_probe.py; profiles/r03_clock_probe.txt)")
     if clocks is not None:

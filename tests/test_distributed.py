@@ -102,3 +102,31 @@ def test_gather_is_identity_without_process_group():
     x = torch.arange(6.0).reshape(2, 3)
     assert gather_views(x) is x
     reduce_gaussian_grads([x])  # no-op
+
+
+@pytest.mark.gpu
+def test_bench_py_two_ranks_on_one_gpu_real_hip_path():
+    """The N > 1 code of bench.py with the REAL HIP path: two ranks launched exactly as the driver launches them
+    (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`), both on the one GPU of the box, the exchange on
+    gloo (BENCH_DIST_BACKEND: RCCL needs one GPU per rank).  Checks what the first real multi-GPU run must also show: the
+    collective saw both ranks, every rank's last view sits in ITS slot of the gathered tensor (the scenes differ per rank, so do
+    the checksums), the whole-job value counts both ranks, and the config-5 leg (one fused gather at the end) ran."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "16", "--warmup", "3",
+           "--preheat-ms", "20", "--gaussians", "60000"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["gather_check"]["ok"], d["gather_check"]
+    a, b = d["gather_check"]["last_view_checksum_per_rank"]
+    assert abs(a - b) > 1.0  # two different scenes
+    assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert d["config5"]["views_per_s"] > 0 and "one fused" in d["config5"]["workload"]
