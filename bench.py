@@ -133,6 +133,19 @@ def pmc_traffic(kernels, n, mode="fwd"):
                 "write_size_raw_bytes": raw[k]["WRITE_SIZE"]} for k in kernels}
 
 
+def usable_cores():
+    """Host threads this process may really run at once: the CPUs of its affinity mask, capped by the cgroup CPU quota (the GPU
+    boxes show 256 CPUs under a quota of 16: more OpenMP threads than that are throttled, not run)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def device_clocks():
     """{"sclk": MHz, "mclk": MHz} of GPU 0 as rocm-smi reports them right now (None if it cannot be asked)."""
     import re
@@ -605,31 +618,80 @@ def main():
              "traffic_over_algorithmic": None if traffic is None else round(traffic[KERNELS[k_]]["traffic"] / kb[k_], 3)}
             for k_ in chain_stages + ("blend_bwd", "preprocess_bwd")]
 
-        # ---- CPU baseline (the oracle = "port"; the reference has no CPU splatting path) + parity spot check
-        if world == 1 and not args.no_cpu_baseline:
-            from tests.oracle_backend import OracleBackend
-            from oracle import load_oracle
+        # ---- CPU baseline (the oracle = "port"; the reference has no CPU splatting path) + parity spot check.
+        # one thread and all cores, configs 1-3, and the reference's own pure-torch point projector
+        # (src/geometry/projection.py:59-71) as a micro-baseline.  Bounded: ~15-25 s of CPU work in all.
+        if world == 1 and not args.no_cpu_baseline and not args.config5:
+            from oracle import OracleRasterizer, load_oracle
 
-            cores = max(1, min(os.cpu_count() or 1, load_oracle().gsro_max_threads()))
-            cpu_args = tuple(t.cpu() for t in (means, cov6, opac, shs))
-            ob1 = OracleBackend(threads=1)
-            t0 = time.perf_counter()
-            oc, _, _, _ = ob1.forward(cfg, viewbuf.cpu(), *cpu_args, None)
-            t1 = time.perf_counter() - t0
-            obn = OracleBackend(threads=cores)
-            reps_cpu, tn = 0, 0.0
-            while tn < 8.0 and reps_cpu < 8:
+            cores = max(1, min(usable_cores(), load_oracle().gsro_max_threads()))
+
+            def oracle_case(seed, n_c, hw_c, backward, budget_s, max_reps):
+                """Views/s of the fp32 oracle on 1 thread and on all cores: inputs prepared once as the arrays the C++ reads (no
+                per-call conversion; the harmonics are read in place), forward (+ backward: dense seeded dL/dcolor) per rep."""
+                sc_c = synthetic.make_scene(seed, n_c, hw_c, d_sh=D_SH)
+                m_c, c_c, o_c, s_c = (np.ascontiguousarray(t[0].numpy()) for t in synthetic.scene_operator_inputs(sc_c))
+                from tests.gpu_util import scene_viewbuf as cpu_viewbuf  # camera records by the oracle's own arithmetic (CPU)
+
+                vb_c = cpu_viewbuf(sc_c)[0].numpy()
+                kw = dict(height=hw_c[0], width=hw_c[1], tanfovx=float(vb_c[35]), tanfovy=float(vb_c[36]), bg=vb_c[37:40],
+                          viewmatrix=vb_c[0:16], projmatrix=vb_c[16:32], campos=vb_c[32:35], sh_degree=4, means3D=m_c,
+                          opacities=o_c, cov3D_precomp=c_c, shs=s_c, borrow_sh=True)
+                g_c = np.random.default_rng(3).uniform(0, 1, (3, *hw_c)).astype(np.float32)
+                out = {}
+                res0 = None
+                for label, th in (("one_thread", 1), ("all_cores", cores)):
+                    o_r = OracleRasterizer(np.float32, threads=th)
+                    reps_c, t_c = 0, 0.0
+                    while reps_c < 1 or (t_c < budget_s and reps_c < max_reps):
+                        t0 = time.perf_counter()
+                        r_c = o_r.forward(**kw)
+                        if backward:
+                            o_r.backward(g_c)
+                        t_c += time.perf_counter() - t0
+                        reps_c += 1
+                    out[label] = {"views_per_s": reps_c / t_c, "ms_per_view": 1e3 * t_c / reps_c, "reps": reps_c}
+                    if res0 is None:
+                        res0 = r_c
+                out["speedup"] = out["all_cores"]["views_per_s"] / out["one_thread"]["views_per_s"]
+                return out, res0
+
+            c1, _ = oracle_case(1, 1000, (64, 64), True, 0.5, 50)
+            c2, res2 = oracle_case(2, n, (H, W), False, 3.0, 40)
+            c3, _ = oracle_case(3, n, (H, W), True, 5.0, 12)
+            assert (res2.n_visible, res2.r16) == (nv, r16), ((res2.n_visible, res2.r16), (nv, r16))
+            oc = torch.from_numpy(res2.color)[None]
+            # the reference's pure-torch projector on the same 300 k means (world -> camera, perspective divide, intrinsics): what
+            # PF3plat can do on a CPU without the CUDA extension - a point projector, no splatting
+            pts = torch.from_numpy(np.ascontiguousarray(scene.gaussians.means[0].numpy()))
+            ext_c, k_c = scene.extrinsics[0, 0], scene.intrinsics[0, 0]
+
+            def project_points():
+                cam_pts = (torch.nn.functional.pad(pts, (0, 1), value=1.0) @ ext_c.inverse().T)[:, :3]
+                in_front = cam_pts[:, 2] >= 0
+                xy = (cam_pts / (cam_pts[:, 2:] + torch.finfo(torch.float32).eps)).nan_to_num(posinf=1e8, neginf=-1e8) @ k_c.T
+                return xy[:, :2], in_front
+
+            proj = {}
+            nthreads0 = torch.get_num_threads()
+            for label, th in (("one_thread", 1), ("all_cores", cores)):
+                torch.set_num_threads(th)
+                project_points()
                 t0 = time.perf_counter()
-                obn.forward(cfg, viewbuf.cpu(), *cpu_args, None)
-                tn += time.perf_counter() - t0
-                reps_cpu += 1
-            st_o = ob1.last_stats[0]
-            assert (st_o.n_visible, st_o.r16) == (nv, r16), ((st_o.n_visible, st_o.r16), (nv, r16))
+                for _ in range(20):
+                    project_points()
+                proj[label + "_ms"] = 1e3 * (time.perf_counter() - t0) / 20
+            torch.set_num_threads(nthreads0)
             result["cpu_baseline"] = {
-                "value": reps_cpu / tn, "unit": "views/s", "cores": cores, "kind": "port",
-                "sample": f"{reps_cpu} forward views of the same 300k/256x256 scene on {cores} threads (oracle C++ fp32, "
-                          f"OpenMP; includes the host-side copy of inputs); 1 thread: {1.0 / t1:.3f} views/s",
-                "one_thread_views_per_s": 1.0 / t1}
+                "value": c2["all_cores"]["views_per_s"], "unit": "views/s", "cores": cores, "kind": "port",
+                "sample": f"{c2['all_cores']['reps']} forward views of the same 300k/256x256 scene (configs[1]) on {cores} threads: the oracle, C++ fp32, "
+                          "OpenMP over Gaussians (preprocess), over chunks and tiles (counting sort + per-tile depth sort) and over tiles "
+                          f"(blend); inputs prepared once; 1 thread: {c2['one_thread']['views_per_s']:.3f} views/s",
+                "one_thread_views_per_s": c2["one_thread"]["views_per_s"],
+                "configs": {"config1_1k_64x64_fwd_bwd": c1, "config2_300k_256x256_fwd": c2, "config3_300k_256x256_fwd_bwd": c3},
+                "mean_projection_micro_baseline": dict(proj, points=int(pts.shape[0]),
+                                                       note="torch CPU restatement of the reference's project() (src/geometry/projection.py:59-71): "
+                                                            "world->camera, divide, intrinsics; no covariance, no binning, no blending")}
             be.run_forward(plan, viewbuf, means, cov6, opac, shs)
             torch.cuda.synchronize()
             hc = plan["color"].cpu().numpy()

@@ -29,7 +29,8 @@ void* forward(const int* dims, const R* view, const R* proj, const R* campos, R 
   auto* h = new Handle<R>();
   State<R>& s = h->s;
   s.d.P = dims[0]; s.d.H = dims[1]; s.d.W = dims[2]; s.d.D = dims[3]; s.d.M = dims[4];
-  s.d.max_sh_eval = dims[5]; s.d.prefiltered = dims[6]; s.d.use_scale_rot = dims[7];
+  s.d.max_sh_eval = dims[5]; s.d.prefiltered = dims[6] & 1; s.d.use_scale_rot = dims[7];
+  const bool borrow_sh = (dims[6] & 2) != 0;  // the caller keeps the SH array alive until the handle is freed: no 300 B/Gaussian copy
   const size_t P = s.d.P;
   std::memcpy(s.cam.view, view, 16 * sizeof(R));
   std::memcpy(s.cam.proj, proj, 16 * sizeof(R));
@@ -40,7 +41,8 @@ void* forward(const int* dims, const R* view, const R* proj, const R* campos, R 
   if (s.d.use_scale_rot) { s.scales.assign(scales, scales + 3 * P); s.rots.assign(rots, rots + 4 * P); }
   else s.cov6.assign(cov6, cov6 + 6 * P);
   s.opac.assign(opac, opac + P);
-  if (s.d.M > 0) s.shs.assign(sh_or_rgb, sh_or_rgb + (size_t)s.d.M * 3 * P);
+  if (s.d.M > 0 && borrow_sh) s.shs_ptr = sh_or_rgb;
+  else if (s.d.M > 0) { s.shs.assign(sh_or_rgb, sh_or_rgb + (size_t)s.d.M * 3 * P); s.shs_ptr = s.shs.data(); }
   else s.colors_precomp.assign(sh_or_rgb, sh_or_rgb + 3 * P);
   if (extra) { s.extra.assign(extra, extra + P); h->has_extra = true; }
   omp_set_num_threads(std::max(1, threads));

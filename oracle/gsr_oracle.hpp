@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <omp.h>
 #include <vector>
 
 namespace gsro {
@@ -72,6 +73,7 @@ struct State {
   Camera<R> cam;
   // copies of the inputs (backward re-reads them, as upstream does)
   std::vector<R> means, cov6, opac, shs, colors_precomp, extra, scales, rots;
+  const R* shs_ptr = nullptr;  // the harmonics: shs.data(), or the caller's array (borrowed: the 90 MB copy at 300 k Gaussians is skipped)
   // geometry state ([EXT] rasterizer_impl.h GeometryState)
   std::vector<R> depth, xy, conic_opacity, rgb, cov6_used;
   std::vector<uint8_t> clamped;
@@ -315,7 +317,7 @@ void preprocess(State<R>& s) {
       dir[0] /= len; dir[1] /= len; dir[2] /= len;
       R b[25];
       const int n = sh_basis(deg, dir[0], dir[1], dir[2], b);
-      const R* sh = &s.shs[(size_t)i * d.M * 3];
+      const R* sh = &s.shs_ptr[(size_t)i * d.M * 3];
       for (int ch = 0; ch < 3; ++ch) {
         R acc = 0;
         for (int k = 0; k < n && k < d.M; ++k) acc += b[k] * sh[3 * k + ch];
@@ -346,27 +348,54 @@ void preprocess(State<R>& s) {
 // over keys emitted in index order).
 template <class R>
 void bin(State<R>& s) {
+  // Same result as one stable sort of all (tile, depth) keys emitted in index order - a counting sort by tile (count, prefix,
+  // emission in index order: stable) and then a stable sort by depth inside every tile - but the per-tile sorts are independent,
+  // so they run under OpenMP (the single std::stable_sort of 852 k keys was two thirds of the all-core forward time).
   const Dims& d = s.d;
   const int gridx = (d.W + kTile - 1) / kTile, gridy = (d.H + kTile - 1) / kTile;
-  struct Key { uint32_t tile; R depth; uint32_t id; };
-  std::vector<Key> keys;
-  keys.reserve((size_t)s.R16);
-  for (int i = 0; i < d.P; ++i) {
-    if (s.radii[i] <= 0) continue;
-    const int* r = &s.rect[4 * (size_t)i];
-    for (int y = r[1]; y < r[3]; ++y)
-      for (int x = r[0]; x < r[2]; ++x) keys.push_back({(uint32_t)(y * gridx + x), s.depth[i], (uint32_t)i});
+  const size_t T = (size_t)gridx * gridy;
+  struct Key { R depth; uint32_t id; };
+  // counting sort by tile, the Gaussians cut into one contiguous chunk per thread: chunk c counts into its own row of `cnt`, a
+  // prefix over (tile, chunk) gives every chunk its cursor inside every tile's list, and the emission keeps index order
+  const int C = std::max(1, omp_get_max_threads());
+  const int P = d.P, per = (P + C - 1) / C;
+  std::vector<uint32_t> cnt((size_t)C * T, 0u), start(T + 1, 0u);
+#pragma omp parallel for schedule(static, 1)
+  for (int c = 0; c < C; ++c) {
+    uint32_t* my = &cnt[(size_t)c * T];
+    for (int i = c * per; i < std::min(P, (c + 1) * per); ++i) {
+      if (s.radii[i] <= 0) continue;
+      const int* r = &s.rect[4 * (size_t)i];
+      for (int y = r[1]; y < r[3]; ++y)
+        for (int x = r[0]; x < r[2]; ++x) ++my[(size_t)y * gridx + x];
+    }
   }
-  std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) {
-    if (a.tile != b.tile) return a.tile < b.tile;
-    return a.depth < b.depth;
-  });
+  for (size_t t = 0; t < T; ++t) {
+    uint32_t run = start[t];
+    for (int c = 0; c < C; ++c) { const uint32_t n = cnt[(size_t)c * T + t]; cnt[(size_t)c * T + t] = run; run += n; }
+    start[t + 1] = run;
+  }
+  std::vector<Key> keys(start[T]);
+#pragma omp parallel for schedule(static, 1)
+  for (int c = 0; c < C; ++c) {
+    uint32_t* cursor = &cnt[(size_t)c * T];
+    for (int i = c * per; i < std::min(P, (c + 1) * per); ++i) {
+      if (s.radii[i] <= 0) continue;
+      const int* r = &s.rect[4 * (size_t)i];
+      for (int y = r[1]; y < r[3]; ++y)
+        for (int x = r[0]; x < r[2]; ++x) keys[cursor[(size_t)y * gridx + x]++] = {s.depth[i], (uint32_t)i};
+    }
+  }
   s.point_list.resize(keys.size());
-  s.ranges.assign(2 * (size_t)gridx * gridy, 0);
-  for (size_t k = 0; k < keys.size(); ++k) {
-    s.point_list[k] = keys[k].id;
-    if (k == 0 || keys[k].tile != keys[k - 1].tile) s.ranges[2 * keys[k].tile] = (uint32_t)k;
-    if (k + 1 == keys.size() || keys[k].tile != keys[k + 1].tile) s.ranges[2 * keys[k].tile + 1] = (uint32_t)(k + 1);
+  s.ranges.assign(2 * T, 0);
+#pragma omp parallel for schedule(dynamic, 8)
+  for (long long t = 0; t < (long long)T; ++t) {
+    const uint32_t b = start[t], e = start[t + 1];
+    if (b == e) continue;
+    std::stable_sort(keys.begin() + b, keys.begin() + e, [](const Key& a, const Key& c) { return a.depth < c.depth; });
+    for (uint32_t k = b; k < e; ++k) s.point_list[k] = keys[k].id;
+    s.ranges[2 * (size_t)t] = b;
+    s.ranges[2 * (size_t)t + 1] = e;
   }
 }
 
@@ -455,10 +484,20 @@ void blend_backward(const State<R>& s, const R* dL_dpix, const R* dL_dextra_pix,
   g.dcolor.assign(3 * (size_t)P, 0); g.dextra.assign(P, 0);
   const bool has_extra = dL_dextra_pix != nullptr && !s.extra.empty();
   const R ddelx_dx = R(0.5) * R(W), ddely_dy = R(0.5) * R(H);
+  // par: every tile first sums its 256 pixels' contributions per list entry in a buffer of its own (10 values per entry) and adds
+  // the entry sums to the per-Gaussian arrays once - one atomic per (tile, splat, value) instead of one per (pixel, splat, value),
+  // which is what kept the all-core backward from scaling.  One thread: the sums go straight to the arrays, in pixel order
+  // (deterministic; the order every fp32-vs-fp64 and golden-statistics test was recorded with).
 #pragma omp parallel for schedule(dynamic, 1) if (par)
   for (int tile = 0; tile < gridx * gridy; ++tile) {
     const int tx = tile % gridx, ty = tile / gridx;
     const uint32_t r0 = s.ranges[2 * (size_t)tile], r1 = s.ranges[2 * (size_t)tile + 1];
+    std::vector<R> loc;
+    if (par) loc.assign((size_t)(r1 - r0) * 10, R(0));
+    auto acc = [&](R* global, uint32_t k, int slot, R v) {
+      if (par) loc[(size_t)(k - r0) * 10 + slot] += v;
+      else *global += v;
+    };
     for (int ly = 0; ly < kTile; ++ly)
       for (int lx = 0; lx < kTile; ++lx) {
         const int px = tx * kTile + lx, py = ty * kTile + ly;
@@ -492,8 +531,8 @@ void blend_backward(const State<R>& s, const R* dL_dpix, const R* dL_dextra_pix,
             accum_rec[ch] = last_alpha * last_color[ch] + (R(1) - last_alpha) * accum_rec[ch];
             last_color[ch] = c;
             dL_dalpha += (c - accum_rec[ch]) * dpix[ch];
-            if (ch < 3) atomic_add(&g.dcolor[3 * (size_t)gi + ch], dchannel_dcolor * dpix[ch], par);
-            else atomic_add(&g.dextra[gi], dchannel_dcolor * dpix[ch], par);
+            if (ch < 3) acc(&g.dcolor[3 * (size_t)gi + ch], k, 6 + ch, dchannel_dcolor * dpix[ch]);
+            else acc(&g.dextra[gi], k, 9, dchannel_dcolor * dpix[ch]);
           }
           dL_dalpha *= T;
           last_alpha = alpha;
@@ -504,13 +543,26 @@ void blend_backward(const State<R>& s, const R* dL_dpix, const R* dL_dextra_pix,
           const R gdx = G * dx, gdy = G * dy;
           const R dG_ddelx = -gdx * co[0] - gdy * co[1];
           const R dG_ddely = -gdy * co[2] - gdx * co[1];
-          atomic_add(&g.dmean2D[2 * (size_t)gi + 0], dL_dG * dG_ddelx * ddelx_dx, par);
-          atomic_add(&g.dmean2D[2 * (size_t)gi + 1], dL_dG * dG_ddely * ddely_dy, par);
-          atomic_add(&g.dconic[3 * (size_t)gi + 0], R(-0.5) * gdx * dx * dL_dG, par);
-          atomic_add(&g.dconic[3 * (size_t)gi + 1], R(-0.5) * gdx * dy * dL_dG, par);
-          atomic_add(&g.dconic[3 * (size_t)gi + 2], R(-0.5) * gdy * dy * dL_dG, par);
-          atomic_add(&g.dopacity[gi], G * dL_dalpha, par);
+          acc(&g.dmean2D[2 * (size_t)gi + 0], k, 0, dL_dG * dG_ddelx * ddelx_dx);
+          acc(&g.dmean2D[2 * (size_t)gi + 1], k, 1, dL_dG * dG_ddely * ddely_dy);
+          acc(&g.dconic[3 * (size_t)gi + 0], k, 2, R(-0.5) * gdx * dx * dL_dG);
+          acc(&g.dconic[3 * (size_t)gi + 1], k, 3, R(-0.5) * gdx * dy * dL_dG);
+          acc(&g.dconic[3 * (size_t)gi + 2], k, 4, R(-0.5) * gdy * dy * dL_dG);
+          acc(&g.dopacity[gi], k, 5, G * dL_dalpha);
         }
+      }
+    if (par)
+      for (uint32_t k = r0; k < r1; ++k) {
+        const R* l = &loc[(size_t)(k - r0) * 10];
+        bool any = false;
+        for (int j = 0; j < 10; ++j) any = any || l[j] != R(0);
+        if (!any) continue;
+        const uint32_t gi = s.point_list[k];
+        atomic_add(&g.dmean2D[2 * (size_t)gi + 0], l[0], true); atomic_add(&g.dmean2D[2 * (size_t)gi + 1], l[1], true);
+        for (int j = 0; j < 3; ++j) atomic_add(&g.dconic[3 * (size_t)gi + j], l[2 + j], true);
+        atomic_add(&g.dopacity[gi], l[5], true);
+        for (int j = 0; j < 3; ++j) atomic_add(&g.dcolor[3 * (size_t)gi + j], l[6 + j], true);
+        if (has_extra) atomic_add(&g.dextra[gi], l[9], true);
       }
   }
 }
@@ -531,16 +583,24 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
   const Camera<R>& cam = s.cam;
   const int deg = std::min(d.D, d.max_sh_eval);
   const size_t ncol = d.M > 0 ? (size_t)d.M * 3 : 3;
-  std::fill(dL_dmeans, dL_dmeans + 3 * (size_t)P, R(0));
-  std::fill(dL_dcov6, dL_dcov6 + 6 * (size_t)P, R(0));
-  std::fill(dL_dopac, dL_dopac + P, R(0));
-  std::fill(dL_dsh_or_rgb, dL_dsh_or_rgb + ncol * P, R(0));
-  if (dL_dextra) std::fill(dL_dextra, dL_dextra + P, R(0));
-  if (dL_dmeans2D) std::fill(dL_dmeans2D, dL_dmeans2D + 3 * (size_t)P, R(0));
-  if (dL_dscales) std::fill(dL_dscales, dL_dscales + 3 * (size_t)P, R(0));
-  if (dL_drots) std::fill(dL_drots, dL_drots + 4 * (size_t)P, R(0));
-  if (dL_dcamera) std::fill(dL_dcamera, dL_dcamera + 35, R(0));
+  // the dense outputs start at zero (rows of culled Gaussians stay there): filled by all threads - at 300 k Gaussians the
+  // harmonics' gradient alone is 90 MB, and a single thread touching it first was most of this function's all-core time
+  auto zero = [&](R* ptr, size_t count) {
+    if (!ptr) return;
+    const long long blocks = (long long)((count + 65535) / 65536);
 #pragma omp parallel for schedule(static)
+    for (long long b = 0; b < blocks; ++b) std::fill(ptr + (size_t)b * 65536, ptr + std::min(count, (size_t)(b + 1) * 65536), R(0));
+  };
+  zero(dL_dmeans, 3 * (size_t)P); zero(dL_dcov6, 6 * (size_t)P); zero(dL_dopac, (size_t)P); zero(dL_dsh_or_rgb, ncol * P);
+  zero(dL_dextra, (size_t)P); zero(dL_dmeans2D, 3 * (size_t)P); zero(dL_dscales, 3 * (size_t)P); zero(dL_drots, 4 * (size_t)P);
+  if (dL_dcamera) std::fill(dL_dcamera, dL_dcamera + 35, R(0));
+  // (the camera gradient is summed per thread and added once per thread: one critical section per GAUSSIAN serialised the
+  // whole loop - the all-core backward of the 300 k scene spent 0.7 s here whatever the thread count)
+#pragma omp parallel
+  {
+  R cam_acc[35];
+  for (int k = 0; k < 35; ++k) cam_acc[k] = R(0);
+#pragma omp for schedule(static) nowait
   for (int i = 0; i < P; ++i) {
     if (!(s.radii[i] > 0)) continue;
     R dcamera[35];
@@ -636,7 +696,7 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
       sh_basis_grad(deg, x, y, z, bx, by, bz);
       R dRGB[3];
       for (int ch = 0; ch < 3; ++ch) dRGB[ch] = s.clamped[3 * (size_t)i + ch] ? R(0) : g.dcolor[3 * (size_t)i + ch];
-      const R* sh = &s.shs[(size_t)i * d.M * 3];
+      const R* sh = &s.shs_ptr[(size_t)i * d.M * 3];
       R* dsh = &dL_dsh_or_rgb[(size_t)i * d.M * 3];
       R ddir[3] = {0, 0, 0};
       for (int k = 0; k < n && k < d.M; ++k)
@@ -658,10 +718,8 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
       for (int ch = 0; ch < 3; ++ch) dL_dsh_or_rgb[3 * (size_t)i + ch] = g.dcolor[3 * (size_t)i + ch];
     }
     for (int j = 0; j < 3; ++j) dL_dmeans[3 * (size_t)i + j] = dmean[j];
-    if (dL_dcamera) {
-#pragma omp critical(gsro_camera_grad)
-      for (int k = 0; k < 35; ++k) dL_dcamera[k] += dcamera[k];
-    }
+    if (dL_dcamera)
+      for (int k = 0; k < 35; ++k) cam_acc[k] += dcamera[k];
     if (!d.use_scale_rot) {
       for (int k = 0; k < 6; ++k) dL_dcov6[6 * (size_t)i + k] = dcov[k];
     } else {
@@ -698,6 +756,11 @@ void preprocess_backward(const State<R>& s, const ScreenGrads<R>& g, R* dL_dmean
       }
     }
   }
+  if (dL_dcamera) {
+#pragma omp critical(gsro_camera_grad)
+    for (int k = 0; k < 35; ++k) dL_dcamera[k] += cam_acc[k];
+  }
+  }  // omp parallel
 }
 
 }  // namespace gsro

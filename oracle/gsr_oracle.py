@@ -109,7 +109,9 @@ class OracleRasterizer:
 
     def forward(self, *, height, width, tanfovx, tanfovy, bg, viewmatrix, projmatrix, campos, sh_degree,
                 means3D, opacities, cov3D_precomp=None, shs=None, colors_precomp=None, extra=None,
-                scales=None, rotations=None, scale_modifier=1.0, prefiltered=False) -> OracleResult:
+                scales=None, rotations=None, scale_modifier=1.0, prefiltered=False, borrow_sh=False) -> OracleResult:
+        """borrow_sh: the oracle reads the harmonics from the caller's array for as long as this object lives (no 300 B / Gaussian
+        copy - bench.py's cpu_baseline leg times it that way; the array is kept referenced here)."""
         self.free()
         means = self._arr(means3D, (-1, 3))
         P = means.shape[0]
@@ -129,7 +131,8 @@ class OracleRasterizer:
             M = 0
         opac = self._arr(opacities, (P,))
         ext = self._arr(extra, (P,)) if extra is not None else None
-        dims = (ctypes.c_int * 8)(P, height, width, int(sh_degree), M, self.max_sh_eval, int(prefiltered), int(use_sr))
+        dims = (ctypes.c_int * 8)(P, height, width, int(sh_degree), M, self.max_sh_eval, int(prefiltered) | (2 if borrow_sh else 0), int(use_sr))
+        self._keep = col if borrow_sh else None
         self._dims = (P, height, width, M, ext is not None, use_sr)
         out_color = np.zeros((3, height, width), dtype=self.dtype)
         out_extra = np.zeros((height, width), dtype=self.dtype) if ext is not None else None
