@@ -21,6 +21,6 @@ from .decoder import DecoderSplattingCUDA, DecoderSplattingCUDACfg, get_decoder 
 from .geometry import depth_to_relative_disparity, get_fov, get_projection_matrix, homogenize_points  # noqa: F401
 
 __version__ = "0.1.0"
-from .ply_export import export_ply, read_ply  # noqa: F401,E402
+from .ply_export import export_ply, gaussians_from_ply, read_ply  # noqa: F401,E402
 from .sh_rotation import rotate_sh  # noqa: F401,E402
 from . import losses  # noqa: F401,E402

@@ -125,3 +125,26 @@ def read_ply(path: Path) -> dict:
     return {"xyz": pick(("x", "y", "z")), "f_dc": pick(("f_dc_0", "f_dc_1", "f_dc_2")), "f_rest": pick(rest),
             "opacity": data[:, col["opacity"]].copy(), "scale": pick(("scale_0", "scale_1", "scale_2")),
             "rot": pick(("rot_0", "rot_1", "rot_2", "rot_3"))}
+
+
+def gaussians_from_ply(source, device=None, opacity_is_logit: bool = False, scale_is_log: bool = True):
+    """A splat `.ply` (path, or the dict `read_ply` returns) -> `pf3plat_amd.types.Gaussians` for ONE scene in the adapter's
+    scale + quaternion form (covariances None; the raster kernels build them on load): means (1, g, 3), scales (1, g, 3),
+    rotations (1, g, 4) x, y, z, w, harmonics (1, g, 3, d_sh), opacities (1, g).  This is what lets an externally trained scene
+    feed the raster path / the benchmark.  Files written by `export_ply` (and the reference's) hold the DC band
+    only and the opacity as it is; 3DGS trainers store `f_rest_*` channel-major (3 x (d_sh - 1)) and the opacity as a logit
+    (`opacity_is_logit=True`)."""
+    from .types import Gaussians
+
+    d = source if isinstance(source, dict) else read_ply(source)
+    g = d["xyz"].shape[0]
+    rest = d["f_rest"].reshape(g, 3, -1) if d["f_rest"].shape[1] else np.zeros((g, 3, 0), np.float32)
+    harmonics = np.concatenate((d["f_dc"][:, :, None], rest), axis=2)
+    opac = d["opacity"].astype(np.float32)
+    if opacity_is_logit:
+        opac = 1.0 / (1.0 + np.exp(-opac))
+    scales = np.exp(d["scale"]) if scale_is_log else d["scale"]
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None].to(device) if device is not None else \
+        torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None]
+    return Gaussians(means=to(d["xyz"]), covariances=None, harmonics=to(harmonics), opacities=to(opac), scales=to(scales),
+                     rotations=to(d["rot"][:, [1, 2, 3, 0]]), frames=None)
