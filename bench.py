@@ -578,14 +578,14 @@ def main():
             be.run_forward(plan_b, viewbuf, means, cov6, opac, shs)
             be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color)
 
-        for _ in range(5):
-            fb()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         n_fb = max(10, K // 4)
+        for _ in range(5 + (400 if args.preheat_ms > 0 else 0)):  # (untimed: the legs before this one end in blocking reads - clocks, as above)
+            fb()
+        barrier()
+        t0 = time.perf_counter()
         for _ in range(n_fb):
             fb()
-        torch.cuda.synchronize()
+        barrier()
         fb_ms = 1e3 * (time.perf_counter() - t0) / n_fb
         bacc = {}
         for _ in range(20):
