@@ -90,7 +90,7 @@ def kernel_bytes(n, nv, r16, hw, k_sh):
 def pmc_traffic(kernels, n, mode="fwd"):
     """HBM bytes per launch of every kernel in `kernels` (name fragments) from the TCC counters, one rocprofv3 pass per
     counter (FETCH_SIZE and WRITE_SIZE do not fit one pass), each profiling a child run of this file (--traffic-child:
-    a dozen eager forward + backward passes of the headline workload).  Units and the gfx950 correction are those of
+    150 eager forward (+ backward) passes of the headline workload).  Units and the gfx950 correction are those of
     /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KB, and FETCH_SIZE reports half the bytes of
     a wide coalesced read, so traffic = 2 * FETCH + WRITE (an upper bound for the gather-type kernels).  None if rocprofv3
     is unavailable or a pass fails."""
@@ -222,8 +222,9 @@ def main():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
 
     if args.traffic_child:  # profiled by pmc_traffic(): a dozen eager passes of the headline workload - the forward as timed
+        n_child = 150  # (enough steps for the shader clock to ramp: a dozen steps run ~15 % slow, profiles/r03_j_clock_probe.txt)
         if args.traffic_child == "fwd":  # (inference), or the training step as timed (forward told that a backward follows)
-            for _ in range(12):
+            for _ in range(n_child):
                 step()
         else:
             from pf3plat_amd import _lib as _gl
@@ -231,7 +232,7 @@ def main():
             g_child = torch.rand((1, 3, H, W), generator=torch.Generator().manual_seed(3)).to(dev)
             cfg_c = RasterConfig(1, 1, 1, n, H, W, 4, D_SH, 4, False, _gl.FLAG_BACKWARD_FOLLOWS)
             plan_c = be.make_plan(cfg_c, dev, capacity=int(plan["dims"].pair_capacity), backward=True)
-            for _ in range(12):
+            for _ in range(n_child):
                 be.run_forward(plan_c, viewbuf, means, cov6, opac, shs)
                 be.run_backward(plan_c, viewbuf, means, cov6, opac, shs, None, g_child)
         torch.cuda.synchronize()
