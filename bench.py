@@ -238,14 +238,17 @@ def main():
         torch.cuda.synchronize()
         return
 
-    def barrier():
+    def device_idle():
         # the host learns of the device going idle by polling an event (a blocking synchronize sleeps, and its wake-up alone is
-        # 30-60 us: 2-3 us per step of a 20-step window), then the synchronize + barrier + synchronize the contract asks for
+        # 30-60 us: 2-3 us per step of a 20-step window), then synchronizes
         ev = torch.cuda.Event()
         ev.record()
         while not ev.query():
             pass
         torch.cuda.synchronize()
+
+    def barrier():  # synchronize + barrier over the ranks + synchronize, as the contract asks around the timed region
+        device_idle()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -582,11 +585,11 @@ def main():
         n_fb = max(10, K // 4)
         for _ in range(5 + (400 if args.preheat_ms > 0 else 0)):  # (untimed: the legs before this one end in blocking reads - clocks, as above)
             fb()
-        barrier()
+        device_idle()  # (rank 0 only runs this leg: no collective here)
         t0 = time.perf_counter()
         for _ in range(n_fb):
             fb()
-        barrier()
+        device_idle()
         fb_ms = 1e3 * (time.perf_counter() - t0) / n_fb
         bacc = {}
         for _ in range(20):

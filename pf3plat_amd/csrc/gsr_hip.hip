@@ -868,28 +868,37 @@ constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 7
 
 // Colour (+0.5, clamp mask; kJ: d rgb / d direction as well) of Gaussian i of `set` - this lane - for the views vbegin,
 // vbegin + vstep, ... of the set, from its SH row `sh` (LDS).  Same expression tree as the oracle: rgb bit-exact.
-template <bool kJ>
+// kFull: the active degree is 4 and all 25 coefficients are in memory (PF3plat's and the benchmark's case), known at compile time -
+// the band tests and the `k < M` tests fold away, the 75 LDS reads of a row sit in ONE basic block (the compiler can then request
+// them ahead of the arithmetic instead of three at a time between branches) - same expression tree, same bits.
+// The camera of a view is wave-uniform: its scale and centre are fetched with scalar loads (readfirstlane on the view index), not
+// with a per-lane global load that every unit's evaluation then waits a full memory round trip for, under the colour stream.
+template <bool kJ, bool kFull>
 __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
                                                 float rmx, float rmy, float rmz) {
-  const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = p.d.sh_coeffs;
-  const int deg = min(p.d.sh_degree, p.d.max_sh_eval);
+  const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = kFull ? 25 : p.d.sh_coeffs;
+  const int deg = kFull ? 4 : min(p.d.sh_degree, p.d.max_sh_eval);
   // coefficient k of channel c sits at k * ks + c * cs: (3, 1) for (N, M, 3), (1, M) for the planar (N, 3, M) layout.  The
   // common layouts get compile-time strides (one base register + immediate offsets); computed per coefficient at run time
   // the 75 LDS addresses occupied 75 registers.
   auto eval_views = [&](auto ks_c, auto cs_c) {
     const int ks = ks_c(), cs = cs_c();
     for (int vv = vbegin; vv < Vs; vv += vstep) {
-      const int v = set * Vs + vv;
+      const int v = __builtin_amdgcn_readfirstlane(set * Vs + vv);
       const GsrView& cam = p.views[v];
-      const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
-      float dx = mx - cam.campos[0], dy = my - cam.campos[1], dz = mz - cam.campos[2];
+      const float cscale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.scale)));
+      const float ccx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.campos[0])));
+      const float ccy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.campos[1])));
+      const float ccz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.campos[2])));
+      const float mx = rmx * cscale, my = rmy * cscale, mz = rmz * cscale;
+      float dx = mx - ccx, dy = my - ccy, dz = mz - ccz;
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float cr = 0, cg = 0, cb = 0;
       float jx[3] = {0, 0, 0}, jy[3] = {0, 0, 0}, jz[3] = {0, 0, 0};
       if (kJ) {  // a backward follows: d rgb / d direction as well, from the coefficients that are in LDS right now
         sh_visit(deg, dx, dy, dz, [&](int k, float bk, float bx, float by, float bz) {
-          if (k < M) {
+          if (kFull || k < M) {
             const float s0 = sh[k * ks + 0 * cs], s1 = sh[k * ks + 1 * cs], s2 = sh[k * ks + 2 * cs];
             cr += bk * s0; cg += bk * s1; cb += bk * s2;
             jx[0] += bx * s0; jx[1] += bx * s1; jx[2] += bx * s2;
@@ -899,7 +908,7 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
         });
       } else {
         sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
-          if (k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
+          if (kFull || k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
         });
       }
       cr += 0.5f; cg += 0.5f; cb += 0.5f;
@@ -914,8 +923,17 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
   };
   const bool planar = (p.d.flags & GSR_FLAG_SH_PLANAR) != 0;
   if (!planar) eval_views([] { return 3; }, [] { return 1; });
-  else if (M == 25) eval_views([] { return 1; }, [] { return 25; });
+  else if (kFull || M == 25) eval_views([] { return 1; }, [] { return 25; });
   else eval_views([] { return 1; }, [&] { return M; });
+}
+// wave-uniform choice of the instance.  kAllowFull: only the colour waves of the binning launch in inference take the compile-time
+// instance - with its loads hoisted it needs ~40 registers more, which the Jacobian variant (twelve accumulators) and the
+// stand-alone k_color (eight workgroups per CU) do not have.
+template <bool kJ, bool kAllowFull>
+__device__ __forceinline__ void color_eval(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
+                                           float rmx, float rmy, float rmz) {
+  if (kAllowFull && p.d.sh_coeffs == 25 && min(p.d.sh_degree, p.d.max_sh_eval) == 4) color_eval_lane<kJ, true>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz);
+  else color_eval_lane<kJ, false>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz);
 }
 
 // `tid` = thread within the group (0 .. kColorThreads - 1), `lds` = the group's 19 200 B; the one barrier inside is the
@@ -972,7 +990,7 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   if (!in_range || !valid) return;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
   if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
-  color_eval_lane<kJ>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz);
+  color_eval<kJ, false>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz);
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -1019,7 +1037,11 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
   __builtin_amdgcn_s_waitcnt(0);  // the DMA writes count as vector memory operations (vmcnt); the plain LDS stores as lgkmcnt
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
-  if (in_range) color_eval_lane<kJ>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz);
+#ifndef GSR_EXP_NO_COLOR_EVAL
+  if (in_range) color_eval<kJ, !kJ>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz);
+#else
+  if (in_range) p.rgbc[(size_t)(set * p.d.views_per_set) * N + i] = make_float4(lds[lane * ldstride], rmx, rmy, rmz);  // experiment: stream without the arithmetic
+#endif
   if (dbg) stamp[3] = __builtin_amdgcn_s_memrealtime();
 }
 
