@@ -873,9 +873,21 @@ constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 7
 // them ahead of the arithmetic instead of three at a time between branches) - same expression tree, same bits.
 // The camera of a view is wave-uniform: its scale and centre are fetched with scalar loads (readfirstlane on the view index), not
 // with a per-lane global load that every unit's evaluation then waits a full memory round trip for, under the colour stream.
+// What the colour pass reads of a view: fetched through the CONSTANT address space, i.e. by scalar loads (s_load_dword, the scalar
+// cache) into scalar registers - the records are written by an earlier launch and wave-uniform here.  As a plain `p.views[v]` read
+// the compiler issues a per-lane global load, and every unit's evaluation then starts by waiting a memory round trip for it
+// under the colour stream.  The colour waves of the binning launch ask for the first view's values BEFORE they wait for the
+// unit's rows (cam_lite early, `cam0`), so the values are there when the rows are.
+struct CamLite { float scale, cx, cy, cz; };
+__device__ __forceinline__ CamLite cam_lite(const GsrView* views, int v_uniform) {
+  typedef const __attribute__((address_space(4))) float* cptr;
+  cptr c = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(views + v_uniform));
+  return CamLite{c[40], c[32], c[33], c[34]};  // GsrView: scale at float 40, campos at 32..34
+}
+
 template <bool kJ, bool kFull>
 __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
-                                                float rmx, float rmy, float rmz) {
+                                                float rmx, float rmy, float rmz, const CamLite& cam0) {
   const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = kFull ? 25 : p.d.sh_coeffs;
   const int deg = kFull ? 4 : min(p.d.sh_degree, p.d.max_sh_eval);
   // coefficient k of channel c sits at k * ks + c * cs: (3, 1) for (N, M, 3), (1, M) for the planar (N, 3, M) layout.  The
@@ -885,13 +897,10 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
     const int ks = ks_c(), cs = cs_c();
     for (int vv = vbegin; vv < Vs; vv += vstep) {
       const int v = __builtin_amdgcn_readfirstlane(set * Vs + vv);
-      const GsrView& cam = p.views[v];
-      const float cscale = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.scale)));
-      const float ccx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.campos[0])));
-      const float ccy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.campos[1])));
-      const float ccz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cam.campos[2])));
-      const float mx = rmx * cscale, my = rmy * cscale, mz = rmz * cscale;
-      float dx = mx - ccx, dy = my - ccy, dz = mz - ccz;
+      CamLite cam = cam0;
+      if (vv != vbegin) cam = cam_lite(p.views, v);
+      const float mx = rmx * cam.scale, my = rmy * cam.scale, mz = rmz * cam.scale;
+      float dx = mx - cam.cx, dy = my - cam.cy, dz = mz - cam.cz;
       const float len = sqrtf(dx * dx + dy * dy + dz * dz);
       dx = dx / len; dy = dy / len; dz = dz / len;
       float cr = 0, cg = 0, cb = 0;
@@ -931,9 +940,9 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
 // stand-alone k_color (eight workgroups per CU) do not have.
 template <bool kJ, bool kAllowFull>
 __device__ __forceinline__ void color_eval(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
-                                           float rmx, float rmy, float rmz) {
-  if (kAllowFull && p.d.sh_coeffs == 25 && min(p.d.sh_degree, p.d.max_sh_eval) == 4) color_eval_lane<kJ, true>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz);
-  else color_eval_lane<kJ, false>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz);
+                                           float rmx, float rmy, float rmz, const CamLite& cam0) {
+  if (kAllowFull && p.d.sh_coeffs == 25 && min(p.d.sh_degree, p.d.max_sh_eval) == 4) color_eval_lane<kJ, true>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz, cam0);
+  else color_eval_lane<kJ, false>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz, cam0);
 }
 
 // `tid` = thread within the group (0 .. kColorThreads - 1), `lds` = the group's 19 200 B; the one barrier inside is the
@@ -990,7 +999,8 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   if (!in_range || !valid) return;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
   if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
-  color_eval<kJ, false>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz);
+  color_eval<kJ, false>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz,
+                        cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs + min(wave, Vs - 1))));
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -1033,12 +1043,13 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
   }
   float rmx = 0, rmy = 0, rmz = 0;
   if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
+  const CamLite cam0 = cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs));  // (requested before the wait below)
   if (dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_waitcnt(0);  // the DMA writes count as vector memory operations (vmcnt); the plain LDS stores as lgkmcnt
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
 #ifndef GSR_EXP_NO_COLOR_EVAL
-  if (in_range) color_eval<kJ, !kJ>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz);
+  if (in_range) color_eval<kJ, !kJ>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz, cam0);
 #else
   if (in_range) p.rgbc[(size_t)(set * p.d.views_per_set) * N + i] = make_float4(lds[lane * ldstride], rmx, rmy, rmz);  // experiment: stream without the arithmetic
 #endif
