@@ -908,6 +908,9 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
       if (kJ) {  // a backward follows: d rgb / d direction as well, from the coefficients that are in LDS right now
         sh_visit(deg, dx, dy, dz, [&](int k, float bk, float bx, float by, float bz) {
           if (kFull || k < M) {
+            // (compile-time instance: a scheduling fence in front of every band keeps the compiler from requesting all 75
+            // coefficients at once - with the twelve accumulators of this variant that spilled)
+            if (kFull && (k == 1 || k == 4 || k == 9 || k == 16 || k == 20)) __builtin_amdgcn_sched_barrier(0);
             const float s0 = sh[k * ks + 0 * cs], s1 = sh[k * ks + 1 * cs], s2 = sh[k * ks + 2 * cs];
             cr += bk * s0; cg += bk * s1; cb += bk * s2;
             jx[0] += bx * s0; jx[1] += bx * s1; jx[2] += bx * s2;
@@ -1026,6 +1029,11 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && lane == 0;
   unsigned long long* stamp = dbg_stamps(p, 16384 + unit);
   if (dbg) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  // the means and the view's parameters are asked for FIRST: vector loads return in order, so they are there when the rows (requested
+  // behind them, 3 us of issuing against the stream's back-pressure) are - asked for last, the evaluation waited a round trip for them
+  float rmx = 0, rmy = 0, rmz = 0;
+  if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
+  const CamLite cam0 = cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs));
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the previous unit's LDS reads have returned before its rows are overwritten
   if ((ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0)) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1041,15 +1049,20 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
       lds[row * ldstride + (k - row * rowf)] = sh_src[k];
     }
   }
-  float rmx = 0, rmy = 0, rmz = 0;
-  if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
-  const CamLite cam0 = cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs));  // (requested before the wait below)
   if (dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
   __builtin_amdgcn_s_waitcnt(0);  // the DMA writes count as vector memory operations (vmcnt); the plain LDS stores as lgkmcnt
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
 #ifndef GSR_EXP_NO_COLOR_EVAL
-  if (in_range) color_eval<kJ, !kJ>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz, cam0);
+#ifndef GSR_COLOR_EVAL_PRIO
+#define GSR_COLOR_EVAL_PRIO 2
+#endif
+  if (GSR_COLOR_EVAL_PRIO) __builtin_amdgcn_s_setprio(GSR_COLOR_EVAL_PRIO);
+#ifndef GSR_COLOR_FULL_J
+#define GSR_COLOR_FULL_J 1
+#endif
+  if (in_range) color_eval<kJ, !kJ || GSR_COLOR_FULL_J>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz, cam0);
+  if (GSR_COLOR_EVAL_PRIO) __builtin_amdgcn_s_setprio(0);
 #else
   if (in_range) p.rgbc[(size_t)(set * p.d.views_per_set) * N + i] = make_float4(lds[lane * ldstride], rmx, rmy, rmz);  // experiment: stream without the arithmetic
 #endif
