@@ -38,6 +38,10 @@
 #define GSR_ABL(flags, bit) false
 #endif
 
+#ifndef GSR_COLOR_FENCE_NOJ
+#define GSR_COLOR_FENCE_NOJ 0  // scheduling fences between the bands of the compile-time colour evaluation without Jacobian
+#endif
+
 namespace gsr {
 
 constexpr int kChunkMax = 2048;   // most Gaussians per binning workgroup (= one row of the per-view count matrix)
@@ -920,7 +924,12 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
         });
       } else {
         sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
-          if (kFull || k < M) { cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs]; }
+          if (kFull || k < M) {
+#if GSR_COLOR_FENCE_NOJ
+            if (kFull && (k == 4 || k == 9 || k == 16)) __builtin_amdgcn_sched_barrier(0);
+#endif
+            cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs];
+          }
         });
       }
       cr += 0.5f; cg += 0.5f; cb += 0.5f;
@@ -1002,7 +1011,10 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   if (!in_range || !valid) return;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
   if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
-  color_eval<kJ, false>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz,
+#ifndef GSR_KCOLOR_FULL
+#define GSR_KCOLOR_FULL 0  // (the stand-alone colour launch lives on bandwidth at eight workgroups per CU: the compile-time instance buys it nothing)
+#endif
+  color_eval<kJ, GSR_KCOLOR_FULL != 0>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz,
                         cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs + min(wave, Vs - 1))));
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
