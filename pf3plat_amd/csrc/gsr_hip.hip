@@ -255,6 +255,29 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
   return a > b ? a : b;
 }
 
+// What the colour pass reads of a view: fetched through the CONSTANT address space, i.e. by scalar loads (s_load_dword, the scalar
+// cache) into scalar registers - the records are written by an earlier launch and wave-uniform here.  As a plain `p.views[v]` read
+// the compiler issues a per-lane global load, and every unit's evaluation then starts by waiting a memory round trip for it
+// under the colour stream.  The colour waves of the binning launch ask for the first view's values BEFORE they wait for the
+// unit's rows (cam_lite early, `cam0`), so the values are there when the rows are.
+struct CamLite { float scale, cx, cy, cz; };
+__device__ __forceinline__ CamLite cam_lite(const GsrView* views, int v_uniform) {
+  typedef const __attribute__((address_space(4))) float* cptr;
+  cptr c = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(views + v_uniform));
+  return CamLite{c[40], c[32], c[33], c[34]};  // GsrView: scale at float 40, campos at 32..34
+}
+
+// The whole record that way (fields that are not used cost nothing): for the kernels whose lanes all work on one view at a time.
+__device__ __forceinline__ GsrView view_const(const GsrView* views, int v_uniform) {
+  typedef const __attribute__((address_space(4))) float* cptr;
+  cptr c = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(views + __builtin_amdgcn_readfirstlane(v_uniform)));
+  GsrView o;
+  float* f = reinterpret_cast<float*>(&o);
+#pragma unroll
+  for (int k = 0; k < (int)(sizeof(GsrView) / 4); ++k) f[k] = c[k];
+  return o;
+}
+
 // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only), so give
 // each XCD a contiguous run of tiles - neighbouring tiles gather the same splat records from one L2.
 __device__ __forceinline__ int xcd_remap(int b, int n) {
@@ -683,7 +706,14 @@ __device__ __forceinline__ GaussIn load_gauss(const Params& p, int v, int i) {
 template <class F, class B>
 __device__ __forceinline__ PreRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big) {
   const int N = p.d.num_gaussians;
+#ifndef GSR_VIEW_CONST
+#define GSR_VIEW_CONST 0  // (measured: the ~30 scalar registers it takes spill in the binning kernels, forward +0.6 us)
+#endif
+#if GSR_VIEW_CONST
+  const GsrView cam = view_const(p.views, v);  // scalar registers, loaded once: not ~35 per-lane loads in every iteration of the caller
+#else
   const GsrView& cam = p.views[v];
+#endif
   const Grid& g = p.g;
   const size_t oi = (size_t)v * N + i;
 
@@ -877,18 +907,6 @@ constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 7
 // them ahead of the arithmetic instead of three at a time between branches) - same expression tree, same bits.
 // The camera of a view is wave-uniform: its scale and centre are fetched with scalar loads (readfirstlane on the view index), not
 // with a per-lane global load that every unit's evaluation then waits a full memory round trip for, under the colour stream.
-// What the colour pass reads of a view: fetched through the CONSTANT address space, i.e. by scalar loads (s_load_dword, the scalar
-// cache) into scalar registers - the records are written by an earlier launch and wave-uniform here.  As a plain `p.views[v]` read
-// the compiler issues a per-lane global load, and every unit's evaluation then starts by waiting a memory round trip for it
-// under the colour stream.  The colour waves of the binning launch ask for the first view's values BEFORE they wait for the
-// unit's rows (cam_lite early, `cam0`), so the values are there when the rows are.
-struct CamLite { float scale, cx, cy, cz; };
-__device__ __forceinline__ CamLite cam_lite(const GsrView* views, int v_uniform) {
-  typedef const __attribute__((address_space(4))) float* cptr;
-  cptr c = reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(views + v_uniform));
-  return CamLite{c[40], c[32], c[33], c[34]};  // GsrView: scale at float 40, campos at 32..34
-}
-
 template <bool kJ, bool kFull>
 __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
                                                 float rmx, float rmy, float rmz, const CamLite& cam0) {
@@ -1839,6 +1857,8 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
     // a list longer than that - a run of the tail region behind the slots, taken from a bump counter.  The usual case
     // (every run stored, list fits its slot and the LDS sort) needs no decision by one thread and no barrier.
     const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kLds;
+    // (the longest list so far, statistics.  Two ways of taking this read off wave 1's path were tried - asked for at the kernel's start:
+    // it reads 0 in every tile and a thousand same-address atomics follow, +2 us; asked for here and compared after the run copy: +11 us)
     if (tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
     if (plain) {
       if (tid == 0) p.ranges[tg] = make_uint2((uint32_t)tg * p.stride, (uint32_t)tg * p.stride + (uint32_t)n);
@@ -2113,6 +2133,11 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
   const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
   const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
 
+  // the view's background through scalar loads, asked for now: read as `p.views[v].bg` where it is used - in the tile's last
+  // instructions - every tile ended with a memory round trip
+  typedef const __attribute__((address_space(4))) float* cfptr;
+  cfptr camc = reinterpret_cast<cfptr>(reinterpret_cast<uintptr_t>(p.views + __builtin_amdgcn_readfirstlane(v)));
+  const float bg0 = camc[37], bg1 = camc[38], bg2 = camc[39];  // GsrView::bg
   if (p.status->overflow) {  // pair workspace too small: nothing was binned.  Poison the outputs so the condition cannot go
     if (wave == 0 && inside) {  // unnoticed even when the caller defers reading the status block.
       const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
@@ -2290,15 +2315,14 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
         last += sLast[h][lane];
       }
       const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
-      const GsrView& cam = p.views[v];
       p.final_T[(size_t)v * HW + pix] = T;
       // the pixel's loop ran through `last` entries before it stopped (every splat it blended has a smaller index; the reference
       // stores the index of the last one it blended - the entries in between are skipped by the alpha < 1/255 test either way)
       p.n_contrib[(size_t)v * HW + pix] = min(last, n);  // (the padding of the last batch counts as alive)
       float* oc = p.out_color + (size_t)v * 3 * HW;
-      oc[pix] = C0 + T * cam.bg[0];
-      oc[HW + pix] = C1 + T * cam.bg[1];
-      oc[2 * HW + pix] = C2 + T * cam.bg[2];
+      oc[pix] = C0 + T * bg0;
+      oc[HW + pix] = C1 + T * bg1;
+      oc[2 * HW + pix] = C2 + T * bg2;
       if (kExtra) p.out_extra[(size_t)v * HW + pix] = E;
     }
   }
