@@ -582,7 +582,7 @@ def main():
             be.run_forward(plan_b, viewbuf, means, cov6, opac, shs)
             be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color)
 
-        n_fb = max(10, K // 4)
+        n_fb = max(50, K // 4)
         for _ in range(5 + (400 if args.preheat_ms > 0 else 0)):  # (untimed: the legs before this one end in blocking reads - clocks, as above)
             fb()
         device_idle()  # (rank 0 only runs this leg: no collective here)
