@@ -2739,7 +2739,14 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   bool seen = false;
   for (int vv = 0; vv < Vs; ++vv) {
     const int v = set * Vs + vv;
+#ifndef GSR_BWD_VIEW_CONST
+#define GSR_BWD_VIEW_CONST 1  // the view record in scalar registers: -2 us (the per-lane loads of the uniform record held ~35 VGPRs)
+#endif
+#if GSR_BWD_VIEW_CONST
+    const GsrView cam = view_const(p.views, v);
+#else
     const GsrView& cam = p.views[v];
+#endif
     const size_t oi = (size_t)v * N + (in_range ? i : 0);
     float sg[12];
 #pragma unroll
