@@ -2413,6 +2413,21 @@ __device__ __forceinline__ unsigned long long to_fixed(float v) {
 }
 __device__ __forceinline__ float from_fixed(long long x) { return (float)x * kFixInv; }
 
+// Which tile a workgroup of k_blend_bwd takes.  A compute unit holds four workgroups of the launch (blocks b, b + 256, b + 512,
+// b + 768 of the first round: HW_ID stamps) and, VALU-bound, is busy for the SUM of their tiles' batches (least squares over
+// the 256 CUs of the 300 k / 256 x 256 workload: end = 0.93 us x sum + 0.0 x max); with the tiles in image order the heaviest
+// CU carried 48 batches against a mean of 39.5.  The tiles of an XCD stay on that XCD (their records are in ITS L2: handing
+// tiles out across the whole chip by load was measured - the gathers then miss, prologue 3.0 -> 4.1 us, no gain), but inside
+// the XCD they are dealt to its 32 CUs heaviest first, every other round mirrored.  Work of a tile = list entries the forward
+// walked (Params::tile_total); every workgroup finds its own tile: a selection by bisection over the <= 256 keys of its XCD, one wave, ballots only.
+#ifndef GSR_BWD_BALANCE
+#define GSR_BWD_BALANCE 1
+#endif
+#ifndef GSR_BWD_WAITALL
+#define GSR_BWD_WAITALL 1
+#endif
+constexpr int kBalanceMax = 256;  // tiles per XCD up to which the deal is computed (more: image order; later rounds balance themselves)
+
 template <bool kExtra, bool kDet>
 __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   __shared__ __attribute__((aligned(16))) float sW[kBwdWaves][kBS][64];  // A -> R, per wave: blend weight w
@@ -2425,8 +2440,47 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   const Grid& g = p.g;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v = blockIdx.y;
-  const int t = xcd_remap(blockIdx.x, g.T);
+  int t = xcd_remap(blockIdx.x, g.T);
+#if GSR_BWD_BALANCE
+  {
+    __shared__ int sPick;
+    const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3, q8 = g.T >> 3, r8 = g.T & 7;
+    const int cnt = q8 + (xcd < r8 ? 1 : 0), base = t - k;  // this XCD's tiles: [base, base + cnt)
+    if (cnt <= kBalanceMax) {
+      if (wave == 0) {
+        // keys (walked + 1) << 8 | (255 - index): distinct, heavier first, equal loads in index order; up to four per lane
+        const uint32_t* tot = p.tile_total + (size_t)v * g.T + base;
+        uint32_t key[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int i = lane + 64 * c;
+          key[c] = i < cnt ? ((tot[i] + 1u) << 8) | (uint32_t)(255 - i) : 0u;
+        }
+        const int round = k >> 5, in = k & 31, len = cnt - (round << 5) < 32 ? cnt - (round << 5) : 32;
+        const int want = (round << 5) + ((round & 1) ? len - 1 - in : in);  // position of this block in heaviest-first order
+        // the key at that position: the largest X with more than `want` keys >= X, bit by bit from the top bit of the largest key
+        const uint32_t top = wave_max_u32(max(max(key[0], key[1]), max(key[2], key[3])));
+        uint32_t X = 0;
+        for (int bit = 31 - __builtin_clz(top | 1u); bit >= 0; --bit) {
+          const uint32_t cand = X | (1u << bit);
+          int n = __builtin_popcountll(__ballot(key[0] >= cand)) + __builtin_popcountll(__ballot(key[1] >= cand));
+          if (cnt > 128) n += __builtin_popcountll(__ballot(key[2] >= cand)) + __builtin_popcountll(__ballot(key[3] >= cand));
+          X = n > want ? cand : X;
+        }
+        if (lane == 0) sPick = 255 - (int)(X & 255u);
+      }
+      __syncthreads();
+      t = base + sPick;
+    }
+  }
+#endif
   const int tx = t % g.sgx, ty = t / g.sgx;
+#ifdef GSR_BWD_LONE  // measurement aid: one workgroup per CU (how fast is a tile that has its SIMDs to itself?)
+  if (blockIdx.x >= 256 * GSR_BWD_LONE) return;
+#endif
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && threadIdx.x == 0;  // measurement aid (tools/bwd_timeline.py)
+  unsigned long long* stamp = p.keys + ((size_t)v * g.T + blockIdx.x) * 4;          // the forward's keys are dead by now
+  if (dbg) stamp[0] = __builtin_amdgcn_s_memrealtime();
   const uint2 rg = p.ranges[(size_t)v * g.T + t];
   const uint32_t n = rg.y - rg.x;
   const size_t HW = (size_t)g.H * g.W;
@@ -2476,17 +2530,26 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     asm volatile("" : "+v"(z));
     return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
   };
-  auto stage = [&](uint32_t it, float4& sg, float4& sg2, float4& sc, uint32_t id) {  // lane = entry; issues the gather
-    sg = make_float4(0, 0, 0, 0); sg2 = sg; sc = sg;
+  // lane = entry.  The gather is ISSUED at the top of an iteration and its values are first touched (exp2-domain scaling, LDS
+  // write) by park() at the end: arithmetic on them right behind the loads made the staging wave - and through the batch's
+  // barrier the whole tile - wait a full memory round trip at the top of every iteration.
+  auto stage = [&](uint32_t it, float4& r0, float4& r1, float4& rc, uint32_t id) {
+    r0 = make_float4(0, 0, 0, 0); r1 = r0; rc = r0;
     const uint32_t ln = lane_now();
     const uint32_t idx = batch_of(it) * kBB + ln;
     if (ln < kBB && idx < nmax) {
       const GeomRec* r = geom + id;
-      float4 q0 = r->q0, q1 = r->q1;
-      const float4 col = rgbc[id];
-      const float ex = kExtra ? q1.z : 0.f;
-      to_exp2_domain(q0, q1);
-      sg = q0; sg2 = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f); sc = make_float4(col.x, col.y, col.z, ex);
+      r0 = r->q0; r1 = r->q1;
+      rc = rgbc[id];
+    }
+  };
+  auto park = [&](int ring, float4 q0, float4 q1, const float4 col, uint32_t id) {  // lanes past the list hold zeros (id 0)
+    const float ex = kExtra ? q1.z : 0.f;
+    to_exp2_domain(q0, q1);
+    if (lane_now() < kBB) {
+      const uint32_t ln = lane_now();
+      sGeo[ring][ln] = q0; sGeo2[ring][ln] = make_float4(q1.x, q1.y, __uint_as_float(id), 0.f);
+      sCol[ring][ln] = make_float4(col.x, col.y, col.z, ex);
     }
   };
   auto load_ids = [&](uint32_t it) -> uint32_t {
@@ -2543,7 +2606,8 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       q = __builtin_fmaf(om[u], q, al[u] * cgv[u]);
     }
   };
-  auto reduce = [&](uint32_t it) {  // stage R: entry e0 + er of iteration it, pixel row pr
+  struct RowSum { float val, tail; uint32_t id; };
+  auto reduce = [&](uint32_t it) -> RowSum {  // stage R: entry e0 + er of iteration it, pixel row pr
     const int ring = it & 3;
     const float4 w0 = *reinterpret_cast<const float4*>(&sW[wave][er][8 * pr]);
     const float4 w1 = *reinterpret_cast<const float4*>(&sW[wave][er][8 * pr + 4]);
@@ -2588,7 +2652,6 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     if (kExtra) v9 = oct_allreduce(v9);
     // a splat that no pixel of the tile blended (or whose pixels carry no gradient) adds exact zeros: skip its atomics
     const bool any = (S0 != 0.f) || (Sx != 0.f) || (Sy != 0.f) || (Sxx != 0.f) || (v6 != 0.f) || (v7 != 0.f) || (v8 != 0.f) || (v9 != 0.f);
-    if (!any || GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_BWD_NO_ATOMIC)) return;
     // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
     const float o = a2.y;
     const float v0 = hW * kLn2 * o * (2.f * a.z * Sx + a.w * Sy);
@@ -2597,27 +2660,62 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     float val = v0;
     val = pr == 1 ? v1 : val; val = pr == 2 ? mh * Sxx : val; val = pr == 3 ? mh * Sxy : val; val = pr == 4 ? mh * Syy : val;
     val = pr == 5 ? S0 : val; val = pr == 6 ? v6 : val; val = pr == 7 ? v7 : val;
-    if (kDet) {
-      unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) +
-                                ((size_t)v * p.d.num_gaussians + __float_as_uint(a2.z)) * GSR_SCREEN_GRAD_FLOATS;
-      atomicAdd(dst + pr, to_fixed(val));
-      if (pr < (kExtra ? 2 : 1)) atomicAdd(dst + 8 + pr, to_fixed(pr == 0 ? v8 : v9));
-    } else {
-      float* dst = scratch + (size_t)__float_as_uint(a2.z) * GSR_SCREEN_GRAD_FLOATS;
-      unsafeAtomicAdd(dst + pr, val);
-      if (pr < (kExtra ? 2 : 1)) unsafeAtomicAdd(dst + 8 + pr, pr == 0 ? v8 : v9);
+    RowSum r;
+    r.val = val; r.tail = pr == 0 ? v8 : v9;
+    r.id = (any && !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_BWD_NO_ATOMIC)) ? __float_as_uint(a2.z) : 0xffffffffu;
+    return r;
+  };
+  // The segment's sums into the accumulator rows of their splats.  Device-scope atomics are executed on the memory side of the
+  // fabric (the L2s of the XCDs are not coherent with each other: TCC_EA0_ATOMIC = TCC_ATOMIC), one transaction per REQUEST the
+  // lanes of an instruction coalesce into - and at 15 requests per wave and batch (floats 0-7 of eight rows, then floats 8 (9)
+  // of the same rows from eight lanes of a second instruction) the launch ran at the rate of those transactions: 42.9 us, 33.8
+  // without the second instruction, 34.3 with both on rows nobody else touches.  Now a row's 9 (10) values leave together:
+  // the lanes of a DPP row are two entries' groups of eight; the first instruction carries the even entries - floats 0-7 from
+  // their own lanes, floats 8 (9) from the first lanes of the odd neighbour's group, which fetch value and row id across the
+  // row (row_ror:8) - the second instruction the odd entries the same way: 9-10 adjacent lanes, 36-40 contiguous bytes, one
+  // request (two where the 48-byte row straddles a 64-byte line; 64-byte rows measured the same, the launch is no longer bound
+  // by the transactions).  TCC_ATOMIC per launch 601 k -> 267-400 k, k_blend_bwd 42.9 -> 34.6 us.
+  auto ror8 = [](uint32_t x) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); };
+  auto scatter = [&](const RowSum& r) {
+    const uint32_t o_id = ror8(r.id);
+    const float o_tail = __uint_as_float(ror8(__float_as_uint(r.tail)));
+    const bool odd = (er & 1) != 0, tail_lane = pr < (kExtra ? 2 : 1);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: even entries, pass 1: odd entries
+      const bool own = odd == (pass == 1);
+      const uint32_t id = own ? r.id : o_id;
+      const float x = own ? r.val : o_tail;
+      const int slot = own ? pr : 8 + pr;
+      if (id != 0xffffffffu && (own || tail_lane)) {
+        if (kDet) {
+          unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) +
+                                    ((size_t)v * p.d.num_gaussians + id) * GSR_SCREEN_GRAD_FLOATS;
+          atomicAdd(dst + slot, to_fixed(x));
+        } else {
+          unsafeAtomicAdd(scratch + (size_t)id * GSR_SCREEN_GRAD_FLOATS + slot, x);
+        }
+      }
     }
   };
 
-  // ---- prologue: waves 0 / 1 stage iterations 0 / 1, wave 2 fetches the list ids of iteration 2; everyone evaluates 0
-  float4 sg, sg2, sc;
+  // ---- prologue: waves 0 / 1 stage and park batches 0 / 1, wave 2 requests batch 2 (parked in iteration 0), wave 3 fetches the
+  // list ids of batch 3; everyone evaluates batch 0.
+  // Gather pipeline of the loop, iteration `it`: wave (it+3)&3 requests the records of batch it+3 (ids in hand since it-1), wave
+  // it&3 requests the list ids of batch it+4, wave (it+2)&3 parks the records it requested in iteration it-1 - more than one
+  // whole iteration after the request, and BEFORE this iteration's atomics (a wave's memory counter is in order: behind its
+  // atomics it would wait until the fabric has acknowledged them).
+  float4 sg = make_float4(0, 0, 0, 0), sg2 = sg, sc = sg;
   uint32_t id_next = 0;
   if (wave == 0 || (wave == 1 && nbat > 1)) {
     const uint32_t it0 = (uint32_t)wave;
-    stage(it0, sg, sg2, sc, load_ids(it0));
-    if (lane < kBB) { sGeo[it0][lane] = sg; sGeo2[it0][lane] = sg2; sCol[it0][lane] = sc; }
+    const uint32_t id0 = load_ids(it0);
+    stage(it0, sg, sg2, sc, id0);
+    park((int)it0, sg, sg2, sc, id0);
   } else if (wave == 2) {
     id_next = load_ids(2);
+    if (2 < nbat) stage(2, sg, sg2, sc, id_next);
+  } else {
+    id_next = load_ids(3);
   }
   __syncthreads();
   eval(0);
@@ -2625,10 +2723,13 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
   float Tb = T_final;                                              // (T, Q) at the back end of the batch: the same in all four
   float Qb = cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2;    // waves (behind the last splat Q = Bg / T_final = bg.g)
+  if (dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
+  // T_final has to have ARRIVED before the loop: a load still counted as pending at the loop's entry makes the compiler wait
+  // for "everything" at the first use of Tb inside the loop - on every iteration, right behind the gather just issued
+  asm volatile("" : "+v"(Tb));
   for (uint32_t it = 0; it < nbat; ++it) {
-    const bool do_stage = (wave == (int)((it + 2) & 3)) && (it + 2 < nbat);
-    if (do_stage) stage(it + 2, sg, sg2, sc, id_next);  // global gather in flight
-    if (wave == (int)((it + 3) & 3)) id_next = load_ids(it + 3);
+    if (wave == (int)((it + 3) & 3) && it + 3 < nbat) stage(it + 3, sg, sg2, sc, id_next);  // global gather in flight
+    if (wave == (int)(it & 3)) id_next = load_ids(it + 4);
     // back to front: wave 3's segment is the deepest.  The same chain in every wave: (t, q) = transmittance and Q at the BACK end
     // of segment k; the front of segment k is the back of segment k - 1.  One segment's three values at a time (register budget).
     float t = Tb, q = Qb, Tf = 0.f, Qk = 0.f;
@@ -2643,13 +2744,24 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     }
     Tb = t; Qb = q;
     replay(Tf, Qk);
-    reduce(it);
+    const RowSum rs = reduce(it);
+#if GSR_BWD_WAITALL
+    // every wave: nothing of its own is in flight past this point except the atomics that follow (an explicit wait the compiler
+    // sees: without it, it has to assume at the top of the loop that a request of an earlier iteration may still be pending on
+    // the registers the next one writes, and waits there for the previous iteration's ATOMICS)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+#endif
+    if (wave == (int)((it + 2) & 3) && it + 2 < nbat) park((int)((it + 2) & 3), sg, sg2, sc, id_next);
+    asm volatile("" ::: "memory");
+    scatter(rs);
     if (it + 1 < nbat) eval(it + 1);
-    if (do_stage && lane < kBB) {
-      const int ring = (it + 2) & 3;
-      sGeo[ring][lane] = sg; sGeo2[ring][lane] = sg2; sCol[ring][lane] = sc;
-    }
     __syncthreads();
+  }
+  if (dbg) {
+    const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
+                        ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
+    stamp[2] = __builtin_amdgcn_s_memrealtime();
+    stamp[3] = ((unsigned long long)hw << 32) | ((unsigned long long)nbat << 16) | (unsigned)t;
   }
 }
 
