@@ -2372,11 +2372,12 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
 //            G dL/dalpha go to a per-wave LDS tile (no barrier: written and read by the same wave);
 //   stage R (batch it),   lane = (entry 0..7, pixel row 0..7): per-splat gradients.  Each lane sums its row of 8 pixels
 //            in registers - only q, q dx, q dx^2 and w g need per-pixel work, dy is constant along a row - a 3-step DPP
-//            all-reduce over the 8 lanes of an entry finishes the sums, and two atomic instructions add 8 splats x 10
-//            values into the per-(view, Gaussian) screen-space accumulator:
+//            all-reduce over the 8 lanes of an entry finishes the sums, and two atomic instructions - four whole rows each,
+//            one fabric transaction per row (see `scatter`) - add 8 splats x 10 values into the per-(view, Gaussian)
+//            screen-space accumulator:
 //              scratch[.. * 12 + {0,1: dmean2D  2,3,4: dconic  5: dopacity  6,7,8: dcolor  9: dextra}]
-// Wave (it mod 4) gathers the records of iteration it: list ids three iterations ahead, records two ahead, LDS one ahead.
-// One barrier per batch.  SQ counters of the previous shape (one chain wave + three helpers exchanging alpha, c.g, w and
+// Gather pipeline: the list ids of a batch are requested four iterations ahead, its records three ahead, and they are parked in
+// LDS two ahead (by the wave that requested them, before that iteration's atomics).  One barrier per batch.  SQ counters of the previous shape (one chain wave + three helpers exchanging alpha, c.g, w and
 // dL/dalpha through LDS, exp2 evaluated again in the reduction): 88 VALU instructions per entry and tile, VALU-issue bound.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBS = 8;                       // entries per wave per batch = entries per reduction pass

@@ -569,6 +569,16 @@ def test_three_views_of_512x512():
     _all_checks(cfg, res, max_tiles=64)
 
 
+@pytest.mark.parametrize("hw, flags", [((40, 40), 0), ((352, 352), 0), ((360, 360), 0), ((136, 264), 0x80), ((256, 256), 0)])
+def test_backward_tile_deal_by_load(hw, flags):
+    """k_blend_bwd takes its tile from a heaviest-first deal over the tiles of its XCD: tile counts that are not a multiple of 8
+    (40x40: 36 tiles -> XCDs of 5 and 4; 136x264: 612 -> 77 and 76, here with the fixed-point deterministic accumulators), a
+    last round shorter than the XCD's 32 CUs, 242 tiles per XCD (352x352), 264.5 (360x360: more than the deal looks at -
+    image order) and the headline's 128 - every tile's gradient contributions must arrive exactly once."""
+    cfg, res = _scene_case(31, 6000, hw, views=2, with_extra=True, flags=flags)
+    _all_checks(cfg, res, lists=False, strict=True)
+
+
 def test_footprints_wider_than_the_mask_window_deferred_and_inline():
     """700 splats that each cover a 128 x 128 image (16 x 16 tiles > the 8 x 8-tile mask window): more than the 256 wide
     footprints a binning workgroup defers to whole-wave walks, so the in-line per-lane walk is exercised too."""
