@@ -2565,6 +2565,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   auto eval = [&](uint32_t it) {  // stage E
     const int ring = it & 3;
     const uint32_t base = batch_of(it) * kBB + e0;
+    const uint32_t rem = my_last > base ? my_last - base : 0u;  // entry u of the segment is in front of the pixel's last one <=> u < rem
     int es = e0;  // opaque copy: the three LDS addresses are then formed here, per batch, instead of living in three registers
     if (kExtra) asm volatile("" : "+v"(es));  // across the whole loop (the kExtra instances spilled exactly those)
 #pragma unroll
@@ -2574,7 +2575,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
       const float G = __builtin_amdgcn_exp2f(p2);
       const float og = a2.y * G;
-      const bool contrib = (base + u < my_last) && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
+      const bool contrib = ((uint32_t)u < rem) && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
       al[u] = contrib ? fminf(0.99f, og) : 0.f;
       Gc[u] = contrib ? G : 0.f;
       float cg = c.x * g0;
@@ -2745,7 +2746,10 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     }
     Tb = t; Qb = q;
     replay(Tf, Qk);
-    const RowSum rs = reduce(it);
+    RowSum rs = reduce(it);
+    // the sums are FINISHED here, in the reduction's own basic block: left to itself the compiler sinks the last step of the
+    // DPP all-reduce below the branch that follows, where a cross-lane move can no longer be folded into its add (+18 VALU)
+    asm volatile("" : "+v"(rs.val), "+v"(rs.tail), "+v"(rs.id));
 #if GSR_BWD_WAITALL
     // every wave: nothing of its own is in flight past this point except the atomics that follow (an explicit wait the compiler
     // sees: without it, it has to assume at the top of the loop that a request of an earlier iteration may still be pending on
