@@ -2518,6 +2518,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   // workgroup-uniform: held in scalar registers (the kExtra instances are at the 128-register limit)
   const float hW = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(0.5f * (float)g.W)));
   const float hH = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(0.5f * (float)g.H)));
+  const float cpr = pr == 0 ? hW * kLn2 : pr == 1 ? hH * kLn2 : -0.5f;  // stage R: what float pr of a row is scaled by (besides the opacity)
 
   const uint32_t nbat = (nmax + kBB - 1) / kBB;
   // iteration `it` works on batch nbat-1-it; ring slots are indexed by the iteration number
@@ -2628,15 +2629,21 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     // dL/dG = o dL/dalpha and dG/ddelx = ln2 (2 a2 gdx + b2 gdy), dG/ddely = ln2 (2 c2 gdy + b2 gdx) are linear in them.
     // (Two pixels per packed-fp32 instruction was tried here: 5 % fewer instructions, but the register pairs it needs push
     // the kernel past its 128 registers - the spills cost more than the packing saves.)
-    float S0 = 0, Sx = 0, Sxx = 0, v6 = 0, v7 = 0, v8 = 0, v9 = 0;
+    float v6 = 0, v7 = 0, v8 = 0, v9 = 0;
     const float dx0 = a.x - (float)rpx0, dy = a.y - (float)rpy;
+    // moments of q along the row about its first pixel (weights k and k^2 are instruction literals), shifted to the splat centre
+    // afterwards: sum q (dx0 - k)^n for n = 1, 2 from S0, S1 = sum k q, S2 = sum k^2 q - 22 instructions instead of 39
+    float S0 = qk[0] + qk[1], S1 = qk[1], S2 = qk[1];
+#pragma unroll
+    for (int k = 2; k < 8; ++k) {
+      S0 += qk[k];
+      S1 = __builtin_fmaf(qk[k], (float)k, S1);
+      S2 = __builtin_fmaf(qk[k], (float)(k * k), S2);
+    }
+    float Sx = __builtin_fmaf(dx0, S0, -S1);               // sum q (dx0 - k)
+    float Sxx = __builtin_fmaf(dx0, Sx - S1, S2);          // sum q (dx0 - k)^2 = dx0 (dx0 S0 - 2 S1) + S2
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const float dx = dx0 - (float)k;
-      const float tq = qk[k] * dx;
-      S0 += qk[k];
-      Sx += tq;
-      Sxx = __builtin_fmaf(tq, dx, Sxx);
       v6 = __builtin_fmaf(wk[k], rg0[k], v6);
       v7 = __builtin_fmaf(wk[k], rg1[k], v7);
       v8 = __builtin_fmaf(wk[k], rg2[k], v8);
@@ -2647,24 +2654,30 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) v9 = __builtin_fmaf(wk[k], rge[k], v9);
     }
-    float Sy = dy * S0, Sxy = dy * Sx, Syy = dy * Sy;
-    S0 = oct_allreduce(S0); Sx = oct_allreduce(Sx); Sy = oct_allreduce(Sy);
-    Sxx = oct_allreduce(Sxx); Sxy = oct_allreduce(Sxy); Syy = oct_allreduce(Syy);
-    v6 = oct_allreduce(v6); v7 = oct_allreduce(v7); v8 = oct_allreduce(v8);
+    const float Sy = dy * S0, Sxy = dy * Sx, Syy = dy * Sy;
+    // The eight values a row receives from this entry are LINEAR in the sums, so every lane forms its share of all eight first -
+    // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B - and the eight
+    // lanes of the entry then reduce-SCATTER them: three exchange steps in which a lane keeps the half of its values that its
+    // own float index selects and hands the other half to its partner (i <-> 7 - i, i ^ 2, i ^ 1), 4 + 2 + 1 adds, and lane pr ends
+    // with the complete value pr - instead of ten all-reduces (30 adds) followed by a selection of one of eight results.
+    float F[8] = {__builtin_fmaf(a.w, Sy, (a.z + a.z) * Sx), __builtin_fmaf(a.w, Sx, (a2.x + a2.x) * Sy), Sxx, Sxy, Syy, S0, v6, v7};
+    auto dpp_add = [](float keep, float send, auto ctrl_c) {
+      return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), ctrl_c(), 0xf, 0xf, false));
+    };
+    const bool b2 = (pr & 4) != 0, b1 = (pr & 2) != 0, b0 = (pr & 1) != 0;
+    float K[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) K[k] = dpp_add(b2 ? F[k + 4] : F[k], b2 ? F[k] : F[k + 4], [] { return 0x141; });  // row_half_mirror
+    float L[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) L[k] = dpp_add(b1 ? K[k + 2] : K[k], b1 ? K[k] : K[k + 2], [] { return 0x4E; });   // quad_perm [2,3,0,1]
+    float val = dpp_add(b0 ? L[1] : L[0], b0 ? L[0] : L[1], [] { return 0xB1; });                                   // quad_perm [1,0,3,2]
+    val *= pr < 5 ? a2.y * cpr : 1.f;  // opacity and the constant of the float: hW ln2, hH ln2, -1/2, -1/2, -1/2 | 1, 1, 1
+    v8 = oct_allreduce(v8);
     if (kExtra) v9 = oct_allreduce(v9);
-    // a splat that no pixel of the tile blended (or whose pixels carry no gradient) adds exact zeros: skip its atomics
-    const bool any = (S0 != 0.f) || (Sx != 0.f) || (Sy != 0.f) || (Sxx != 0.f) || (v6 != 0.f) || (v7 != 0.f) || (v8 != 0.f) || (v9 != 0.f);
-    // conic (A,B,C) = (-2 ln2 a2, -ln2 b2, -2 ln2 c2):  dG/ddelx = -gdx A - gdy B,  dG/ddely = -gdy C - gdx B
-    const float o = a2.y;
-    const float v0 = hW * kLn2 * o * (2.f * a.z * Sx + a.w * Sy);
-    const float v1 = hH * kLn2 * o * (2.f * a2.x * Sy + a.w * Sx);
-    const float mh = -0.5f * o;
-    float val = v0;
-    val = pr == 1 ? v1 : val; val = pr == 2 ? mh * Sxx : val; val = pr == 3 ? mh * Sxy : val; val = pr == 4 ? mh * Syy : val;
-    val = pr == 5 ? S0 : val; val = pr == 6 ? v6 : val; val = pr == 7 ? v7 : val;
     RowSum r;
     r.val = val; r.tail = pr == 0 ? v8 : v9;
-    r.id = (any && !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_BWD_NO_ATOMIC)) ? __float_as_uint(a2.z) : 0xffffffffu;
+    r.id = !GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_BWD_NO_ATOMIC) ? __float_as_uint(a2.z) : 0xffffffffu;
     return r;
   };
   // The segment's sums into the accumulator rows of their splats.  Device-scope atomics are executed on the memory side of the
@@ -2688,7 +2701,8 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       const uint32_t id = own ? r.id : o_id;
       const float x = own ? r.val : o_tail;
       const int slot = own ? pr : 8 + pr;
-      if (id != 0xffffffffu && (own || tail_lane)) {
+      // (a lane whose value is an exact zero - a splat that no pixel of the tile blended, or whose pixels carry no gradient - adds nothing)
+      if (id != 0xffffffffu && (own || tail_lane) && x != 0.f) {
         if (kDet) {
           unsigned long long* dst = reinterpret_cast<unsigned long long*>(p.scratch) +
                                     ((size_t)v * p.d.num_gaussians + id) * GSR_SCREEN_GRAD_FLOATS;
