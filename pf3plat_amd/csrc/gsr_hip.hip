@@ -2605,8 +2605,9 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     }
 #pragma unroll
     for (int u = kBS - 1; u >= 0; --u) {  // back to front: Q, and G dL/dalpha = G T (c.g - Q)
-      sQ[wave][u][lane] = Gc[u] * (cgv[u] - q);
-      q = __builtin_fmaf(om[u], q, al[u] * cgv[u]);
+      const float d = cgv[u] - q;
+      sQ[wave][u][lane] = Gc[u] * d;
+      q = __builtin_fmaf(al[u], d, q);  // alpha c.g + (1 - alpha) Q = Q + alpha (c.g - Q): the difference is already there
     }
   };
   struct RowSum { float val, tail; uint32_t id; };
