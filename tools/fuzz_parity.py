@@ -51,12 +51,15 @@ def one_case(rng):
     follows = bool(rng.random() < 0.5)  # the forward saves d rgb / d direction and the backward uses it instead of the harmonics
     if follows:
         flags |= _lib.FLAG_BACKWARD_FOLLOWS
+    det = bool(rng.random() < 0.2)  # 64-bit fixed-point accumulators in the backward blend
+    if det:
+        flags |= _lib.FLAG_DETERMINISTIC
     cfg = RasterConfig(views, sets, vps, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, flags)
     gc = torch.tensor(rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32))
     ge = torch.tensor(rng.uniform(0, 1, (views, h, w)).astype(np.float32)) if with_extra else None
     cap = None if rng.random() < 0.7 else int(rng.integers(1, 5000))
     desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap,
-                planar=planar, cov33=cov33, emode=emode, follows=follows)
+                planar=planar, cov33=cov33, emode=emode, follows=follows, det=det)
     one_case.last = desc
     one_case.inputs = (cfg, vb, means, cov6, opac, colors, extra, gc, ge)
     res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
