@@ -77,9 +77,14 @@ extern "C" {
 /* Test aid: take the windowed binning path (preprocess, count, prefix, scan, emit, sort) even when the image has few enough
  * tiles for the fused one (k_preprocess_bin + gathering sort). */
 #define GSR_FLAG_WINDOWED_BINNING 0x4000
+/* Test aid: every per-tile index list is depth-ordered to its end.  Without it the tile launch of the usual case orders only
+ * the nearest ~512 entries of a list before it blends and the rest only if the blend gets that far (a tile of a dense scene
+ * stops after a quarter of its list): positions of a list beyond max(512, entries the tile walked) are then undefined.  The
+ * backward never reads them.  Images, gradients and the status block are the same either way. */
+#define GSR_FLAG_FULL_LISTS 0x20000
 /* Every other bit is rejected (GSR_ERR_INVALID_ARGUMENT). */
 #define GSR_FLAG_VALID_MASK (GSR_FLAG_PREFILTERED | GSR_FLAG_DEBUG | GSR_FLAG_SH_PLANAR | GSR_FLAG_COV_3X3 | 0x70 | \
-                             GSR_FLAG_DETERMINISTIC | GSR_FLAG_WINDOWED_BINNING | GSR_FLAG_BACKWARD_FOLLOWS)
+                             GSR_FLAG_DETERMINISTIC | GSR_FLAG_WINDOWED_BINNING | GSR_FLAG_BACKWARD_FOLLOWS | GSR_FLAG_FULL_LISTS)
 #ifdef GSR_ABLATE
 /* Measurement-only build (tools/ablate.py compiles its own copy of the library with -DGSR_ABLATE; the product library does
  * not contain these branches and rejects the bits): switches that make results WRONG on purpose to time a kernel without

@@ -24,6 +24,7 @@ FLAG_SH_PLANAR = 0x4
 FLAG_COV_3X3 = 0x8
 FLAG_DETERMINISTIC = 0x80  # backward accumulates in 64-bit fixed point: bit-identical from run to run
 FLAG_BACKWARD_FOLLOWS = 0x10000  # forward zero-fills the backward's accumulator rows (inside geom); backward scratch may be None
+FLAG_FULL_LISTS = 0x20000  # test aid: every per-tile list depth-ordered to its end (default: the nearest ~512 entries + what the blend walks)
 FLAG_WINDOWED_BINNING = 0x4000  # test aid: the windowed binning path on an image small enough for the fused one
 
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]

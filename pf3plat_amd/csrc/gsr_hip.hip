@@ -2116,47 +2116,28 @@ struct BlendLds {
   uint32_t sLast[kFwdWaves][64];
 };
 
-// The blend of tile t of view v over the index-list range rg (256 threads; `lds` may alias anything the workgroup is done with)
-template <bool kExtra>
-__device__ __forceinline__ void blend_tile(const Params& p, const int v, const int t, const uint2 rg, BlendLds& lds) {
-  auto& sXY = lds.sXY; auto& sAB = lds.sAB; auto& sCO = lds.sCO; auto& sRG = lds.sRG; auto& sBE = lds.sBE;
-  auto& sP = lds.sP; auto& sPart = lds.sPart; auto& sLast = lds.sLast;
-  const Grid& g = p.g;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int tx = t % g.sgx, ty = t / g.sgx;
-  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
-  const bool inside = pxi < g.W && pyi < g.H;
-  const float pxf = (float)pxi, pyf = (float)pyi;
-  const uint32_t n = rg.y - rg.x;
-  const uint32_t nbat = (n + kFB - 1) / kFB;
-  const uint32_t* plist = p.point_list + rg.x;
-  const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
-  const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
+// What a tile's blend carries from one range of its list to the next (k_tile_fwd_prefix blends the ranked prefix of the list
+// first and comes back for the rest only if some pixel is still open): the free-running transmittance at the start of the
+// next batch (the same bits in all four waves), and this wave's partial results.
+struct BlendAcc {
+  float Tb;     // free-running transmittance at the start of the batch (same in all waves)
+  float Tmin;   // smallest transmittance that passed the test in this wave's segments
+  f2 CR, CG, CB, CE;  // colour sums over even / odd entries
+  uint32_t last, consumed;
+};
 
-  // the view's background through scalar loads, asked for now: read as `p.views[v].bg` where it is used - in the tile's last
-  // instructions - every tile ended with a memory round trip
-  typedef const __attribute__((address_space(4))) float* cfptr;
-  cfptr camc = reinterpret_cast<cfptr>(reinterpret_cast<uintptr_t>(p.views + __builtin_amdgcn_readfirstlane(v)));
-  const float bg0 = camc[37], bg1 = camc[38], bg2 = camc[39];  // GsrView::bg
-  if (p.status->overflow) {  // pair workspace too small: nothing was binned.  Poison the outputs so the condition cannot go
-    if (wave == 0 && inside) {  // unnoticed even when the caller defers reading the status block.
-      const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
-      const float qnan = __uint_as_float(0x7fc00000u);
-      float* oc = p.out_color + (size_t)v * 3 * HW;
-      oc[pix] = qnan; oc[HW + pix] = qnan; oc[2 * HW + pix] = qnan;
-      if (kExtra) p.out_extra[(size_t)v * HW + pix] = qnan;
-      p.final_T[(size_t)v * HW + pix] = 1.f;
-      p.n_contrib[(size_t)v * HW + pix] = 0u;
-    }
-    return;
-  }
-  float Tb = inside ? 1.f : 0.f;               // free-running transmittance at the start of the batch (same in all waves)
-  float Tmin = 1.f;                             // smallest transmittance that passed the test in this wave's segments
+// Batches [b0, nbat) of the list `plist` (entries at positions >= n read as null records), 256 threads.  Returns true when every
+// pixel's loop has stopped (workgroup-uniform: the decision is taken on bit-identical values in all four waves).
+template <bool kExtra>
+__device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* rgbc, const uint32_t* plist, const uint32_t n,
+                                            const uint32_t b0, const uint32_t nbat, BlendLds& lds, BlendAcc& s, const float pxf,
+                                            const float pyf) {
+  auto& sXY = lds.sXY; auto& sAB = lds.sAB; auto& sCO = lds.sCO; auto& sRG = lds.sRG; auto& sBE = lds.sBE;
+  auto& sP = lds.sP;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float Tb = s.Tb, Tmin = s.Tmin;
   f2 al[kFS / 2];                               // alphas of this wave's segment of the batch about to be accumulated
-  uint32_t last = 0, consumed = 0;
-  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
-  unsigned long long tm0 = 0, tm1 = 0, rt0 = 0;
-  if (dbg) { tm0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  uint32_t last = s.last, consumed = s.consumed;
   const int e0 = wave * kFS;
 
   const f2 px2 = {pxf, pxf}, py2 = {pyf, pyf};
@@ -2180,7 +2161,7 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
     }
     sP[b & 1][wave][lane] = P2.x * P2.y;
   };
-  f2 CR = {0.f, 0.f}, CG = {0.f, 0.f}, CB = {0.f, 0.f}, CE = {0.f, 0.f};  // colour sums over even / odd entries
+  f2 CR = s.CR, CG = s.CG, CB = s.CB, CE = s.CE;  // colour sums over even / odd entries
   // Stage A; Tf = transmittance at the start of this wave's segment.  A pixel's loop has stopped <=> T (1 - alpha) < 1e-4, and T
   // only falls: within the entries a wave sees, "alive" is a PREFIX.  So a pixel that is dead on entry (Tf < 1e-4: it died at an
   // earlier entry) is given T = 0 - every weight of the segment is then 0 by itself - and only a segment INSIDE which some pixel
@@ -2239,38 +2220,39 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
     rg2[o] = c.x; rg2[o + 2] = c.y; be[o] = c.z; be[o + 2] = c.w;
   };
 
-  if (nbat > 0) {
-    // ---- gather pipeline: wave w brings in the batches b = w (mod 4).  The records of a batch are requested FOUR iterations
+  bool done = false;
+  if (nbat > b0) {
+    // ---- gather pipeline: the wave with (wave - b) % 4 == 0 brings in batch b.  The records of a batch are requested FOUR iterations
     // before they are parked in LDS (and its list ids four iterations before that): a tile that is left alone on its SIMDs runs
     // an iteration in ~0.4 us, less than one trip to HBM - with the loads issued only one iteration ahead the last tiles of
     // every CU ran at memory latency (1.4 us per batch, measured) exactly when nothing else was there to cover it.
-    // Prologue: waves 0 / 1 stage batches 0 / 1 at once and request 4 / 5; waves 2 / 3 request 2 / 3; everyone evaluates batch 0.
+    // Prologue (w = the wave's number relative to the first batch): w = 0 / 1 stage batches b0 / b0 + 1 at once and request
+    // b0 + 4 / b0 + 5; w = 2 / 3 request b0 + 2 / b0 + 3; everyone evaluates batch b0.
     float4 sg = make_float4(0, 0, 0, 0), sc = sg;
     float2 sg2 = make_float2(0, 0);
     uint32_t id_next = 0;
     const auto list_id = [&](uint32_t b) { return (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u; };
     if (lane < kFB) {
-      const uint32_t w = (uint32_t)wave;
+      const uint32_t w = (uint32_t)(wave - (int)b0) & 3u, bw = b0 + w;
       if (w < 2) {
-        const uint32_t id0 = list_id(w), id4 = list_id(w + 4);
-        id_next = list_id(w + 8);
-        if (w < nbat) {
-          stage_batch(geom, rgbc, n, w * kFB, lane, id0, kExtra, sg, sg2, sc);
-          put_records((int)w, sg, sg2, sc);
+        const uint32_t id0 = list_id(bw), id4 = list_id(bw + 4);
+        id_next = list_id(bw + 8);
+        if (bw < nbat) {
+          stage_batch(geom, rgbc, n, bw * kFB, lane, id0, kExtra, sg, sg2, sc);
+          put_records((int)(bw & 3), sg, sg2, sc);
         }
-        stage_batch(geom, rgbc, n, (w + 4) * kFB, lane, id4, kExtra, sg, sg2, sc);
+        stage_batch(geom, rgbc, n, (bw + 4) * kFB, lane, id4, kExtra, sg, sg2, sc);
       } else {
-        const uint32_t id2 = list_id(w);
-        id_next = list_id(w + 4);
-        stage_batch(geom, rgbc, n, w * kFB, lane, id2, kExtra, sg, sg2, sc);
+        const uint32_t id2 = list_id(bw);
+        id_next = list_id(bw + 4);
+        stage_batch(geom, rgbc, n, bw * kFB, lane, id2, kExtra, sg, sg2, sc);
       }
     }
     __syncthreads();
-    eval(0);
+    eval(b0);
     __syncthreads();
-    if (dbg) tm1 = __builtin_readcyclecounter();
     // ---- steady state, iteration i: A(i), E(i+1) | batch i+2 parked in LDS, batch i+6 requested, ids of batch i+10 requested
-    for (uint32_t i = 0; i < nbat; ++i) {
+    for (uint32_t i = b0; i < nbat; ++i) {
       const float P0 = sP[i & 1][0][lane], P1 = sP[i & 1][1][lane], P2 = sP[i & 1][2][lane], P3 = sP[i & 1][3][lane];
       const uint32_t bs = i + 2;
       const bool duty = (wave == (int)(bs & 3)) && (lane < kFB);
@@ -2286,27 +2268,52 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
       Tb = t4;
       consumed = (i + 1) * kFB;
       __syncthreads();
-      if (__all(Tb < 0.0001f)) break;  // bit-identical Tb in all four waves: a workgroup-uniform decision
+      if (__all(Tb < 0.0001f)) { done = true; break; }  // bit-identical Tb in all four waves: a workgroup-uniform decision
     }
   }
-  float C0 = CR.x + CR.y, C1 = CG.x + CG.y, C2 = CB.x + CB.y, E = CE.x + CE.y;  // this wave's partial colour sums
+  s.Tb = Tb; s.Tmin = Tmin; s.CR = CR; s.CG = CG; s.CB = CB; s.CE = CE; s.last = last; s.consumed = consumed;
+  return done;
+}
+
+// Pair workspace too small (status->overflow): nothing was binned.  Poison the outputs so the condition cannot go unnoticed
+// even when the caller defers reading the status block.  Workgroup-uniform result: true = poisoned, nothing to blend.
+template <bool kExtra>
+__device__ __forceinline__ bool blend_poisoned(const Params& p, const int v, const int pxi, const int pyi, const bool inside,
+                                               const bool known = false) {
+  // (the flag may be raised by another tile while this workgroup's waves read it: the decision is taken once for the workgroup)
+  if (!known && !__syncthreads_or((int)(p.status->overflow != 0u))) return false;
+  const Grid& g = p.g;
+  if (threadIdx.x < 64 && inside) {
+    const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
+    const float qnan = __uint_as_float(0x7fc00000u);
+    float* oc = p.out_color + (size_t)v * 3 * HW;
+    oc[pix] = qnan; oc[HW + pix] = qnan; oc[2 * HW + pix] = qnan;
+    if (kExtra) p.out_extra[(size_t)v * HW + pix] = qnan;
+    p.final_T[(size_t)v * HW + pix] = 1.f;
+    p.n_contrib[(size_t)v * HW + pix] = 0u;
+  }
+  return true;
+}
+
+// The four waves' partial results -> the pixel: image, final transmittance, contributor count; the entries the tile walked.
+template <bool kExtra>
+__device__ __forceinline__ void blend_finish(const Params& p, const int v, const int t, const uint32_t n, BlendLds& lds, const BlendAcc& s,
+                                             const int pxi, const int pyi, const bool inside, const float bg0, const float bg1,
+                                             const float bg2) {
+  auto& sPart = lds.sPart; auto& sLast = lds.sLast;
+  const Grid& g = p.g;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float C0 = s.CR.x + s.CR.y, C1 = s.CG.x + s.CG.y, C2 = s.CB.x + s.CB.y, E = s.CE.x + s.CE.y;  // this wave's partial colour sums
   sPart[wave][0][lane] = C0; sPart[wave][1][lane] = C1; sPart[wave][2][lane] = C2;
   if (kExtra) sPart[wave][3][lane] = E;
-  sPart[wave][4][lane] = Tmin;
-  sLast[wave][lane] = last;
+  sPart[wave][4][lane] = s.Tmin;
+  sLast[wave][lane] = s.last;
   __syncthreads();
-  if (dbg && threadIdx.x == 0) {
-    unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
-    // where it ran: HW_ID (id 4: wave, simd, pipe, cu, sh, se ...) and XCC_ID (id 20), 16 bits each
-    const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
-                        ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
-    o[0] = tm0; o[1] = ((unsigned long long)hw << 32) | (unsigned)(tm1 - tm0); o[2] = __builtin_readcyclecounter();
-    o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
-  }
   if (wave == 0) {
-    if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(consumed, n);  // statistics: list entries this tile walked
+    if (lane == 0) p.tile_total[(size_t)v * g.T + t] = min(s.consumed, n);  // statistics: list entries this tile walked
     if (inside) {
-      float T = Tmin;
+      float T = s.Tmin;
+      uint32_t last = s.last;
 #pragma unroll
       for (int h = 1; h < kFwdWaves; ++h) {
         C0 += sPart[h][0][lane]; C1 += sPart[h][1][lane]; C2 += sPart[h][2][lane];
@@ -2326,6 +2333,41 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
       if (kExtra) p.out_extra[(size_t)v * HW + pix] = E;
     }
   }
+}
+
+// The blend of tile t of view v over the index-list range rg (256 threads; `lds` may alias anything the workgroup is done with)
+template <bool kExtra>
+__device__ __forceinline__ void blend_tile(const Params& p, const int v, const int t, const uint2 rg, BlendLds& lds) {
+  const Grid& g = p.g;
+  const int lane = threadIdx.x & 63;
+  const int tx = t % g.sgx, ty = t / g.sgx;
+  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
+  const bool inside = pxi < g.W && pyi < g.H;
+  const uint32_t n = rg.y - rg.x;
+  // the view's background through scalar loads, asked for now: read as `p.views[v].bg` where it is used - in the tile's last
+  // instructions - every tile ended with a memory round trip
+  typedef const __attribute__((address_space(4))) float* cfptr;
+  cfptr camc = reinterpret_cast<cfptr>(reinterpret_cast<uintptr_t>(p.views + __builtin_amdgcn_readfirstlane(v)));
+  const float bg0 = camc[37], bg1 = camc[38], bg2 = camc[39];  // GsrView::bg
+  if (blend_poisoned<kExtra>(p, v, pxi, pyi, inside)) return;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
+  unsigned long long tm0 = 0, rt0 = 0;
+  if (dbg) { tm0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  BlendAcc acc;
+  acc.Tb = inside ? 1.f : 0.f; acc.Tmin = 1.f;
+  acc.CR = f2{0.f, 0.f}; acc.CG = acc.CR; acc.CB = acc.CR; acc.CE = acc.CR;
+  acc.last = 0; acc.consumed = 0;
+  (void)blend_range<kExtra>(p.geom + (size_t)v * p.d.num_gaussians, p.rgbc + (size_t)v * p.d.num_gaussians, p.point_list + rg.x, n, 0u,
+                            (n + kFB - 1) / kFB, lds, acc, (float)pxi, (float)pyi);
+  if (dbg && threadIdx.x == 0) {
+    unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
+    // where it ran: HW_ID (id 4: wave, simd, pipe, cu, sh, se ...) and XCC_ID (id 20), 16 bits each
+    const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
+                        ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
+    o[0] = tm0; o[1] = ((unsigned long long)hw << 32); o[2] = __builtin_readcyclecounter();
+    o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
+  }
+  blend_finish<kExtra>(p, v, t, n, lds, acc, pxi, pyi, inside, bg0, bg1, bg2);
 }
 
 // One launch per tile for both: the tile's sort (its gather latency under the blend arithmetic of the other tiles of the CU),
@@ -2352,6 +2394,342 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
   const int tg = kGather ? xcd_remap((int)bid, (int)p.sort_blocks) : (int)bid;
   const int v = tg / p.g.T;
   blend_tile<kExtra>(p, v, tg - v * p.g.T, rg, *reinterpret_cast<BlendLds*>(smem));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 for the usual case (round 4): fused binning, at most kSortThreads binning rows, lists that sit in their slots of at most 2048
+// entries.  Same results as k_tile_fwd<true, 2048, .>, two things done differently:
+//   * gather without the scan over the rows: a row's run takes its place in the LDS key array with one LDS atomic on a cursor
+//     (the order of the runs does not matter - the sort that follows is total), the depth range of the tile is taken from the keys
+//     as they pass through the copying thread's registers, and the bucket histogram is filled in the pass that brings the keys
+//     back into registers: two block-wide phases (and four barriers) fewer than sort_tile before the first key is in its bucket;
+//   * PREFIX RANK.  A tile of the 300 k / 256 x 256 workload lists ~1220 splats and its blend walks 224-448 of them (measured:
+//     every pixel's transmittance is below 1e-4 by then; tools/sim_tiles.py replays it on the CPU).  Buckets are in depth order,
+//     so after the scatter the first kPrefix positions of the key array hold exactly the kPrefix nearest splats: only those are
+//     ranked (the quadratic-in-bucket-size part of the sort) and written to the index list before the blend starts.  The key
+//     array and the bucket cursors stay in LDS beside the blend's own area; a tile whose pixels are still open when the prefix is
+//     used up ranks the rest then and goes on (an outer loop around the blend's range, the batch loop itself is untouched).  The
+//     backward reads a tile's list up to the largest contributor count of its pixels, which lies inside what was ranked.
+//     GSR_FLAG_FULL_LISTS ranks everything at once (tests that look at the whole list).
+// Everything unusual - a run that was not stored, a list longer than its slot or than the LDS array, a degenerate depth
+// distribution - goes through sort_tile<true, 2048> as before (the workgroup starts over: rare).
+// ------------------------------------------------------------------------------------------------
+#ifndef GSR_PREFIX
+#define GSR_PREFIX 512
+#endif
+#ifndef GSR_NO_PREFIX_KERNEL
+#define GSR_NO_PREFIX_KERNEL 0  // 1: measurement builds that time the round-3 tile launch (k_tile_fwd<true, 2048, .>) on the same tree
+#endif
+constexpr int kPrefix = GSR_PREFIX;  // list positions ranked before the blend starts (a multiple of kFB)
+static_assert(kPrefix % kFB == 0 && kPrefix >= 2 * kFB, "the prefix is whole batches");
+
+// The rare paths of k_tile_fwd_prefix as real calls (s_swappc), NOT inlined: with them inline the kernel was 22.7 KB of code with the
+// usual path scattered through it, and every phase of every tile ran 2-3 x slower (forward 65 us against 56) - four tiles per CU
+// in four different phases fetch four different parts of the kernel, and the instruction cache (shared by two CUs) no longer
+// held them.  The usual path is one compact run of code.
+#ifndef GSR_PREFIX_NOINLINE
+#define GSR_PREFIX_NOINLINE 0
+#endif
+#if GSR_PREFIX_NOINLINE
+#define GSR_COLD __attribute__((noinline))
+#else
+#define GSR_COLD __forceinline__
+#endif
+GSR_COLD __device__ uint2 sort_tile_general_2048(const Params& p, const uint32_t bid, unsigned long long* smem, uint32_t* red, uint32_t* sInfo) {
+  return sort_tile<true, 2048>(p, bid, smem, red, sInfo);
+}
+GSR_COLD __device__ void bitonic_whole_list(unsigned long long* sk, uint32_t* out, const int n) {
+  int lgnp = 1;
+  while ((1 << lgnp) < n) ++lgnp;
+  bitonic_block(sk, n, lgnp, (int)threadIdx.x);
+  for (int k = threadIdx.x; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
+}
+
+template <bool kExtra>
+__global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params p) {
+  constexpr int kLds = 2048;
+  constexpr int kBk = SortLds<kLds>::kBuckets, kBkBits = SortLds<kLds>::kBucketBits, kBpt = kBk / kSortThreads;
+  constexpr int Q = kLds / kSortThreads;
+  __shared__ __attribute__((aligned(16))) unsigned long long smem[SortLds<kLds>::kWords];  // keys | bucket counters, then cursors
+#ifndef GSR_PREFIX_ALIAS
+#define GSR_PREFIX_ALIAS 0  // 1 (measurement): the blend's area over the keys as in k_tile_fwd, every list ranked to its end
+#endif
+#if GSR_PREFIX_ALIAS
+  BlendLds& blds = *reinterpret_cast<BlendLds*>(smem);
+#else
+  __shared__ __attribute__((aligned(16))) BlendLds blds;  // NOT over the keys: a tile may come back to rank the rest of its list
+#endif
+  __shared__ uint32_t red[8];
+  __shared__ uint32_t sInfo[4];
+  __shared__ uint32_t sCount;
+#ifndef GSR_PF_EARLY_STATUS
+#define GSR_PF_EARLY_STATUS 1  // status->overflow asked for at the kernel's start instead of between the sort and the blend
+#endif
+  const uint32_t bid = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // (overflow is raised by tiles of THIS launch only - a tile that cannot place its list - and such a tile poisons its own pixels
+  // whatever it read here; for everybody else the flag is a courtesy whose outcome depends on timing either way)
+  uint32_t overflow_early = 0;
+  if (GSR_PF_EARLY_STATUS && tid == 0) overflow_early = p.status->overflow;
+  unsigned long long* sk = smem;
+  uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kLds);
+  uint32_t* cur = hist;
+  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
+  unsigned long long* stamp = dbg_stamps(p, 8192 + bid);
+  unsigned long long* stamp2 = dbg_stamps(p, 8192 + p.sort_blocks + bid);
+#define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define GSR_STAMP2(k) do { if (dbg && tid == 0) stamp2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(GSR_SORT_PRIO);
+  GSR_STAMP(0);
+  const int T = p.g.T, R = p.rows;
+  const int tg = xcd_remap((int)bid, (int)p.sort_blocks);
+  const int v = tg / T, t = tg - v * T;
+  // (de-phasing of the first resident round: see sort_tile.  With this kernel's shorter gather 1 us between the four groups is
+  // enough: sleeps of 16 / 24 / 32 / 40 / 64 gave 53.0 / 52.9 / 53.0 / 53.0 / 53.9 us for the forward)
+#ifndef GSR_PF_DEPHASE_SLEEP
+#define GSR_PF_DEPHASE_SLEEP 32
+#endif
+  if (bid < 1024u)
+    for (int q = 0; q < (int)((bid >> GSR_DEPHASE_SHIFT) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_PF_DEPHASE_SLEEP);
+  // ---- gather: column (v, :, t) of the pair matrix, one row per thread
+  uint2 e0 = make_uint2(0u, 0u);
+  uint32_t bb0 = 0;
+  if (tid < R) {
+    e0 = p.pair_mat[((size_t)v * R + tid) * ((size_t)T + 8) + t];
+    bb0 = p.blk_base[(size_t)v * R + tid];
+  }
+  for (int k = tid; k < kBk; k += kSortThreads) hist[k] = 0;  // (while the column is on its way)
+  if (tid == 0) sCount = 0;
+  __syncthreads();
+  GSR_STAMP2(0);
+  const bool has = e0.y != 0u, miss = has && bb0 == 0xffffffffu;
+  // a run's place in the key array: the wave's runs side by side (DPP scan of the counts), the wave's block from ONE atomic on
+  // the cursor - 247 lanes adding to the same LDS word are processed one lane after the other and hold up the LDS pipeline of
+  // the whole CU while they are (measured: the per-lane form made every LDS phase of every tile on the CU 2-3 x slower)
+#ifdef GSR_PF_SCAN  // (experiment: the rows' places from a block scan, as sort_tile does)
+  uint32_t tot_scan;
+  const uint32_t start0 = block_exclusive_scan(e0.y, red, tid, tot_scan);
+  if (tid == 0) sCount = tot_scan;
+  __syncthreads();
+#else
+  const uint32_t incl = wave_inclusive_scan_u32(e0.y);
+  uint32_t wbase = 0;
+  if (lane == 63 && incl) wbase = atomicAdd(&sCount, incl);
+  wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
+  const uint32_t start0 = wbase + incl - e0.y;
+#endif
+  const bool fits = start0 + e0.y <= (uint32_t)kLds;
+  GSR_STAMP2(1);
+  uint32_t lo = 0xffffffffu, hi = 0u;
+  if (has && !miss && fits) {
+    // six keys per step as three 16-byte loads issued together; the loads may run one key past the run (the buffer is padded)
+    const unsigned long long* src = p.keys + bb0 + e0.x;
+    unsigned long long* d0 = sk + start0;
+    auto take = [&](unsigned long long* d, unsigned long long key) {
+      *d = key;
+      const uint32_t dep = (uint32_t)(key >> 32);
+      lo = dep < lo ? dep : lo;
+      hi = dep > hi ? dep : hi;
+    };
+    for (uint32_t j = 0; j < e0.y; j += 6) {
+      const ull2 a = *reinterpret_cast<const ull2*>(src + j);
+      ull2 b = {0ull, 0ull}, c = {0ull, 0ull};
+      if (j + 2 < e0.y) b = *reinterpret_cast<const ull2*>(src + j + 2);
+      if (j + 4 < e0.y) c = *reinterpret_cast<const ull2*>(src + j + 4);
+      unsigned long long* d = d0 + j;
+      take(d, a.x);
+      if (j + 1 < e0.y) take(d + 1, a.y);
+      if (j + 2 < e0.y) take(d + 2, b.x);
+      if (j + 3 < e0.y) take(d + 3, b.y);
+      if (j + 4 < e0.y) take(d + 4, c.x);
+      if (j + 5 < e0.y) take(d + 5, c.y);
+    }
+  }
+  hi = wave_max_u32(hi);
+  lo = ~wave_max_u32(~lo);
+  if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+  if (tid == 0) sInfo[3] = overflow_early;
+  const bool bad = __syncthreads_or((int)(miss || (has && !fits))) != 0;
+  GSR_STAMP2(2);
+  GSR_STAMP(1);
+  uint32_t n = sCount, ranked = 0, obase = (uint32_t)tg * p.stride;
+  uint32_t dlo = 0;
+  int shift = 0;
+  bool fast_path = false;
+  bool bucketed = false;  // the keys sit in bucket order in `sk`, cur[b] = end of bucket b: positions are ranked on demand
+  if (bad || n > p.stride) {  // workgroup-uniform: the general path, from the start
+    __syncthreads();
+#ifdef GSR_PREFIX_NOGENERAL  // (experiment: how much of the kernel's time is the SIZE of its code?)
+    if (tid == 0) { p.status->overflow = 1u; p.ranges[tg] = make_uint2(0u, 0u); }
+    n = 0; ranked = 0;
+#else
+    const uint2 rg = sort_tile_general_2048(p, bid, smem, red, sInfo);
+    obase = rg.x; n = rg.y - rg.x; ranked = n;
+#endif
+  } else {
+    if (tid == 0) p.ranges[tg] = make_uint2(obase, obase + n);
+    fast_path = true;
+    if (bid == 0) {  // total pair count = sum of the binning workgroups' totals
+      unsigned long long part = 0;
+      for (int k = tid; k < p.d.num_views * R; k += kSortThreads) part += p.blk_total[k];
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+      __shared__ unsigned long long sPartSum[kSortThreads / 64];
+      if (lane == 0) sPartSum[wave] = part;
+      __syncthreads();
+      if (tid == 0) p.status->num_pairs = sPartSum[0] + sPartSum[1] + sPartSum[2] + sPartSum[3];
+    }
+    uint32_t* out = p.point_list + obase;
+    if (n == 1) {
+      if (tid == 0) out[0] = (uint32_t)sk[0];
+      ranked = 1;
+    } else if (n > 1) {
+      dlo = min(min(red[0], red[1]), min(red[2], red[3]));
+      const uint32_t dhi = max(max(red[4], red[5]), max(red[6], red[7]));
+      const uint32_t range = dhi - dlo;
+      shift = range < (uint32_t)kBk ? 0 : (32 - __clz((int)range)) - kBkBits;
+      unsigned long long kreg[Q];
+#ifdef GSR_PF_SPLIT  // (experiment: keys to registers, barrier, then the histogram - as sort_tile does)
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int k = tid + q * kSortThreads;
+        kreg[q] = (k < (int)n) ? sk[k] : ~0ull;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < Q; ++q)
+        if (tid + q * kSortThreads < (int)n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - dlo) >> shift], 1u);
+#else
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int k = tid + q * kSortThreads;
+        kreg[q] = (k < (int)n) ? sk[k] : ~0ull;
+        if (k < (int)n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - dlo) >> shift], 1u);
+      }
+#endif
+      __syncthreads();
+      GSR_STAMP(2);
+      // exclusive scan of the bucket counts: thread t owns kBpt consecutive buckets
+      uint32_t c[kBpt], span = 0, cmax = 0;
+#pragma unroll
+      for (int q = 0; q < kBpt; ++q) { c[q] = hist[kBpt * tid + q]; span += c[q]; cmax = max(cmax, c[q]); }
+      uint32_t total;
+      uint32_t start = block_exclusive_scan(span, red, tid, total);
+#pragma unroll
+      for (int q = 0; q < kBpt; ++q) { cur[kBpt * tid + q] = start; start += c[q]; }
+      const bool big = __syncthreads_or(cmax > (uint32_t)kSpanMax) != 0;
+      GSR_STAMP(3);
+      if (big) {  // degenerate depth distribution: the bitonic network on the same array, whole list
+#ifdef GSR_PREFIX_NOGENERAL
+        if (tid == 0) p.status->overflow = 1u;
+#else
+        bitonic_whole_list(sk, out, (int)n);
+#endif
+        ranked = n;
+      } else {
+        // scatter into bucket order (every key is in a register: in place)
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (tid + q * kSortThreads < (int)n) {
+            const uint32_t slot = atomicAdd(&cur[((uint32_t)(kreg[q] >> 32) - dlo) >> shift], 1u);
+            sk[slot] = kreg[q];
+          }
+        __syncthreads();
+        GSR_STAMP(4);
+        // after the scatter cur[b] is the END of bucket b.  Rank the buckets that reach into the first kPrefix positions
+        ranked = n;
+        if (!GSR_PREFIX_ALIAS && !(p.d.flags & GSR_FLAG_FULL_LISTS) && n > (uint32_t)(kPrefix + kPrefix / 4))
+          ranked = cur[((uint32_t)(sk[kPrefix - 1] >> 32) - dlo) >> shift];
+        bucketed = true;
+      }
+    }
+  }
+  // finish by ranking: every entry counts the smaller keys of its own bucket (keys are unique: they carry the Gaussian index) and goes
+  // straight to its final slot in the global list; four bucket members per step, requested together
+  auto rank_positions = [&](uint32_t k0, uint32_t k1) {
+    uint32_t* out = p.point_list + obase;
+    for (int k = (int)k0 + tid; k < (int)k1; k += kSortThreads) {
+      const unsigned long long key = sk[k];
+      const uint32_t b = ((uint32_t)(key >> 32) - dlo) >> shift;
+      const int bs = b ? (int)cur[b - 1] : 0, be = (int)cur[b];
+      int rank = bs;
+      for (int j = bs; j < be; j += 4) {
+        const unsigned long long k0_ = sk[j], k1_ = sk[min(j + 1, be - 1)], k2_ = sk[min(j + 2, be - 1)], k3_ = sk[min(j + 3, be - 1)];
+        rank += (k0_ < key ? 1 : 0) + ((j + 1 < be && k1_ < key) ? 1 : 0) + ((j + 2 < be && k2_ < key) ? 1 : 0) +
+                ((j + 3 < be && k3_ < key) ? 1 : 0);
+      }
+      out[rank] = (uint32_t)key;
+    }
+  };
+  if (bucketed) rank_positions(0u, ranked);
+  GSR_STAMP(5);
+  GSR_STAMP(6);
+  if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(0);
+  if (bid == 0 && tid == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;  // the binning launch's (take_pages)
+  __syncthreads();  // the list is this workgroup's own: its stores are visible to its waves from here on
+#ifdef GSR_PF_OLDBLEND  // (experiment: the one-range blend of k_tile_fwd behind the new gather / sort)
+  rank_positions(ranked, n);
+  __syncthreads();
+  blend_tile<kExtra>(p, v, t, make_uint2(obase, obase + n), blds);
+  return;
+#endif
+  // ---- blend: the ranked prefix (whole batches of it), then - only if some pixel is still open - the rest
+  const Grid& g = p.g;
+  const int tx = t % g.sgx, ty = t / g.sgx;
+  const int pxi = tx * 8 + (lane & 7), pyi = ty * 8 + (lane >> 3);
+  const bool inside = pxi < g.W && pyi < g.H;
+  typedef const __attribute__((address_space(4))) float* cfptr;
+  cfptr camc = reinterpret_cast<cfptr>(reinterpret_cast<uintptr_t>(p.views + __builtin_amdgcn_readfirstlane(v)));
+  const float bg0 = camc[37], bg1 = camc[38], bg2 = camc[39];  // GsrView::bg
+  // the longest list so far (statistics for the caller's sizing): as the tile's LAST memory operation.  Where sort_tile has it -
+  // between the gather and the next barrier - a barrier's wait for outstanding memory operations includes this load and, for the
+  // first tiles to arrive, a device-scope atomic on an address every tile of the launch goes for
+  auto report_length = [&]() {
+    if (fast_path && tid == 64 && n > p.status->max_list) atomicMax(&p.status->max_list, n);
+  };
+  // (usual path: the flag as thread 0 read it at the kernel's start, handed round through LDS - the same value in every wave)
+  if ((GSR_PF_EARLY_STATUS && fast_path) ? (sInfo[3] != 0u && blend_poisoned<kExtra>(p, v, pxi, pyi, inside, true))
+                                          : blend_poisoned<kExtra>(p, v, pxi, pyi, inside)) {
+    report_length();
+    return;
+  }
+  unsigned long long tm0 = 0, rt0 = 0;
+  if (dbg) { tm0 = __builtin_readcyclecounter(); rt0 = __builtin_amdgcn_s_memrealtime(); }
+  BlendAcc acc;
+  acc.Tb = inside ? 1.f : 0.f; acc.Tmin = 1.f;
+  acc.CR = f2{0.f, 0.f}; acc.CG = acc.CR; acc.CB = acc.CR; acc.CE = acc.CR;
+  acc.last = 0; acc.consumed = 0;
+  const GeomRec* geom = p.geom + (size_t)v * p.d.num_gaussians;
+  const float4* rgbc = p.rgbc + (size_t)v * p.d.num_gaussians;
+  const uint32_t* plist = p.point_list + obase;
+  const uint32_t nbat = (n + kFB - 1) / kFB;
+  uint32_t b0 = 0;
+#pragma clang loop unroll(disable)
+  for (int pass = 0; pass < 2; ++pass) {
+    // pass 0: the whole batches inside the ranked prefix (all of the list when everything was ranked); pass 1: from there to the end
+    const bool whole = ranked >= n;
+    const uint32_t b1 = whole ? nbat : ranked / kFB;
+    bool done = blend_range<kExtra>(geom, rgbc, plist, whole ? n : b1 * kFB, b0, b1, blds, acc, (float)pxi, (float)pyi);
+    done = done || whole || __all(acc.Tb < 0.0001f);  // (Tb: the same bits in all four waves)
+    if (done) break;
+    if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(GSR_SORT_PRIO);
+    rank_positions(ranked, n);
+    if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(0);
+    ranked = n;
+    b0 = b1;
+    __syncthreads();
+  }
+  if (dbg && tid == 0) {
+    unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
+    const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
+                        ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
+    o[0] = tm0; o[1] = ((unsigned long long)hw << 32); o[2] = __builtin_readcyclecounter();
+    o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
+  }
+  blend_finish<kExtra>(p, v, t, n, blds, acc, pxi, pyi, inside, bg0, bg1, bg2);
+  report_length();
+#undef GSR_STAMP
+#undef GSR_STAMP2
+  (void)sInfo;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3672,7 +4050,10 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   } while (0)
     // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
     if (!fused_bin) GSR_TILES(false, 4096);
-    else if (p.stride <= 2048u) GSR_TILES(true, 2048);
+    else if (p.stride <= 2048u && p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {  // the usual case: cursor gather + prefix rank
+      if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else hipLaunchKernelGGL((k_tile_fwd_prefix<false>), tgrid, dim3(kFwdThreads), 0, st, p);
+    } else if (p.stride <= 2048u) GSR_TILES(true, 2048);
     else GSR_TILES(true, 4096);
 #undef GSR_TILES
   }

@@ -43,13 +43,14 @@ def decode_workspaces(backend, cfg: RasterConfig, saved):
     st = b[:16]
     num_pairs = int(st[:8].view(torch.int64).item())
     ranges = b[lay["ranges"]: lay["ranges"] + V * T * 8].view(torch.int32).reshape(V, T, 2).numpy()
+    walked = b[lay["tile_total"]: lay["tile_total"] + V * T * 4].view(torch.int32).reshape(V, T).numpy()  # list entries each tile's blend went through
     cap = int(dims.pair_capacity)
     plist = b[lay["point_list"]: lay["point_list"] + cap * 4].view(torch.int32).numpy()  # a tile's list: ranges[v, t]
     keys = b[lay["keys"]: lay["keys"] + cap * 8].view(torch.int64).numpy()
     im = img.cpu()
     final_T = im[lay["final_T"]: lay["final_T"] + V * H * W * 4].view(torch.float32).reshape(V, H, W).numpy()
     n_contrib = im[lay["n_contrib"]: lay["n_contrib"] + V * H * W * 4].view(torch.int32).reshape(V, H, W).numpy()
-    return dict(geom=g, depth=depth, rgb=rgbc[:, :, :3], radius=bits & 0x0FFFFFFF, clamped=cbits & 7, ranges=ranges, point_list=plist, keys=keys,
+    return dict(geom=g, depth=depth, rgb=rgbc[:, :, :3], radius=bits & 0x0FFFFFFF, clamped=cbits & 7, ranges=ranges, walked=walked, point_list=plist, keys=keys,
                 final_T=final_T, n_contrib=n_contrib, num_pairs=num_pairs, overflow=int(st[8:12].view(torch.int32).item()),
                 max_list=int(st[12:16].view(torch.int32).item()), sgx=sgx, sgy=sgy, T=T)
 

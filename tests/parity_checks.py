@@ -88,9 +88,16 @@ def _contributing(geo, ids, px0, py0, W, H):
     return ok.reshape(len(ids), -1).any(1)
 
 
+FLAG_FULL_LISTS = 0x20000  # GSR_FLAG_FULL_LISTS (include/gsr.h)
+PREFIX = 512  # list positions the tile launch of the usual case orders before it blends (kPrefix, gsr_hip.hip)
+
+
 def check_tile_lists(res, cfg, v=0, max_tiles=None, rng=None):
     """Each 8x8 tile's list is sorted by (depth, id), is a subset of the reference's 16x16-tile list for the parent
-    tile, and contains every splat of that list that can contribute in the tile (so dropping the rest changes nothing)."""
+    tile, and contains every splat of that list that can contribute in the tile (so dropping the rest changes nothing).
+    Without GSR_FLAG_FULL_LISTS only the nearest part of a list is ordered - max(512, entries the tile walked) positions are
+    guaranteed (include/gsr.h) - and that part is what is checked: sorted, a subset, and complete up to its last key (no
+    contributing splat of the parent list that is nearer than the prefix's last entry may be absent from it)."""
     ws = res["hip"]["ws"]
     o, _ = res["oracle"]["handles"][v]
     geo = o.geometry()
@@ -98,20 +105,23 @@ def check_tile_lists(res, cfg, v=0, max_tiles=None, rng=None):
     W, H = cfg.width, cfg.height
     gx16 = (W + 15) // 16
     sgx, T = ws["sgx"], ws["T"]
+    full = bool(cfg.flags & FLAG_FULL_LISTS)
     depth_bits = geo["depth"].astype(np.float32).view(np.uint32).astype(np.int64)
     tiles = np.arange(T)
     if max_tiles is not None and T > max_tiles:
         tiles = (rng or np.random.default_rng(0)).choice(T, max_tiles, replace=False)
     m = dict(unsorted=0, not_subset=0, missing=0, pairs=0, pairs16=int(len(binn["point_list"])), checked_tiles=len(tiles),
-             extra_kept=0)
+             extra_kept=0, prefix_only_tiles=0)
     for t in tiles:
         tx, ty = int(t % sgx), int(t // sgx)
         a, b = ws["ranges"][v, t]
-        ids = ws["point_list"][a:b].astype(np.int64)
-        m["pairs"] += len(ids)
+        n = int(b - a)
+        m["pairs"] += n
         if tx * 8 >= W or ty * 8 >= H:
-            assert len(ids) == 0, ("tile outside image has entries", t)
+            assert n == 0, ("tile outside image has entries", t)
             continue
+        keep = n if full else min(n, max(int(ws["walked"][v, t]), PREFIX))
+        ids = ws["point_list"][a:a + keep].astype(np.int64)
         key = depth_bits[ids] * (1 << 32) + ids
         m["unsorted"] += int((np.diff(key) <= 0).sum())
         p = (ty // 2) * gx16 + (tx // 2)
@@ -119,6 +129,9 @@ def check_tile_lists(res, cfg, v=0, max_tiles=None, rng=None):
         parent = binn["point_list"][pa:pb].astype(np.int64)
         m["not_subset"] += int((~np.isin(ids, parent)).sum())
         need = parent[_contributing(geo, parent, tx * 8, ty * 8, W, H)]
+        if keep < n:  # ordered prefix only: complete up to its last key
+            m["prefix_only_tiles"] += 1
+            need = need[depth_bits[need] * (1 << 32) + need <= key[-1]]
         m["missing"] += int((~np.isin(need, ids)).sum())
         m["extra_kept"] += len(ids) - len(need)
     assert m["unsorted"] == 0 and m["not_subset"] == 0 and m["missing"] == 0, m

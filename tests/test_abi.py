@@ -74,9 +74,9 @@ def test_flag_bits_are_validated_and_ablation_switches_are_not_in_the_product_li
     z = ctypes.c_size_t()
     sizes = lambda d: lib.gsr_workspace_sizes(ctypes.byref(d), ctypes.byref(z), ctypes.byref(z), ctypes.byref(z))
     ok = (_lib.FLAG_PREFILTERED | _lib.FLAG_DEBUG | _lib.FLAG_SH_PLANAR | _lib.FLAG_COV_3X3 | _lib.FLAG_DETERMINISTIC |
-          _lib.FLAG_BACKWARD_FOLLOWS | (4 << 4))
+          _lib.FLAG_BACKWARD_FOLLOWS | _lib.FLAG_FULL_LISTS | (4 << 4))
     assert sizes(be._dims(rasterizer.RasterConfig(1, 1, 1, 100, 16, 16, 4, 25, 4, True, ok), 1000)) == 0
-    for bad in (0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x8000, 0x20000, 1 << 30, 5 << 4, 7 << 4):
+    for bad in (0x100, 0x200, 0x400, 0x800, 0x1000, 0x2000, 0x8000, 0x40000, 1 << 30, 5 << 4, 7 << 4):
         assert sizes(be._dims(rasterizer.RasterConfig(1, 1, 1, 100, 16, 16, 4, 25, 4, True, bad), 1000)) == -1, hex(bad)
     hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
     product, _, _ = hdr.partition("#ifdef GSR_ABLATE")

@@ -91,6 +91,43 @@ def test_20k_gaussians_128x128():
     _all_checks(cfg, res)
 
 
+def test_prefix_rank_full_lists_flag_orders_every_list_to_its_end():
+    """GSR_FLAG_FULL_LISTS: the tile launch ranks whole lists (the default orders the nearest 512 entries of a list and the
+    rest only if the blend gets that far); same image, and the complete list checks hold on every tile."""
+    cfg_p, res_p = _scene_case(2, 300000, (256, 256), with_extra=False, grads=False)
+    cfg_f, res_f = _scene_case(2, 300000, (256, 256), with_extra=False, grads=False, flags=parity_checks.FLAG_FULL_LISTS)
+    m_p = parity_checks.check_tile_lists(res_p, cfg_p, max_tiles=128)
+    m_f = parity_checks.check_tile_lists(res_f, cfg_f, max_tiles=128)
+    assert m_p["prefix_only_tiles"] > 100 and m_f["prefix_only_tiles"] == 0, (m_p, m_f)
+    assert np.array_equal(res_p["hip"]["color"], res_f["hip"]["color"])
+    ws_p, ws_f = res_p["hip"]["ws"], res_f["hip"]["ws"]
+    assert np.array_equal(ws_p["walked"], ws_f["walked"]) and np.array_equal(ws_p["n_contrib"], ws_f["n_contrib"])
+    # the ordered prefix of the default mode is the head of the fully ordered list
+    for t in (0, 357, 1023):
+        a, b = ws_f["ranges"][0, t]
+        k = min(int(b - a), parity_checks.PREFIX)
+        assert np.array_equal(ws_p["point_list"][a:a + k], ws_f["point_list"][a:a + k])
+
+
+def test_prefix_rank_returns_for_the_rest_of_a_list_when_pixels_stay_open():
+    """Faint splats (opacity x 0.05 + 0.01): no pixel saturates, a tile's blend uses up the ranked prefix of its 600-1000-entry
+    list, goes back to rank the rest and walks on to the end - forward and backward against the oracle."""
+    n, hw = 300000, (256, 256)
+    sc = synthetic.make_scene(77, n, hw)
+    means, cov6, opac, colors = gpu_util.scene_tensors(sc)
+    opac = opac * 0.05 + 0.01
+    vb = gpu_util.scene_viewbuf(sc)
+    rng = np.random.default_rng(77)
+    cfg = RasterConfig(1, 1, 1, n, hw[0], hw[1], 4, 25, 4, False, 0)
+    gc = torch.tensor(rng.uniform(0, 1, (1, 3, *hw)).astype(np.float32))
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, None)
+    ws = res["hip"]["ws"]
+    ln = ws["ranges"][0, :, 1] - ws["ranges"][0, :, 0]
+    long = ln > parity_checks.PREFIX + parity_checks.PREFIX // 4
+    assert long.sum() > 500 and (ws["walked"][0][long] == ln[long]).all(), (np.median(ln), np.median(ws["walked"][0]))
+    _all_checks(cfg, res, strict=True)
+
+
 def test_config2_config3_full_size_300k_256x256():
     """BASELINE configs[1]/[2] at full size: forward image, saved state, and all gradients vs the oracle
     (the oracle finishes this in a few seconds on the host cores)."""

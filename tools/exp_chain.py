@@ -23,9 +23,12 @@ def main():
     vb = synthetic.scene_viewbuf(sc).to(dev)
     cfg = RasterConfig(1, 1, 1, n, 256, 256, 4, 25, 4, False)
     be = HipBackend()
-    plan = be.make_plan(cfg, dev, capacity=8 * n, backward=True)
-    be.run_forward(plan, vb, means, cov6, opac, shs)
-    plan = be.make_plan(cfg, dev, capacity=be.capacity_for(cfg, be.read_status(plan), headroom=1.1), backward=True)
+    if os.environ.get("EXP_CAP"):  # a known-good pair capacity (variants whose sizing call would not report the real status)
+        plan = be.make_plan(cfg, dev, capacity=int(os.environ["EXP_CAP"]), backward=True)
+    else:
+        plan = be.make_plan(cfg, dev, capacity=8 * n, backward=True)
+        be.run_forward(plan, vb, means, cov6, opac, shs)
+        plan = be.make_plan(cfg, dev, capacity=be.capacity_for(cfg, be.read_status(plan), headroom=1.1), backward=True)
     for _ in range(30):
         be.run_forward(plan, vb, means, cov6, opac, shs)
     torch.cuda.synchronize()

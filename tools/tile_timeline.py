@@ -12,7 +12,7 @@ LIB = os.path.join(ROOT, "tools", "libgsr_hip_ablate.so")
 os.environ["GSR_LIB_PATH"] = LIB
 from pf3plat_amd import _lib  # noqa: E402
 
-_lib.build(force=True, extra_flags=["-DGSR_ABLATE", *sys.argv[1:]], out=LIB)
+_lib.build(force=not os.environ.get("GSR_KEEP_LIB"), extra_flags=["-DGSR_ABLATE", *sys.argv[1:]], out=LIB)  # GSR_KEEP_LIB=1: use the file as built (cross-compiled before the GPU call)
 from pf3plat_amd import synthetic  # noqa: E402
 from pf3plat_amd.rasterizer import HipBackend, RasterConfig  # noqa: E402
 
@@ -94,6 +94,12 @@ def main():
     for gsel in (None, 0, 3):
         m = torch.ones(T, dtype=torch.bool) if gsel is None else grp == gsel
         print(f"sort phases, median us (de-phase group {gsel}): " + ", ".join(f"{nm} {torch.median((pts[k + 1] - pts[k])[m]).item():.2f}" for k, nm in enumerate(names)))
+    if os.environ.get("TILE_DUMP"):  # raw per-tile arrays for offline analysis
+        import numpy as np
+        os.makedirs(os.path.dirname(os.environ["TILE_DUMP"]) or ".", exist_ok=True)
+        np.savez(os.environ["TILE_DUMP"], sort_start=(ss - t0).numpy(), sort_end=(se - t0).numpy(), blend_start=(bs - t0).numpy(),
+                 blend_end=(be_ - t0).numpy(), cu=cu.numpy(), bid=bid_of_tile.numpy(), n=ln.numpy(), walked=walked.numpy(),
+                 phases=torch.stack([p_ for p_ in pts]).numpy())
     ms = be.run_forward(plan, vb, means, cov6, opac, shs, profile=True)
     print("profile-mode stage ms:", {k: round(v, 4) for k, v in ms.items()})
 
