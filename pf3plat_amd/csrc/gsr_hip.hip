@@ -2569,15 +2569,6 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
   } else {
     if (tid == 0) p.ranges[tg] = make_uint2(obase, obase + n);
     fast_path = true;
-    if (bid == 0) {  // total pair count = sum of the binning workgroups' totals
-      unsigned long long part = 0;
-      for (int k = tid; k < p.d.num_views * R; k += kSortThreads) part += p.blk_total[k];
-      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-      __shared__ unsigned long long sPartSum[kSortThreads / 64];
-      if (lane == 0) sPartSum[wave] = part;
-      __syncthreads();
-      if (tid == 0) p.status->num_pairs = sPartSum[0] + sPartSum[1] + sPartSum[2] + sPartSum[3];
-    }
     uint32_t* out = p.point_list + obase;
     if (n == 1) {
       if (tid == 0) out[0] = (uint32_t)sk[0];
@@ -2685,6 +2676,15 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
   // first tiles to arrive, a device-scope atomic on an address every tile of the launch goes for
   auto report_length = [&]() {
     if (fast_path && tid == 64 && n > p.status->max_list) atomicMax(&p.status->max_list, n);
+    if (fast_path && bid == 0) {  // total pair count = sum of the binning workgroups' totals (a general-path tile has done it in sort_tile)
+      unsigned long long part = 0;
+      for (int k = tid; k < p.d.num_views * R; k += kSortThreads) part += p.blk_total[k];
+      for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+      __shared__ unsigned long long sPartSum[kSortThreads / 64];
+      if (lane == 0) sPartSum[wave] = part;
+      __syncthreads();
+      if (tid == 0) p.status->num_pairs = sPartSum[0] + sPartSum[1] + sPartSum[2] + sPartSum[3];
+    }
   };
   // (usual path: the flag as thread 0 read it at the kernel's start, handed round through LDS - the same value in every wave)
   if ((GSR_PF_EARLY_STATUS && fast_path) ? (sInfo[3] != 0u && blend_poisoned<kExtra>(p, v, pxi, pyi, inside, true))

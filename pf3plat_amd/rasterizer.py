@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes
 import struct
+import threading
 from dataclasses import dataclass
 from typing import NamedTuple, Optional
 
@@ -89,7 +90,44 @@ def pack_views(viewmatrix: Tensor, projmatrix: Tensor, campos: Tensor, tanfovx: 
 # HIP backend: tensors in, tensors out, through the C ABI
 # --------------------------------------------------------------------------------------------------
 def _ptr(t: Optional[Tensor]):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    return None if t is None else t.data_ptr()  # (a plain int: the argtypes are c_void_p, ctypes converts it without an object per argument)
+
+
+def _f32c(t: Optional[Tensor]) -> Optional[Tensor]:
+    """fp32 + contiguous, touching nothing when the tensor already is (the usual case: two no-op dispatches less per argument)."""
+    if t is None or (t.dtype is torch.float32 and t.is_contiguous()):
+        return t
+    return t.to(torch.float32).contiguous()
+
+
+class _on_device:
+    """`with torch.cuda.device(dev)` only when `dev` is not already the current device (the context manager costs ~10 us of
+    get / set device calls per use; a training step makes half a dozen library calls)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.ctx = None if idx == torch.cuda.current_device() else torch.cuda.device(idx)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+        return False
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream_ptr(dev) -> int:
+    """The current HIP stream of `dev` as a raw handle (torch's C entry point when it is there: the Python-level
+    `torch.cuda.current_stream(dev).cuda_stream` builds a Stream object, ~4 us per call, three calls per training step)."""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 class HipBackend:
@@ -100,10 +138,17 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self.capacity_hint = {}  # (V, N, H, W) -> largest pair_capacity any call of that shape has needed (headroom included)
+        self.seen = {}  # (V, N, H, W) -> forwards of that shape whose status block has been read
         self.sync_policy = "sync"  # or "lazy" (opt-in, inference / benchmarks): see forward()
+        # "sync" policy, calls that will be differentiated: once `defer_after` status blocks of a shape have been read, such a
+        # call is sized from the running maximum and its status is verified at the end of its own backward instead of in the
+        # forward (0: never - every forward blocks until its status has been read)
+        self.defer_after = 4
         self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
         self.pending = []  # (pinned status copy, event, shape key, cfg, workspace id) of lazy forwards not yet verified
-        self._status_host = None
+        self._pinned = []  # 16-byte pinned status buffers not in use
+        self._sizes = {}  # (cfg, capacity) -> (GsrDims, geom bytes, bin bytes, img bytes, backward scratch bytes)
+        self._lock = threading.Lock()  # pending / pools / caches: the process-wide backend may be called from several threads
         self.workspace_cache = {}  # (cfg, capacity, device, stream) -> (geom, bin, img) of forwards that nothing differentiates
         self.last_status = None
 
@@ -134,8 +179,8 @@ class HipBackend:
         self._check_device(scales, rotations)
         n = scales.shape[0]
         out = torch.empty((n, 6), dtype=torch.float32, device=scales.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
-        with torch.cuda.device(scales.device):
+        stream = _stream_ptr(scales.device)
+        with _on_device(scales.device):
             rc = self.lib.gsr_cov_from_scale_rot(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(out), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_cov_from_scale_rot failed with code {rc}")
@@ -144,8 +189,8 @@ class HipBackend:
     def cov_from_scale_rot_backward(self, scales: Tensor, rotations: Tensor, scale_modifier: float, d_cov6: Tensor):
         n = scales.shape[0]
         d_s, d_r = torch.empty_like(scales), torch.empty_like(rotations)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(scales.device).cuda_stream)
-        with torch.cuda.device(scales.device):
+        stream = _stream_ptr(scales.device)
+        with _on_device(scales.device):
             rc = self.lib.gsr_cov_from_scale_rot_backward(n, _ptr(scales), _ptr(rotations), float(scale_modifier), _ptr(d_cov6),
                                                           _ptr(d_s), _ptr(d_r), stream)
         if rc != 0:
@@ -179,8 +224,8 @@ class HipBackend:
         else:
             ty = float(rs.tanfovy)
         out = torch.empty((1, VIEW_FLOATS), dtype=f32, device=device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-        with torch.cuda.device(device):
+        stream = _stream_ptr(device)
+        with _on_device(device):
             rc = self.lib.gsr_pack_view(_ptr(vm), _ptr(pm), _ptr(cp), int(cp.stride(0)), _ptr(bg), tx, ty, _ptr(txd), _ptr(tyd),
                                         float(rs.scale_modifier), _ptr(out), stream)
         if rc != 0:
@@ -225,6 +270,26 @@ class HipBackend:
             return int(hint)
         return cfg.num_views * max(8 * cfg.num_gaussians, 1 << 18)
 
+    def _sized(self, cfg: RasterConfig, capacity: int):
+        """(GsrDims, geom, bin, img, backward-scratch bytes) of a call shape: host-only library arithmetic, asked once per shape."""
+        key = (cfg, int(capacity))
+        hit = self._sizes.get(key)
+        if hit is None:
+            dims = self._dims(cfg, capacity)
+            hit = (dims, *self.workspace_sizes(dims), int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims))))
+            with self._lock:
+                if len(self._sizes) >= 64:
+                    self._sizes.clear()
+                self._sizes[key] = hit
+        return hit
+
+    def release_workspaces(self):
+        """Drop the cached workspaces of the no-autograd path (up to 8 sets of geom / bin / img stay alive otherwise) and the
+        size cache."""
+        with self._lock:
+            self.workspace_cache.clear()
+            self._sizes.clear()
+
     # ---- plans: outputs + workspaces allocated once, launch chains enqueued many times (bench / HIP-graph capture)
     def make_plan(self, cfg: RasterConfig, device, capacity: int, backward: bool = False, colors_shape=None,
                   reuse_workspaces: bool = False) -> dict:
@@ -233,20 +298,25 @@ class HipBackend:
         allocations and a workspace-size query per view less)."""
         v, h, w, n, s = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians, cfg.num_sets
         f32, u8 = torch.float32, torch.uint8
-        dims = self._dims(cfg, capacity)
+        dims, gb, bb, ib, scratch_bytes = self._sized(cfg, capacity)
         ws = None
         if reuse_workspaces:
-            key = (cfg, int(capacity), str(device), torch.cuda.current_stream(device).cuda_stream)
+            key = (cfg, int(capacity), str(device), _stream_ptr(device))
             ws = self.workspace_cache.get(key)
-        if ws is None:
-            gb, bb, ib = self.workspace_sizes(dims)
-            ws = (torch.empty(gb, dtype=u8, device=device), torch.empty(bb, dtype=u8, device=device), torch.empty(ib, dtype=u8, device=device))
+        if ws is None:  # one allocation, three slices on 2 MiB boundaries (as separate large allocations would sit; the library
+            # lays geom's own sub-arrays out on such boundaries too)
+            al = (2 << 20) - 1
+            o_g = (bb + al) & ~al
+            o_i = o_g + ((gb + al) & ~al)
+            whole = torch.empty(o_i + ib, dtype=u8, device=device)
+            ws = (whole[o_g:o_g + gb], whole[:bb], whole[o_i:o_i + ib])
             if reuse_workspaces:
-                if len(self.workspace_cache) >= 8:
-                    self.workspace_cache.clear()
-                self.workspace_cache[key] = ws
+                with self._lock:
+                    if len(self.workspace_cache) >= 8:
+                        self.workspace_cache.clear()
+                    self.workspace_cache[key] = ws
         plan = dict(
-            cfg=cfg, dims=dims, device=device,
+            cfg=cfg, dims=_lib.GsrDims.from_buffer_copy(dims), device=device,  # (a copy: tools flip flag bits in a plan's dims)
             color=torch.empty((v, 3, h, w), dtype=f32, device=device),
             extra_img=torch.empty((v, h, w), dtype=f32, device=device) if cfg.has_extra else None,
             radii=torch.empty((v, n), dtype=torch.int32, device=device),
@@ -260,8 +330,7 @@ class HipBackend:
                     colors_shape = (s, n, 3)
             plan.update(
                 # (a forward announced with FLAG_BACKWARD_FOLLOWS keeps the accumulator rows inside geom: no scratch, no zero-fill)
-                scratch=None if cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS else torch.empty(
-                    max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=u8, device=device),
+                scratch=None if cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS else torch.empty(max(16, scratch_bytes), dtype=u8, device=device),
                 d_means=torch.empty((s, n, 3), dtype=f32, device=device),
                 d_cov6=torch.empty((s, n, 7) if cfg.scale_rot else (s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6),
                                    dtype=f32, device=device),
@@ -286,14 +355,14 @@ class HipBackend:
         """Enqueue one forward launch chain on the current stream.  profile=True returns per-stage ms (synchronises).
         out_color: render into this contiguous (V, 3, H, W) fp32 tensor instead of the plan's own image (e.g. a slot of a
         buffer that is all-gathered later: no copy)."""
-        stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
+        stream = _stream_ptr(plan["device"])
         color = plan["color"] if out_color is None else out_color
         if color.shape != plan["color"].shape or color.dtype != torch.float32 or not color.is_contiguous():
             raise ValueError("out_color must be a contiguous fp32 tensor of the plan's image shape")
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
                 _ptr(color), _ptr(plan["extra_img"]), _ptr(plan["radii"]), _ptr(plan["geom"]), _ptr(plan["bin"]),
                 _ptr(plan["img"]), stream)
-        with torch.cuda.device(plan["device"]):  # kernels launch on the process's current device: make it the tensors' device
+        with _on_device(plan["device"]):  # kernels launch on the process's current device: make it the tensors' device
             if plan["cfg"].scale_rot:
                 fr, nf = self._frames_args(plan["cfg"], frames)
                 ms = None
@@ -311,13 +380,13 @@ class HipBackend:
                      want_means2d: bool = True, profile: bool = False, frames=None, d_views=None):
         """d_views: a (V, 48) fp32 tensor that receives the camera gradients (gsr_backward_ex)."""
         cfg = plan["cfg"]
-        stream = ctypes.c_void_p(torch.cuda.current_stream(plan["device"]).cuda_stream)
+        stream = _stream_ptr(plan["device"])
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
                 _ptr(plan["geom"]), _ptr(plan["bin"]), _ptr(plan["img"]), _ptr(g_color),
                 _ptr(g_extra_img if cfg.has_extra else None), _ptr(plan["scratch"]), _ptr(plan["d_means"]),
                 _ptr(plan["d_cov6"]), _ptr(plan["d_opac"]), _ptr(plan["d_colors"]), _ptr(plan["d_extra"]),
                 _ptr(plan["d_means2d"] if want_means2d else None), stream)
-        with torch.cuda.device(plan["device"]):
+        with _on_device(plan["device"]):
             if d_views is not None:
                 fr, nf = self._frames_args(cfg, frames) if cfg.scale_rot else (None, 0)
                 partials = plan.get("pose_partials")
@@ -340,49 +409,92 @@ class HipBackend:
         self._rc(rc, "gsr_backward", _lib.BWD_STAGES)
         return None if ms is None else dict(zip(_lib.BWD_STAGES, [float(x) for x in ms]))
 
-    def read_status(self, plan: dict) -> dict:
-        """Blocking read of the status block of the plan's last forward (16 bytes into a pinned buffer kept for the purpose)."""
-        host = self._status_host
-        if host is None:
-            host = self._status_host = torch.empty(16, dtype=torch.uint8, pin_memory=True)
-        host.copy_(plan["bin"][:16])  # blocking device-to-host copy: the one sync of the default policy
-        num_pairs, overflow, max_list = struct.unpack("<qii", host.numpy().tobytes())
-        return {"num_pairs": int(num_pairs), "overflow": int(overflow), "max_list": int(max_list)}
+    # The status block travels to the host through a pinned 16-byte buffer that the host fills with a sentinel first: the copy
+    # has landed when the sentinel is gone (num_pairs and max_list are never negative).  No event object, no blocking call - a
+    # blocking copy / synchronize sleeps and wakes up 30-60 us late, an Event costs ~6 us to create and record.
+    _SENTINEL = -1
 
-    # ---- autograd-facing calls: fresh outputs/workspaces per call, kept alive for backward
+    def _pinned_status(self):
+        with self._lock:
+            host = self._pinned.pop() if self._pinned else None
+        if host is None:
+            buf = torch.empty(16, dtype=torch.uint8, pin_memory=True)
+            host = (buf, buf.numpy().view("<i8"), buf.numpy().view("<i4"))  # (tensor, num_pairs view, (.., .., overflow, max_list) view)
+        host[1][0] = self._SENTINEL
+        host[2][3] = self._SENTINEL
+        return host
+
+    def _status_copy(self, binb: Tensor):
+        """Enqueue the 16-byte status block's copy into a pinned buffer behind the forward (torch's current stream)."""
+        host = self._pinned_status()
+        host[0].copy_(binb[:16], non_blocking=True)
+        return host
+
+    @staticmethod
+    def _arrived(host) -> bool:
+        return host[1][0] != HipBackend._SENTINEL and host[2][3] != HipBackend._SENTINEL
+
+    def _take_status(self, host) -> dict:
+        st = {"num_pairs": int(host[1][0]), "overflow": int(host[2][2]), "max_list": int(host[2][3])}
+        with self._lock:
+            self._pinned.append(host)
+        return st
+
+    def read_status(self, plan: dict) -> dict:
+        """The status block of the plan's last forward, waited for (polling): the one host sync of the default policy."""
+        host = self._status_copy(plan["bin"])
+        while not self._arrived(host):
+            pass
+        return self._take_status(host)
+
+    # ---- autograd-facing calls: fresh outputs per call; fresh workspaces too (kept alive for the backward) unless the caller says
+    # that nothing will be differentiated
     def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None,
-                frames=None):
-        """Pair-count policy (`self.sync_policy`):
-        "sync"  - (default) read the 16-byte status block back after every call (one host sync, as the reference extension
+                frames=None, reuse_workspaces: bool = False):
+        """-> (color, extra_img, radii, saved).  `saved` = (dims, geom, bin, img) for `backward`, or None with reuse_workspaces.
+
+        reuse_workspaces: the caller will not differentiate this call (rasterize_views' no-autograd branch): geom / bin / img
+        come from a per-(shape, device, stream) cache that the next call of the same shape overwrites, and nothing is handed
+        back for a backward (`release_workspaces()` drops the cache).
+
+        Pair-count policy (`self.sync_policy`):
+        "sync"  - (default) read the 16-byte status block back after the call (one host sync, as the reference extension
                   does with its num_rendered) and retry with the exact size on overflow: a jump in the pair count from one
-                  scene to the next costs one retry, never a wrong image;
-        "lazy"  - opt-in (inference loops, benchmarks): do that only the first time a (views, N, H, W) shape is seen;
+                  scene to the next costs one retry, never a wrong image.  Exception (`defer_after`, default 4): a call that
+                  will be differentiated (GSR_FLAG_BACKWARD_FOLLOWS), of a shape whose status has been read that many times,
+                  is sized from the running maximum (x 1.25) and does NOT block: its status is verified at the end of its own
+                  backward - the host then runs ahead of the device through the whole training step instead of idling the
+                  device between forward and backward.  Should the workspace turn out too small, that call's image is NaN
+                  (so is the loss) and its backward raises; the capacity hint has grown by then;
+        "lazy"  - opt-in (inference loops, benchmarks): block only the first time a (views, N, H, W) shape is seen;
                   afterwards size the workspace at 1.25x the largest pair count seen, copy the status block asynchronously
                   and verify it at the next call, at `check_pending()`, and - for a call that is differentiated - at the
-                  start of its backward.  A workspace that turns out too small poisons that call's image with NaN
+                  end of its backward.  A workspace that turns out too small poisons that call's image with NaN
                   (k_tile_fwd) and raises at verification - it cannot pass silently."""
         self._check_device(viewbuf, means, cov6, opac, colors, extra)
-        self.check_pending()
+        if self.pending:
+            self.check_pending()
         dev = viewbuf.device
         v, h, w, n = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians
         key = (v, n, h, w)
-        lazy = (self.sync_policy == "lazy" and capacity is None and key in self.capacity_hint) or self.defer_status
+        known = capacity is None and key in self.capacity_hint
+        lazy = (self.sync_policy == "lazy" and known) or self.defer_status
+        if (not lazy and known and not reuse_workspaces and (cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) and self.defer_after > 0
+                and self.seen.get(key, 0) >= self.defer_after):
+            lazy = True
         cap = self._default_capacity(cfg) if capacity is None else int(capacity)
         for attempt in range(3):
-            plan = self.make_plan(cfg, dev, cap, reuse_workspaces=not (cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) and not lazy)
+            plan = self.make_plan(cfg, dev, cap, reuse_workspaces=reuse_workspaces and not lazy)
             self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
-            saved = (plan["dims"], plan["geom"], plan["bin"], plan["img"])
+            saved = None if reuse_workspaces else (plan["dims"], plan["geom"], plan["bin"], plan["img"])
             out = (plan["color"], plan["extra_img"], plan["radii"], saved)
             if n == 0 or v == 0:
                 return out
             if lazy:
-                host = torch.empty(16, dtype=torch.uint8, pin_memory=True)
-                host.copy_(plan["bin"][:16], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(dev))
-                self.pending.append((host, ev, key, cfg, plan["bin"].data_ptr()))
+                self.pending.append((self._status_copy(plan["bin"]), key, cfg, plan["bin"].data_ptr(), plan["bin"]))
                 return out
             self.last_status = st = self.read_status(plan)
+            self.seen[key] = self.seen.get(key, 0) + 1
             self._raise_hint(key, self.capacity_for(cfg, st))
             if not st["overflow"]:
                 return out
@@ -397,31 +509,33 @@ class HipBackend:
         `only_ws`: just the forward that owns that workspace, waiting for it)."""
         keep, failed = [], None
         for item in self.pending:
-            host, ev, key, cfg, ws = item
+            host, key, cfg, ws, _keepalive = item
             mine = only_ws is not None and ws == only_ws
             if only_ws is not None and not mine:
                 keep.append(item)
                 continue
             if wait or mine:
-                ev.synchronize()
-            elif not ev.query():
+                while not self._arrived(host):  # (polling: a blocking synchronize sleeps and wakes up 30-60 us late)
+                    pass
+            elif not self._arrived(host):
                 keep.append(item)
                 continue
-            num_pairs = int(host[:8].view(torch.int64).item())
-            overflow = int(host[8:12].view(torch.int32).item())
-            self.last_status = {"num_pairs": num_pairs, "overflow": overflow, "max_list": int(host[12:16].view(torch.int32).item())}
-            self._raise_hint(key, self.capacity_for(cfg, self.last_status))
-            if overflow and failed is None:
-                failed = num_pairs
+            self.last_status = st = self._take_status(host)
+            self.seen[key] = self.seen.get(key, 0) + 1
+            self._raise_hint(key, self.capacity_for(cfg, st))
+            if st["overflow"] and failed is None:
+                failed = st["num_pairs"]
         self.pending = keep
         if failed is not None:
             raise RuntimeError(
                 f"an earlier gsr_forward needed {failed} pairs but its workspace was smaller; that call's image was "
-                "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync').")
+                "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync' with "
+                "defer_after = 0).")
 
     def _verify_own_forward(self, binb):
-        """Backward of a lazily sized forward: its status must be known to be good before gradients are computed from
-        its workspace (an overflowed forward binned nothing)."""
+        """Backward of a lazily sized forward: its status must be known to be good before its gradients are handed out (an
+        overflowed forward binned nothing; the backward kernels over it are harmless - no pixel has a contributor - but
+        their result means nothing)."""
         if self.pending:
             self.check_pending(only_ws=binb.data_ptr())
 
@@ -430,14 +544,15 @@ class HipBackend:
         """rows_in_workspace: the forward ran with FLAG_BACKWARD_FOLLOWS and this is the first backward over it - accumulate
         into the rows it zero-filled inside geom (no scratch, no zero-fill pass).  want_views: a seventh result, the (V, 48)
         gradient of the camera records (view matrix, projection matrix, camera centre)."""
+        if saved is None:
+            raise RuntimeError("this forward ran with reuse_workspaces=True (nothing was to be differentiated): it has no backward")
         dims, geom, binb, img = saved
         dev = viewbuf.device
         v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         f32 = torch.float32
-        self._verify_own_forward(binb)
+        own_rows = rows_in_workspace and bool(cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS)
         plan = dict(cfg=cfg, dims=dims, device=dev, geom=geom, bin=binb, img=img,
-                    scratch=None if (rows_in_workspace and cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) else torch.empty(
-                        max(16, int(self.lib.gsr_backward_scratch_bytes(ctypes.byref(dims)))), dtype=torch.uint8, device=dev),
+                    scratch=None if own_rows else torch.empty(max(16, self._sized(cfg, int(dims.pair_capacity))[4]), dtype=torch.uint8, device=dev),
                     d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
                     d_cov6=torch.empty((s, n, 7) if cfg.scale_rot else (s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6),
                                        dtype=f32, device=dev),
@@ -445,15 +560,17 @@ class HipBackend:
                     d_extra=torch.empty((v, n), dtype=f32, device=dev) if (cfg.has_extra and not (cfg.flags >> 4) & 7) else None,
                     d_means2d=torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None)
         if n > 0 and v > 0:
-            g_color = g_color.contiguous().to(f32)
+            g_color = _f32c(g_color)
             if cfg.has_extra:
                 g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
-                               else g_extra_img.contiguous().to(f32))
+                               else _f32c(g_extra_img))
             d_views = torch.empty((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
             self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d, frames=frames,
                               d_views=d_views)
         else:
             d_views = torch.zeros((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
+        # (after the launches: the device works on the backward while the host waits for the forward's status, if it has to)
+        self._verify_own_forward(binb)
         out = plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
         return out + (d_views,) if want_views else out
 
@@ -462,11 +579,10 @@ class HipBackend:
         self._check_device(extrinsics, intrinsics, near, far, background)
         v = extrinsics.shape[0]
         f32 = torch.float32
-        ext, intr = extrinsics.to(f32).contiguous(), intrinsics.to(f32).contiguous()
-        nr, fr, bg = near.to(f32).contiguous(), far.to(f32).contiguous(), background.to(f32).contiguous()
+        ext, intr, nr, fr, bg = _f32c(extrinsics), _f32c(intrinsics), _f32c(near), _f32c(far), _f32c(background)
         out = torch.empty((v, VIEW_FLOATS), dtype=f32, device=ext.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(ext.device).cuda_stream)
-        with torch.cuda.device(ext.device):
+        stream = _stream_ptr(ext.device)
+        with _on_device(ext.device):
             rc = self.lib.gsr_setup_views(v, _ptr(ext), _ptr(intr), _ptr(nr), _ptr(fr), _ptr(bg), 3 if bg.dim() == 2 else 0,
                                           int(bool(scale_invariant)), _ptr(out), stream)
         if rc != 0:
@@ -483,8 +599,8 @@ class HipBackend:
         ext, wd, ht, nr, fr, bg = c(extrinsics), c(width).reshape(v), c(height).reshape(v), c(near).reshape(v), c(far).reshape(v), c(background)
         out = torch.empty((v, VIEW_FLOATS), dtype=f32, device=ext.device)
         dump = torch.empty((v, 20), dtype=f32, device=ext.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(ext.device).cuda_stream)
-        with torch.cuda.device(ext.device):
+        stream = _stream_ptr(ext.device)
+        with _on_device(ext.device):
             rc = self.lib.gsr_setup_views_orthographic(v, _ptr(ext), _ptr(wd), _ptr(ht), _ptr(nr), _ptr(fr), _ptr(bg),
                                                        3 if bg.dim() == 2 else 0, float(fov_degrees), _ptr(out), _ptr(dump), stream)
         if rc != 0:
@@ -501,8 +617,8 @@ class HipBackend:
         self._check_device(viewbuf, means)
         present = torch.empty((cfg.num_sets, cfg.num_gaussians), dtype=torch.uint8, device=means.device)
         dims = self._dims(cfg, 0)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(means.device).cuda_stream)
-        with torch.cuda.device(means.device):
+        stream = _stream_ptr(means.device)
+        with _on_device(means.device):
             rc = self.lib.gsr_mark_visible(ctypes.byref(dims), _ptr(viewbuf), _ptr(means), _ptr(present), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_mark_visible failed with code {rc}")
@@ -596,20 +712,14 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     if v != s * views_per_set:
         raise ValueError(f"{v} views != {s} sets x {views_per_set} views per set")
     h, w = image_shape
-    f32 = torch.float32
-    means = means.to(f32).contiguous()
-    cov6 = cov6.to(f32).contiguous()
-    opacities = opacities.to(f32).contiguous()
-    colors = colors.to(f32).contiguous()
-    if extra is not None:
-        extra = extra.to(f32).contiguous()
+    means, cov6, opacities, colors, extra = _f32c(means), _f32c(cov6), _f32c(opacities), _f32c(colors), _f32c(extra)
     if use_sh and colors.dim() != 4:
         raise ValueError("shs must be (sets, N, M, 3) or (sets, N, 3, M)")
     if scale_rot:
         if cov_3x3 or cov6.shape[2:] != (7,):
             raise ValueError(f"scale/rotation records have shape {tuple(cov6.shape)}; expected (sets, N, 7)")
         if frames is not None:
-            frames = frames.detach().to(f32).contiguous()
+            frames = _f32c(frames.detach())
     elif frames is not None:
         raise ValueError("`frames` goes with scale_rot=True")
     elif cov6.shape[2:] != ((3, 3) if cov_3x3 else (6,)):
@@ -629,11 +739,12 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     has_extra = extra is not None or extra_mode is not None
     cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags,
                        bool(scale_rot))
+    viewbuf = _f32c(viewbuf)
     if not (flags & _lib.FLAG_BACKWARD_FOLLOWS):  # nothing here can be differentiated: no autograd node, no saved workspaces
-        color, extra_img, radii, _ = get_backend().forward(cfg, viewbuf.contiguous(), means, cov6, opacities, colors, extra, frames=frames)
+        color, extra_img, radii, _ = get_backend().forward(cfg, viewbuf, means, cov6, opacities, colors, extra, frames=frames,
+                                                           reuse_workspaces=True)
         return color, (extra_img if has_extra else None), radii
-    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf.contiguous(), cfg,
-                                                    frames)
+    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf, cfg, frames)
     return color, (extra_img if has_extra else None), radii
 
 

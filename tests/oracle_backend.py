@@ -56,7 +56,7 @@ class OracleBackend:
             colors = colors.permute(0, 1, 3, 2)
         return cov6, colors
 
-    def forward(self, cfg, viewbuf, means, cov6, opac, colors, extra, capacity=None, frames=None):
+    def forward(self, cfg, viewbuf, means, cov6, opac, colors, extra, capacity=None, frames=None, reuse_workspaces=False):
         sr_graph = None
         if getattr(cfg, "scale_rot", False):  # covariance from (S, N, 7) scale + quaternion records, kept differentiable
             with torch.enable_grad():
