@@ -41,7 +41,7 @@ extern "C" {
 #define GSR_ERR_INVALID_ARGUMENT (-1)
 #define GSR_ERR_LAUNCH (-2)
 #define GSR_ERR_UNSUPPORTED (-3)
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 /* GsrDims.flags input-layout bits: the arrays PF3plat's `Gaussians` record carries (src/model/types.py:7-18) can be passed
  * as they are, with no re-layout copy (the reference wrapper makes two per call: cuda_splatting.py:75 and :115,123). */
 #define GSR_FLAG_SH_PLANAR 0x4  /* colors are (num_sets, N, 3, M) "harmonics" instead of (num_sets, N, M, 3); grads likewise */
@@ -207,6 +207,13 @@ typedef struct GsrBackwardOptions {
   int32_t scale_rot;
   float* dL_dviews;
   float* pose_partials;
+  int32_t depth_term_only; /* != 0: dL_dviews receives ONLY what the built-in depth channel (GSR_FLAG_EXTRA_MODE) sends to the
+                              camera - floats 2, 6, 10, 14 of the view matrix, the row that forms z; zeros elsewhere.  This is the
+                              one camera gradient the reference's own training graph carries: its depth render forms z with
+                              extrinsics.inverse() in torch (cuda_splatting.py:239-242, extrinsics requiring grad at
+                              model_wrapper.py:148-156) while nothing reaches a camera through the rasterizer.  Costs four wave
+                              reductions in the backward preprocess instead of thirty-five and two small reduce launches. */
+  int32_t reserved_;
 } GsrBackwardOptions;
 size_t gsr_pose_partials_bytes(const GsrDims* dims);
 int gsr_backward_ex(const GsrDims* dims, const GsrView* views, const float* means, const float* cov, const float* opacities,
@@ -239,6 +246,13 @@ int gsr_pack_view(const float* viewmatrix, const float* projmatrix, const float*
  * cuda_splatting.py:17-44, extrinsics.inverse(), view @ proj).  scale_invariant != 0 applies the 1/near rescale. */
 int gsr_setup_views(int num_views, const float* extrinsics, const float* intrinsics, const float* near, const float* far,
                     const float* background, int background_stride, int scale_invariant, GsrView* views, void* stream);
+
+/* Backward of gsr_setup_views (scale_invariant as the records say): dL_dviews (V, 48) - the camera-record gradient gsr_backward_ex
+ * returns, laid out like GsrView - carried to dL_dextrinsics (V, 4, 4) in closed form (view = (E'^-1)^T, full = view P^T,
+ * campos = E'[:3, 3]; fp64 inside), one launch.  Intrinsics, near, far receive nothing.  This is the path by which the one camera
+ * gradient of the reference's training graph - the depth render's extrinsics.inverse(), cuda_splatting.py:239-242 - reaches
+ * `extrinsics` without a torch op. */
+int gsr_setup_views_backward(int num_views, const GsrView* views, const float* dL_dviews, float* dL_dextrinsics, void* stream);
 
 /* The same for the reference's fake orthographic camera (render_cuda_orthographic, cuda_splatting.py:153-181): per view the
  * extent (width, height) of the orthographic window in world units; the camera is moved back along its own -z by

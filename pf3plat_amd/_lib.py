@@ -16,7 +16,7 @@ REPO_ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "gsr_hip.hip")
 HEADER = os.path.join(REPO_ROOT, "include", "gsr.h")
 LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")  # (override: tools/ablate.py's measurement build)
-GSR_ABI_VERSION = 2  # bump with include/gsr.h whenever a struct, a workspace layout or a signature changes
+GSR_ABI_VERSION = 3  # bump with include/gsr.h whenever a struct, a workspace layout or a signature changes
 SCREEN_GRAD_FLOATS = 12
 FLAG_PREFILTERED = 0x1  # accepted and ignored, as upstream with prefiltered = False
 FLAG_DEBUG = 0x2  # upstream's `debug`: synchronise + check after every stage
@@ -42,7 +42,8 @@ class GsrDims(ctypes.Structure):
 
 class GsrBackwardOptions(ctypes.Structure):
     _fields_ = [("frames", ctypes.c_void_p), ("num_frames", ctypes.c_int32), ("scale_rot", ctypes.c_int32),
-                ("dL_dviews", ctypes.c_void_p), ("pose_partials", ctypes.c_void_p)]
+                ("dL_dviews", ctypes.c_void_p), ("pose_partials", ctypes.c_void_p), ("depth_term_only", ctypes.c_int32),
+                ("reserved_", ctypes.c_int32)]
 
 
 def find_hipcc() -> str:
@@ -138,6 +139,8 @@ def load():
     lib.gsr_mark_visible.argtypes = [dp, vp, vp, vp, vp]
     lib.gsr_setup_views.restype = ctypes.c_int
     lib.gsr_setup_views.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp]
+    lib.gsr_setup_views_backward.restype = ctypes.c_int
+    lib.gsr_setup_views_backward.argtypes = [ctypes.c_int, vp, vp, vp, vp]
     lib.gsr_setup_views_orthographic.restype = ctypes.c_int
     lib.gsr_setup_views_orthographic.argtypes = [ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_float, vp, vp, vp]
     fp = ctypes.POINTER(ctypes.c_float)
@@ -156,7 +159,7 @@ EXPORTED_SYMBOLS = (
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
     "gsr_colour_in_binning", "gsr_geom_layout", "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
-    "gsr_image_loss", "gsr_image_loss_partials", "gsr_pack_view",
+    "gsr_image_loss", "gsr_image_loss_partials", "gsr_pack_view", "gsr_setup_views_backward",
 )
 # gsr_forward_profile's stages.  On images of up to 20 480 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).

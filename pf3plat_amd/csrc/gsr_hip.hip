@@ -3171,7 +3171,11 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
 constexpr int kPoseFloats = 35;  // dL/d viewmatrix (16), projmatrix (16), campos (3) of a view
 // kJ: the forward saved d rgb / d direction of every (view, Gaussian) (Params::shj, GSR_FLAG_BACKWARD_FOLLOWS): the harmonics
 // themselves are then not read here at all - 300 B per Gaussian less of the kernel's ~750.
-template <bool kPose, bool kJ>
+// kPose: 0 no camera gradient; 1 all of it (35 floats per view); 2 only what the built-in depth channel contributes - the four
+// entries 2, 6, 10, 14 of the view matrix that form z: the ONE camera gradient the reference's own graph carries (its depth render
+// reads extrinsics.inverse() in torch, cuda_splatting.py:239-242; nothing reaches a camera through the rasterizer)
+constexpr int kPoseZFloats = 4;
+template <int kPose, bool kJ>
 __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x, set = blockIdx.y;
@@ -3290,10 +3294,10 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     // [16..32) and campos [32..35) - every place the forward reads them: t = V p and M = J Wr in the EWA covariance, the
     // projection p_hom = F p, the view direction of the harmonics, the depth of the built-in extra channel.  Summed over
     // the wave below, one partial row per (view, workgroup); k_pose_reduce adds the rows up.
-    float pose[kPose ? kPoseFloats : 1];
+    float pose[kPose == 1 ? kPoseFloats : kPoseZFloats];
     if (kPose) {
 #pragma unroll
-      for (int k = 0; k < kPoseFloats; ++k) pose[k] = 0.f;
+      for (int k = 0; k < (kPose == 1 ? kPoseFloats : kPoseZFloats); ++k) pose[k] = 0.f;
     }
     if (vis) {
     seen = true;
@@ -3346,7 +3350,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     float dm[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) dm[j] = vw[4 * j + 0] * dtx + vw[4 * j + 1] * dty + vw[4 * j + 2] * dtz;
-    if (kPose) {
+    if (kPose == 1) {
       const float mj[4] = {mx, my, mz, 1.f}, dt[3] = {dtx, dty, dtz};
 #pragma unroll
       for (int j = 0; j < 4; ++j)
@@ -3369,7 +3373,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
     dm[0] += (pr[0] * m_w - pr[3] * mul1) * sg[0] + (pr[1] * m_w - pr[3] * mul2) * sg[1];
     dm[1] += (pr[4] * m_w - pr[7] * mul1) * sg[0] + (pr[5] * m_w - pr[7] * mul2) * sg[1];
     dm[2] += (pr[8] * m_w - pr[11] * mul1) * sg[0] + (pr[9] * m_w - pr[11] * mul2) * sg[1];
-    if (kPose) {  // p_hom_k = sum_j F[4j + k] m_j;  ndc = p_hom.xy / (p_hom.w + eps)
+    if (kPose == 1) {  // p_hom_k = sum_j F[4j + k] m_j;  ndc = p_hom.xy / (p_hom.w + eps)
       const float mj[4] = {mx, my, mz, 1.f};
       const float gk[4] = {sg[0] * m_w, sg[1] * m_w, 0.f, -(sg[0] * mul1 + sg[1] * mul2)};
 #pragma unroll
@@ -3421,7 +3425,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       const float gdir1 = (-ox * oy * ddx + (sum2 - oy * oy) * ddy - oz * oy * ddz) * invsum32;
       const float gdir2 = (-ox * oz * ddx - oy * oz * ddy + (sum2 - oz * oz) * ddz) * invsum32;
       dm[0] += gdir0; dm[1] += gdir1; dm[2] += gdir2;
-      if (kPose) { pose[32] -= gdir0; pose[33] -= gdir1; pose[34] -= gdir2; }  // direction = mean - campos
+      if (kPose == 1) { pose[32] -= gdir0; pose[33] -= gdir1; pose[34] -= gdir2; }  // direction = mean - campos
     } else {
       dcol[0] += sg[6]; dcol[1] += sg[7]; dcol[2] += sg[8];
     }
@@ -3434,15 +3438,17 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
       (void)extra_from_depth(emode, z, cam.reserved[0], cam.reserved[1], dfdz);
       const float gz = sg[9] * dfdz;
       dmean[0] += gz * vw[2]; dmean[1] += gz * vw[6]; dmean[2] += gz * vw[10];
-      if (kPose) { const float gs = gz / cam.scale; pose[2] += gs * mx; pose[6] += gs * my; pose[10] += gs * mz; pose[14] += gs; }
+      if (kPose == 1) { const float gs = gz / cam.scale; pose[2] += gs * mx; pose[6] += gs * my; pose[10] += gs * mz; pose[14] += gs; }
+      if (kPose == 2) { const float gs = gz / cam.scale; pose[0] += gs * mx; pose[1] += gs * my; pose[2] += gs * mz; pose[3] += gs; }
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
     }  // vis
     if (kPose) {  // sums over the four 16-lane DPP rows (4 DPP adds per value; a full wave sum costs 6 LDS permutes): 4 partial rows
-      float* row = p.pose_partials + (((size_t)v * gridDim.x + blockIdx.x) * 4 + (lane >> 4)) * kPoseFloats;
+      constexpr int kF = kPose == 1 ? kPoseFloats : kPoseZFloats;
+      float* row = p.pose_partials + (((size_t)v * gridDim.x + blockIdx.x) * 4 + (lane >> 4)) * kF;
 #pragma unroll
-      for (int k = 0; k < kPoseFloats; ++k) {
+      for (int k = 0; k < kF; ++k) {
         const float s = row_allreduce(pose[k]);
         if ((lane & 15) == 0) row[k] = s;
       }
@@ -3546,6 +3552,32 @@ __global__ __launch_bounds__(256) void k_pose_reduce(const float* in, int rows, 
     if (tid < kPoseFloats)
       for (int j = 0; j < 7; ++j) sum += part[j][tid];
     dst[tid] = sum;
+  }
+}
+
+// The same for the four-float rows of the depth-only camera gradient (kPose == 2): 256 threads = 64 rows x 4 columns per step.
+// `final`: write the (V, 48) record - the sums at floats 2, 6, 10, 14 (the z row of the transposed view matrix), zeros elsewhere.
+__global__ __launch_bounds__(256) void k_pose_reduce_z(const float* in, int rows, float* out, int final) {
+  __shared__ float part[64][kPoseZFloats];
+  const int v = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int per = (rows + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int r_begin = b * per, r_end = min(rows, r_begin + per);
+  const int k = tid & 3, r0 = tid >> 2;
+  const float* base = in + (size_t)v * rows * kPoseZFloats;
+  float acc = 0.f;
+  for (int r = r_begin + r0; r < r_end; r += 64) acc += base[(size_t)r * kPoseZFloats + k];
+  part[r0][k] = acc;
+  __syncthreads();
+  if (tid < kPoseZFloats) {
+    float sum = 0.f;
+    for (int j = 0; j < 64; ++j) sum += part[j][tid];  // fixed order: deterministic
+    part[0][tid] = sum;
+  }
+  __syncthreads();
+  if (final) {
+    if (tid < 48) out[(size_t)v * 48 + tid] = ((tid & 3) == 2 && tid < 16) ? part[0][tid >> 2] : 0.f;
+  } else if (tid < kPoseZFloats) {
+    out[((size_t)v * gridDim.y + b) * kPoseZFloats + tid] = part[0][tid];
   }
 }
 
@@ -3673,6 +3705,67 @@ __global__ void k_setup_views_ortho(int V, const float* ext, const float* width,
     for (int i = 0; i < 16; ++i) dp[i] = E[i];
     dp[16] = fov_x; dp[17] = fov_y; dp[18] = nr; dp[19] = fr;
   }
+}
+
+// Backward of k_setup_views: the gradient of the (V, 48) camera records (as gsr_backward_ex returns it: d viewmatrix [0, 16),
+// d projmatrix [16, 32), d campos [32, 35)) carried to the (V, 4, 4) camera-to-world extrinsics, one thread per view, in fp64:
+//   view = (E'^-1)^T,  full = view P^T,  campos = E'[:3, 3]   with E' = E, translation times s (the scale-invariant factor)
+//   => dL/dview += dL/dfull P;  dL/dE' = -(E'^-1)^T (dL/d(E'^-1)) (E'^-1)^T;  translation column += dL/dcampos, then times s.
+// Intrinsics, near and far get nothing (the operator treats the fields of view as constants).  What the Python layer used to do
+// with a dozen fp64 torch launches per backward (190 us of device time for three cameras) is one ~3 us launch.
+__global__ void k_setup_views_bwd(int V, const GsrView* views, const float* d_views, float* d_ext) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  const GsrView& c = views[v];
+  const float* g = d_views + (size_t)v * 48;
+  const double s = c.scale, nr = (double)c.reserved[0] * s, fr = (double)c.reserved[1] * s;
+  double P[16] = {0};  // the projection matrix of finish_view (row-major)
+  P[0] = 1.0 / c.tanfovx; P[5] = 1.0 / c.tanfovy; P[14] = 1.0;
+  P[10] = fr / (fr - nr); P[11] = -(fr * nr) / (fr - nr);
+  // A = E'^-1 (world -> camera); the record holds A^T:  A[i][j] = viewmatrix[4 j + i]
+  double A[16], dV[16], dA[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) A[4 * i + j] = c.viewmatrix[4 * j + i];
+  // dL/dview = dL/dviewmatrix + dL/dprojmatrix P   (full = view P^T, both stored transposed)
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = g[4 * i + j];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += (double)g[16 + 4 * i + k] * P[4 * k + j];
+      dV[4 * i + j] = a;
+    }
+  // view = A^T  =>  dL/dA = (dL/dview)^T
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dA[4 * i + j] = dV[4 * j + i];
+  // A = E'^-1  =>  dL/dE' = -A^T dA A^T
+  double T[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += A[4 * k + i] * dA[4 * k + j];  // (A^T dA)[i][j]
+      T[4 * i + j] = a;
+    }
+  float* o = d_ext + (size_t)v * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a += T[4 * i + k] * A[4 * j + k];  // (T A^T)[i][j]
+      a = -a;
+      if (j == 3 && i < 3) a = (a + (double)g[32 + i]) * s;
+      o[4 * i + j] = (float)a;
+    }
 }
 
 // One record of the per-view API (gsr_pack_view): thread k writes float k.
@@ -3851,7 +3944,7 @@ extern "C" {
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }
 
 const char* gsr_build_info(void) {
-  return "gsr_hip gfx950 wave64 tile8x8 binning+colour tile-sort+segment-blend single-stream abi2";
+  return "gsr_hip gfx950 wave64 tile8x8 binning+colour tile-sort+segment-blend single-stream abi3";
 }
 
 int gsr_last_failed_stage(void) { return g_failed_stage; }
@@ -4101,7 +4194,7 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
                          const void* bin, const void* img, const float* dL_dcolor, const float* dL_dextra_img,
                          void* scratch, float* dL_dmeans, float* dL_dcov6, float* dL_dopacities,
                          float* dL_dcolors, float* dL_dextra, float* dL_dmeans2D, void* stream_, const SrArgs* sr,
-                         float* dL_dviews = nullptr, float* pose_partials = nullptr) {
+                         float* dL_dviews = nullptr, float* pose_partials = nullptr, int depth_term_only = 0) {
   if (!dims_ok(dims) || !sr_ok(dims, sr)) return GSR_ERR_INVALID_ARGUMENT;
   hipStream_t st = static_cast<hipStream_t>(stream_);
   const GsrDims& d = *dims;
@@ -4145,18 +4238,38 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
   const int rowf = 3 * d.sh_coeffs, ldstride = rowf | 1;
   const size_t shmem = d.sh_coeffs > 0 ? (size_t)64 * ldstride * sizeof(float) : 0;
   const dim3 pgrid((unsigned)((N + 63) / 64), (unsigned)d.num_sets);
-  if (dL_dviews) {
+  if (dL_dviews && depth_term_only) {
     if (!pose_partials) return GSR_ERR_INVALID_ARGUMENT;
     p.pose_partials = pose_partials;
-    if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<true, true>), pgrid, dim3(64), shmem, st, p);
-    else hipLaunchKernelGGL((k_preprocess_bwd<true, false>), pgrid, dim3(64), shmem, st, p);
+    const int emode = (d.flags >> 4) & 7;
+    if (!d.has_extra || emode == 0) {  // no built-in depth channel: nothing of this call reads the camera's z row
+      GSR_CHECK(hipMemsetAsync(dL_dviews, 0, V * sizeof(GsrView), st));
+      if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<0, true>), pgrid, dim3(64), shmem, st, p);
+      else hipLaunchKernelGGL((k_preprocess_bwd<0, false>), pgrid, dim3(64), shmem, st, p);
+    } else {
+      if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<2, true>), pgrid, dim3(64), shmem, st, p);
+      else hipLaunchKernelGGL((k_preprocess_bwd<2, false>), pgrid, dim3(64), shmem, st, p);
+      const int rows1 = (int)pgrid.x * 4, blocks1 = rows1 < 64 ? 1 : 64;
+      float* level1 = pose_partials + (size_t)V * rows1 * kPoseZFloats;  // behind the rows of the first level
+      if (blocks1 > 1) {
+        hipLaunchKernelGGL(k_pose_reduce_z, dim3((unsigned)V, (unsigned)blocks1), dim3(256), 0, st, pose_partials, rows1, level1, 0);
+        hipLaunchKernelGGL(k_pose_reduce_z, dim3((unsigned)V, 1), dim3(256), 0, st, level1, blocks1, dL_dviews, 1);
+      } else {
+        hipLaunchKernelGGL(k_pose_reduce_z, dim3((unsigned)V, 1), dim3(256), 0, st, pose_partials, rows1, dL_dviews, 1);
+      }
+    }
+  } else if (dL_dviews) {
+    if (!pose_partials) return GSR_ERR_INVALID_ARGUMENT;
+    p.pose_partials = pose_partials;
+    if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<1, true>), pgrid, dim3(64), shmem, st, p);
+    else hipLaunchKernelGGL((k_preprocess_bwd<1, false>), pgrid, dim3(64), shmem, st, p);
     const int rows1 = (int)pgrid.x * 4;
     float* level1 = pose_partials + (size_t)V * rows1 * kPoseFloats;  // behind the rows of the first level
     hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V, kPoseBlocks), dim3(256), 0, st, pose_partials, rows1, level1, kPoseFloats, kPoseBlocks);
     hipLaunchKernelGGL(k_pose_reduce, dim3((unsigned)V, 1), dim3(256), 0, st, level1, kPoseBlocks, dL_dviews, 48, 1);
   } else {
-    if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<false, true>), pgrid, dim3(64), shmem, st, p);
-    else hipLaunchKernelGGL((k_preprocess_bwd<false, false>), pgrid, dim3(64), shmem, st, p);
+    if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<0, true>), pgrid, dim3(64), shmem, st, p);
+    else hipLaunchKernelGGL((k_preprocess_bwd<0, false>), pgrid, dim3(64), shmem, st, p);
   }
   GSR_STAGE_DONE(1);
 #undef GSR_STAGE_DONE
@@ -4208,7 +4321,7 @@ int gsr_backward_ex(const GsrDims* dims, const GsrView* views, const float* mean
   const SrArgs sr{opt->frames, opt->num_frames};
   return backward_impl(dims, views, means, cov, opacities, colors, extra, geom, bin, img, dL_dcolor, dL_dextra_img, scratch,
                        dL_dmeans, dL_dcov, dL_dopacities, dL_dcolors, dL_dextra, dL_dmeans2D, stream_, opt->scale_rot ? &sr : nullptr,
-                       opt->dL_dviews, opt->pose_partials);
+                       opt->dL_dviews, opt->pose_partials, opt->depth_term_only);
 }
 
 // Measurement aid (bench.py): gsr_backward with events between its two stages (blend backward, preprocess backward);
@@ -4243,6 +4356,16 @@ int gsr_setup_views(int num_views, const float* extrinsics, const float* intrins
   if (!extrinsics || !intrinsics || !near_ || !far_ || !background || !views) return GSR_ERR_INVALID_ARGUMENT;
   hipLaunchKernelGGL(k_setup_views, dim3((unsigned)((num_views + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream_),
                      num_views, extrinsics, intrinsics, near_, far_, background, background_stride, scale_invariant, views);
+  GSR_CHECK(hipGetLastError());
+  return GSR_OK;
+}
+
+int gsr_setup_views_backward(int num_views, const GsrView* views, const float* dL_dviews, float* dL_dextrinsics, void* stream_) {
+  if (num_views < 0) return GSR_ERR_INVALID_ARGUMENT;
+  if (num_views == 0) return GSR_OK;
+  if (!views || !dL_dviews || !dL_dextrinsics) return GSR_ERR_INVALID_ARGUMENT;
+  hipLaunchKernelGGL(k_setup_views_bwd, dim3((unsigned)((num_views + 63) / 64)), dim3(64), 0, static_cast<hipStream_t>(stream_),
+                     num_views, views, dL_dviews, dL_dextrinsics);
   GSR_CHECK(hipGetLastError());
   return GSR_OK;
 }

@@ -377,8 +377,9 @@ class HipBackend:
         return None if ms is None else dict(zip(_lib.FWD_STAGES, [float(x) for x in ms]))
 
     def run_backward(self, plan: dict, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img=None,
-                     want_means2d: bool = True, profile: bool = False, frames=None, d_views=None):
-        """d_views: a (V, 48) fp32 tensor that receives the camera gradients (gsr_backward_ex)."""
+                     want_means2d: bool = True, profile: bool = False, frames=None, d_views=None, depth_term_only: bool = False):
+        """d_views: a (V, 48) fp32 tensor that receives the camera gradients (gsr_backward_ex); depth_term_only: only
+        what the built-in depth channel sends to the camera (the z row of the view matrix), the gradient of the reference's graph."""
         cfg = plan["cfg"]
         stream = _stream_ptr(plan["device"])
         args = (ctypes.byref(plan["dims"]), _ptr(viewbuf), _ptr(means), _ptr(cov6), _ptr(opac), _ptr(colors), _ptr(extra),
@@ -393,7 +394,7 @@ class HipBackend:
                 if partials is None:
                     partials = plan["pose_partials"] = torch.empty(
                         max(16, int(self.lib.gsr_pose_partials_bytes(args[0]))), dtype=torch.uint8, device=plan["device"])
-                opt = _lib.GsrBackwardOptions(_ptr(fr), nf, int(cfg.scale_rot), _ptr(d_views), _ptr(partials))
+                opt = _lib.GsrBackwardOptions(_ptr(fr), nf, int(cfg.scale_rot), _ptr(d_views), _ptr(partials), int(bool(depth_term_only)), 0)
                 ms = None
                 rc = self.lib.gsr_backward_ex(*args[:-1], ctypes.byref(opt), stream)
             elif cfg.scale_rot:
@@ -540,10 +541,11 @@ class HipBackend:
             self.check_pending(only_ws=binb.data_ptr())
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
-                 want_means2d: bool, rows_in_workspace: bool = False, frames=None, want_views: bool = False):
+                 want_means2d: bool, rows_in_workspace: bool = False, frames=None, want_views=False):
         """rows_in_workspace: the forward ran with FLAG_BACKWARD_FOLLOWS and this is the first backward over it - accumulate
         into the rows it zero-filled inside geom (no scratch, no zero-fill pass).  want_views: a seventh result, the (V, 48)
-        gradient of the camera records (view matrix, projection matrix, camera centre)."""
+        gradient of the camera records - True: all of it (view matrix, projection matrix, camera centre); "depth": only what
+        the built-in depth channel contributes (the z row of the view matrix: the reference graph's camera gradient)."""
         if saved is None:
             raise RuntimeError("this forward ran with reuse_workspaces=True (nothing was to be differentiated): it has no backward")
         dims, geom, binb, img = saved
@@ -566,7 +568,7 @@ class HipBackend:
                                else _f32c(g_extra_img))
             d_views = torch.empty((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
             self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d, frames=frames,
-                              d_views=d_views)
+                              d_views=d_views, depth_term_only=(want_views == "depth"))
         else:
             d_views = torch.zeros((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
         # (after the launches: the device works on the backward while the host waits for the forward's status, if it has to)
@@ -587,6 +589,18 @@ class HipBackend:
                                           int(bool(scale_invariant)), _ptr(out), stream)
         if rc != 0:
             raise RuntimeError(f"gsr_setup_views failed with code {rc}")
+        return out
+
+    def setup_views_backward(self, viewbuf: Tensor, d_views: Tensor) -> Tensor:
+        """(V, 48) camera records + their gradient -> dL/d extrinsics (V, 4, 4), one launch (gsr_setup_views_backward)."""
+        self._check_device(viewbuf, d_views)
+        v = viewbuf.shape[0]
+        vb, dv = _f32c(viewbuf), _f32c(d_views)
+        out = torch.empty((v, 4, 4), dtype=torch.float32, device=vb.device)
+        with _on_device(vb.device):
+            rc = self.lib.gsr_setup_views_backward(v, _ptr(vb), _ptr(dv), _ptr(out), _stream_ptr(vb.device))
+        if rc != 0:
+            raise RuntimeError(f"gsr_setup_views_backward failed with code {rc}")
         return out
 
     def setup_views_orthographic(self, extrinsics, width, height, near, far, background, fov_degrees: float):
@@ -645,8 +659,9 @@ def get_backend():
 # --------------------------------------------------------------------------------------------------
 class _RasterizeViews(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, means, cov6, opac, colors, extra, means2d, viewbuf, cfg: RasterConfig, frames=None):
+    def forward(ctx, means, cov6, opac, colors, extra, means2d, viewbuf, cfg: RasterConfig, frames=None, camera_gradient="full"):
         backend = get_backend()
+        ctx.camera_gradient = camera_gradient
         color, extra_img, radii, saved = backend.forward(cfg, viewbuf, means, cov6, opac, colors, extra, frames=frames)
         ctx.frames = frames
         ctx.cfg = cfg
@@ -674,7 +689,7 @@ class _RasterizeViews(torch.autograd.Function):
         if ctx.needs_input_grad[6]:  # cameras being learned (PF3plat's pose refinement): opt-in, SURVEY 8f-3
             d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, d_views = ctx.backend.backward(
                 cfg, ctx.saved_ws, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, ctx.want_means2d,
-                rows_in_workspace=ctx.rows_fresh, frames=ctx.frames, want_views=True)
+                rows_in_workspace=ctx.rows_fresh, frames=ctx.frames, want_views=("depth" if ctx.camera_gradient == "depth" else True))
         else:
             d_views = None
             d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d = ctx.backend.backward(
@@ -683,14 +698,15 @@ class _RasterizeViews(torch.autograd.Function):
         ctx.rows_fresh = False
         # the workspaces stay with ctx (freed with the graph): a second backward (retain_graph=True, several autograd.grad
         # calls over one render) runs on them again, as upstream's Function can
-        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, d_views, None, None
+        return d_means, d_cov6, d_opac, d_colors, d_extra, d_means2d, d_views, None, None, None
 
 
 def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tensor, viewbuf: Tensor, *,
                     image_shape, sh_degree: int, use_sh: bool, views_per_set: int, extra: Optional[Tensor] = None,
                     means2d: Optional[Tensor] = None, max_sh_eval: int = 4, sh_planar: bool = False, cov_3x3: bool = False,
                     extra_mode: Optional[str] = None, debug: bool = False, prefiltered: bool = False,
-                    deterministic: Optional[bool] = None, scale_rot: bool = False, frames: Optional[Tensor] = None):
+                    deterministic: Optional[bool] = None, scale_rot: bool = False, frames: Optional[Tensor] = None,
+                    camera_gradient: str = "full"):
     """Render V = num_sets * views_per_set views in one launch chain.
 
     means (S,N,3); cov6 (S,N,6) or, with cov_3x3, the full symmetric (S,N,3,3); opacities (S,N); colors (S,N,M,3) or, with
@@ -703,6 +719,9 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     scale_rot: `cov6` is (S,N,7) = scale (x,y,z) + quaternion (x,y,z,w), the form PF3plat's encoder emits (reference
     gaussian_adapter.py:63-83); the covariance R diag(s^2) R^T - rotated into world space by `frames` (S,F,3,3), one rotation per
     group of N/F consecutive Gaussians, no gradient - is built inside the kernels and the gradient comes back as (S,N,7).
+    camera_gradient (only matters when `viewbuf` requires grad, i.e. comes from `views_from_cameras(pose_gradients=True)`): "full" -
+    every place the forward reads a camera (an extension); "depth" - only the built-in depth channel's term, which
+    is what the reference's own graph sends to `extrinsics` (cuda_splatting.py:239-242).
     debug: upstream's `settings.debug` - the library synchronises and checks for errors after every stage and names the
     stage that failed.  deterministic: the backward accumulates per-Gaussian gradients in 64-bit fixed point (bit-identical
     from run to run); None = follow `torch.are_deterministic_algorithms_enabled()`.
@@ -744,7 +763,9 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
         color, extra_img, radii, _ = get_backend().forward(cfg, viewbuf, means, cov6, opacities, colors, extra, frames=frames,
                                                            reuse_workspaces=True)
         return color, (extra_img if has_extra else None), radii
-    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf, cfg, frames)
+    if camera_gradient not in ("full", "depth"):
+        raise ValueError("camera_gradient must be 'full' or 'depth'")
+    color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf, cfg, frames, camera_gradient)
     return color, (extra_img if has_extra else None), radii
 
 
@@ -765,18 +786,7 @@ class _SetupViews(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_views):
         (vb,) = ctx.saved_tensors
-        v = vb.shape[0]
-        vb, d_views = vb.double(), d_views.double()
-        w2c = vb[:, 0:16].reshape(v, 4, 4).transpose(1, 2)  # records hold the transposed world-to-camera matrix
-        scale, near, far = vb[:, 40], vb[:, 43] * vb[:, 40], vb[:, 44] * vb[:, 40]
-        proj = torch.zeros((v, 4, 4), dtype=torch.float64, device=vb.device)
-        proj[:, 0, 0], proj[:, 1, 1] = 1.0 / vb[:, 35], 1.0 / vb[:, 36]
-        proj[:, 2, 2], proj[:, 2, 3], proj[:, 3, 2] = far / (far - near), -(far * near) / (far - near), 1.0
-        d_view = d_views[:, 0:16].reshape(v, 4, 4) + d_views[:, 16:32].reshape(v, 4, 4) @ proj  # full = view @ proj^T
-        d_w2c = d_view.transpose(1, 2)
-        d_ext = -(w2c.transpose(1, 2) @ d_w2c @ w2c.transpose(1, 2))  # A = B^-1  =>  dL/dB = -A^T (dL/dA) A^T
-        d_ext[:, :3, 3] += d_views[:, 32:35]
-        d_ext[:, :3, 3] *= scale[:, None]
+        d_ext = get_backend().setup_views_backward(vb, d_views)  # one launch (gsr_setup_views_backward), fp64 inside
         return d_ext.to(ctx.ext_dtype), None, None, None, None, None
 
 

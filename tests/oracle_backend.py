@@ -137,7 +137,8 @@ class OracleBackend:
             d_means[s] += torch.from_numpy(g["means3D"]) * float(f["scale"])
             d_cov6[s] += torch.from_numpy(g["cov3D_precomp"]) * float(f["scale2"])
             d_opac[s] += torch.from_numpy(g["opacities"])
-            d_views[v, :35] = torch.from_numpy(g["camera"])
+            if want_views != "depth":  # ("depth": only the built-in depth channel's term, below)
+                d_views[v, :35] = torch.from_numpy(g["camera"])
             d_colors[s] += torch.from_numpy(g["colors"])
             if cfg.has_extra and emode:
                 vm = f["viewmatrix"]
@@ -177,6 +178,23 @@ class OracleBackend:
         rec = cameras.view_records(self._np(extrinsics), self._np(intrinsics), self._np(near), self._np(far), self._np(background),
                                    bool(scale_invariant))
         return torch.from_numpy(rec)
+
+    def setup_views_backward(self, viewbuf, d_views):
+        """dL/d(V, 48) camera records -> dL/d extrinsics (V, 4, 4): view = inv(c2w')^T, full = view P^T, campos = c2w'[:3, 3]
+        (c2w' = c2w with its translation times the scale-invariant factor) in closed form, fp64 torch ops."""
+        v = viewbuf.shape[0]
+        vb, d_views = viewbuf.double(), d_views.double()
+        w2c = vb[:, 0:16].reshape(v, 4, 4).transpose(1, 2)  # records hold the transposed world-to-camera matrix
+        scale, near, far = vb[:, 40], vb[:, 43] * vb[:, 40], vb[:, 44] * vb[:, 40]
+        proj = torch.zeros((v, 4, 4), dtype=torch.float64)
+        proj[:, 0, 0], proj[:, 1, 1] = 1.0 / vb[:, 35], 1.0 / vb[:, 36]
+        proj[:, 2, 2], proj[:, 2, 3], proj[:, 3, 2] = far / (far - near), -(far * near) / (far - near), 1.0
+        d_view = d_views[:, 0:16].reshape(v, 4, 4) + d_views[:, 16:32].reshape(v, 4, 4) @ proj  # full = view @ proj^T
+        d_w2c = d_view.transpose(1, 2)
+        d_ext = -(w2c.transpose(1, 2) @ d_w2c @ w2c.transpose(1, 2))  # A = B^-1  =>  dL/dB = -A^T (dL/dA) A^T
+        d_ext[:, :3, 3] += d_views[:, 32:35]
+        d_ext[:, :3, 3] *= scale[:, None]
+        return d_ext.to(torch.float32)
 
     def setup_views_orthographic(self, extrinsics, width, height, near, far, background, fov_degrees):
         rec, moved = cameras.view_records_orthographic(self._np(extrinsics), self._np(width), self._np(height), self._np(near),

@@ -157,6 +157,47 @@ def test_decoder_forward_config4_full_size_colour_and_depth_fwd_bwd():
     _cmp_grads(gl, ol)
 
 
+@pytest.mark.parametrize("mode", ["depth", "relative_disparity"])
+def test_reference_graph_training_call_config4_fused_depth_term_reaches_extrinsics(mode):
+    """PF3plat's training call as the reference makes it: `extrinsics` requires grad (src/model/model_wrapper.py:148-156) and depth
+    is rendered every step (config/main.yaml:50).  The reference's graph then sends ONE gradient to the camera - through the depth
+    render's `extrinsics.inverse()` (cuda_splatting.py:239-251).  Fused path on the device (f(z) inside the kernels, the depth
+    term of the camera gradient out of the backward preprocess, carried to `extrinsics` by the set-up's closed-form backward)
+    against torch autograd over the literal graph - `depth_fake_color` blended as an explicit channel - on the oracle:
+    BASELINE configs[3] size (B = 1, G = 131 072, V = 3, colour + depth), every Gaussian gradient and `extrinsics.grad`."""
+    from pf3plat_amd.rasterizer import rasterize_views
+    from pf3plat_amd.splatting import _viewbuf, depth_fake_color
+
+    hw = (256, 256)
+    sc = synthetic.make_scene(50, 131072, hw, num_views=3)
+    w = torch.rand((1, 3, 3, *hw), generator=torch.Generator().manual_seed(2))
+    wd = torch.rand((1, 3, *hw), generator=torch.Generator().manual_seed(3)) * 0.1
+
+    def fused(device):
+        m, c, h, o = _leafs(sc, device)
+        ext = sc.extrinsics.clone().to(device).requires_grad_(True)
+        dec = pf3plat_amd.DecoderSplattingCUDA().to(device)
+        out = dec.forward(Gaussians(m, c, h, o), ext, sc.intrinsics.to(device), sc.near.to(device), sc.far.to(device), hw, depth_mode=mode)
+        ((out.color * w.to(device)).sum() + (out.depth * wd.to(device)).sum()).backward()
+        return out.color.detach().cpu().numpy(), out.depth.detach().cpu().numpy(), (m, c, h, o), ext.grad.cpu().numpy()
+
+    def literal():  # (oracle backend, CPU): the reference's graph, f(z) by torch ops, autograd doing the chain to means AND extrinsics
+        m, c, h, o = _leafs(sc, "cpu")
+        ext = sc.extrinsics.clone().requires_grad_(True)
+        e3, nr, fr = ext.reshape(3, 4, 4), sc.near.reshape(3), sc.far.reshape(3)
+        vb = _viewbuf(e3.detach(), sc.intrinsics.reshape(3, 3, 3), nr, fr, torch.zeros(3), True)
+        color, depth, _ = rasterize_views(m, c, o, h, vb, image_shape=hw, sh_degree=4, use_sh=True, views_per_set=3, sh_planar=True,
+                                          cov_3x3=True, extra=depth_fake_color(e3, nr, fr, m, mode))
+        ((color.reshape(1, 3, 3, *hw) * w).sum() + (depth.reshape(1, 3, *hw) * wd).sum()).backward()
+        return color.detach().numpy().reshape(1, 3, 3, *hw), depth.detach().numpy().reshape(1, 3, *hw), (m, c, h, o), ext.grad.numpy()
+
+    gc, gd, gl, ge = fused(DEV)
+    oc, od, ol, oe = _with_oracle(literal)
+    assert rel_l2(gc, oc) < 1e-4 and rel_l2(gd, od) < 1e-4
+    _cmp_grads(gl, ol)
+    assert np.abs(oe[0, :, :3]).sum() > 0 and rel_l2(ge, oe) < 1e-4, rel_l2(ge, oe)
+
+
 def test_backward_twice_with_retain_graph_and_settings_debug():
     """Upstream's Function can be differentiated repeatedly (retain_graph=True / several autograd.grad calls over one render);
     `settings.debug=True` reaches the library (per-stage synchronise + check) and changes no result."""
