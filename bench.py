@@ -191,8 +191,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_FORCE_DIST=1: take every distributed branch below even with ONE rank - the real "nccl" (= RCCL) backend then meets a
+    # communicator (init with device_id, all_gather_into_tensor destinations, async handles, barrier, all_reduce, the config-5 leg)
+    # on a 1-GPU box, before the first 8-GPU node does (tests/test_distributed.py::test_bench_py_rccl_communicator_world_size_1)
+    dist_on = world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -249,7 +254,7 @@ def main():
 
     def barrier():  # synchronize + barrier over the ranks + synchronize, as the contract asks around the timed region
         device_idle()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -278,16 +283,16 @@ def main():
     # N > 1: every rank keeps the K views it renders and ONE fused RCCL all-gather exchanges them at the end of the
     # timed region (north_star: "all-gather of rendered tiles ... only at the end").  Eager launches (the per-step
     # destination slot is not capturable in a static graph).
-    views = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev) if world > 1 else None
+    views = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev) if dist_on else None
     # The exchange is cut into up to 8 chunks of consecutive steps; a chunk's all-gather is issued (async, RCCL's own
     # stream) as soon as its last view is enqueued and overlaps the rendering of the next chunk - only the last chunk's
     # gather is exposed.  Every view is rendered straight into its slot of `views` (no copy).
-    n_chunks = (1 if args.config5 else min(8, max(1, K // 8))) if world > 1 else 0
+    n_chunks = (1 if args.config5 else min(8, max(1, K // 8))) if dist_on else 0
     bounds = [round(c * K / n_chunks) for c in range(n_chunks + 1)] if n_chunks else []
     # one (world, chunk, 3, H, W) destination per chunk: all_gather_into_tensor writes rank r's chunk at [r] (no list of slices,
     # which the RCCL backend would serve through a flat temporary and a copy)
     all_views = ([torch.empty((world, bounds[c + 1] - bounds[c], 3, H, W), dtype=torch.float32, device=dev) for c in range(n_chunks)]
-                 if (world > 1 and backend == "nccl") else None)
+                 if (dist_on and backend == "nccl") else None)
 
     def timed(fn, k, keep_views):
         barrier()
@@ -314,7 +319,7 @@ def main():
         return time.perf_counter() - t0
 
     gathered = []
-    if world > 1:
+    if dist_on:
         graph = None
     run = (graph.replay if graph is not None else step)
     # untimed set-up: bring the shader clock up.  MI355X drops to a low-power state within milliseconds of idle (the set-up above
@@ -342,14 +347,14 @@ def main():
             step()
     for _ in range(Wm):
         step()
-    dt = timed(step, K, world > 1)  # the headline: eager launches
+    dt = timed(step, K, dist_on)  # the headline: eager launches
     graph_dt = None
     if graph is not None:  # --graph: the same protocol over replays of the captured step, reported beside the headline
         for _ in range(min(Wm, 5)):
             graph.replay()
         graph_dt = timed(graph.replay, K, False)
     ranks_seen = 1
-    if world > 1:
+    if dist_on:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -361,7 +366,7 @@ def main():
     launch_mode = "eager"
     eager_dt = dt
     gather_check = None
-    if world > 1:
+    if dist_on:
         # what arrived: rank r's LAST rendered view must sit at [r] of the gathered tensor (every rank renders its own scene, so
         # the checksums differ and a permuted or stale slot shows)
         box = [None] * world
@@ -409,7 +414,7 @@ def main():
                             f"all_gather_into_tensor of the {K} x {world} views at the end",
                 "views_per_s": world * K / float(dt5.item()), "ms_per_step": 1e3 * float(dt5.item()) / K}
 
-    config5 = config5_leg() if (world > 1 and not args.config5) else None
+    config5 = config5_leg() if (dist_on and not args.config5) else None
 
     result = {
         "metric": "rendered views/sec, 300k Gaussians @ 256x256 (fwd raster); bwd ms and HBM GB/s vs roofline alongside",
@@ -425,7 +430,7 @@ def main():
                    "camera_setup": "excluded (gsr_setup_views runs once before the loop; ~4 us per batch of views)",
                    "num_pairs_8x8": status["num_pairs"], "max_tile_list": status["max_list"]},
     }
-    if world > 1:
+    if dist_on:
         result["rccl_ranks"] = ranks_seen
         result["dist_backend"] = backend
         result["gather_check"] = gather_check
@@ -441,7 +446,7 @@ def main():
     if args.headline_only:
         if rank == 0:
             print(json.dumps(result))
-        if world > 1:
+        if dist_on:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -464,16 +469,15 @@ def main():
         if color_in_bin:
             kb["preprocess"] += kb.pop("color")
         chain_stages = ("preprocess", "tiles") if color_in_bin else ("color", "preprocess", "tiles")
-        raw_acc = dict(acc)
-        # what an event boundary adds to a stage that holds a launch: the three event-timed stages minus the eager step (no
-        # events), per launch.  (An EMPTY stage - count_scan / emit on this path - reads higher, ~5 us: nothing hides its cost.)
+        # The stage times are the HIP-event readings AS MEASURED (events on the launch stream around each launch).  An event
+        # boundary keeps the next launch from being set up under the previous one, so the readings of the chain's launches add up to
+        # a little more than an eager step: that difference, per launch, is reported as `event_gap_ms` - it is NOT taken off.
         gap = max(0.0, (sum(acc[k_] for k_ in chain_stages) - 1e3 * (eager_dt if eager_dt is not None else dt) / K) / len(chain_stages))
-        for k_ in chain_stages:
-            acc[k_] = max(acc[k_] - gap, 1e-6)
         dom = max(chain_stages, key=lambda k_: acc[k_])
         ach = kb[dom] / (acc[dom] * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "kernel": KERNELS[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": kb[dom], "avg_ms": acc[dom]}
+                              "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_over_algorithmic": None,
+                              "algorithmic_bytes": kb[dom], "avg_ms": acc[dom], "event_gap_ms": gap}
         result["roofline_chain"] = {"bound": "hbm", "achieved": ab["total"] / (dt / K) / 1e9,
                                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ab["total"] / (dt / K) / 1e9 / HBM_PEAK_GBS,
                                     "algorithmic_bytes": ab["total"], "N": n, "N_v": nv, "R16": r16}
@@ -516,12 +520,11 @@ def main():
                 del rr, plan_rr
             except Exception as e:  # must never take the headline down
                 result["roofline_chain_cold"] = f"{type(e).__name__}: {e}"
-        result["stage_ms"] = {k_: round(acc[k_], 5) for k_ in chain_stages}
-        result["stage_ms_raw"] = {k_: round(raw_acc[k_], 5) for k_ in raw_acc}
+        result["stage_ms"] = {k_: round(acc[k_], 5) for k_ in acc}
         result["stage_ms"]["note"] = ("HIP events on the launch stream around each launch of the product chain ("
                                       + ("k_preprocess_bin with the colour pass inside it, " if color_in_bin else "k_color, k_preprocess_bin, ") +
-                                      f"k_tile_fwd) minus the cost of an event boundary ({1e3 * gap:.1f} us per launch: the event-timed stages minus the eager "
-                                      "step, so the stages add up to the eager step); stage_ms_raw holds the event readings")
+                                      "k_tile_fwd*), as measured; color / count_scan / emit hold no launch on this path (an empty event gap "
+                                      f"each); the launches' readings exceed the eager step by event_gap_ms = {1e3 * gap:.1f} us per launch")
         # ---- on-box HBM ceilings ("fraction against both"): device copy and triad over 1 GiB arrays
         try:
             nel = 256 << 20
@@ -564,6 +567,7 @@ def main():
                 traffic = None
             if traffic is not None:
                 result["roofline"]["traffic"] = traffic[KERNELS[dom]]["traffic"]
+                result["roofline"]["traffic_over_algorithmic"] = traffic[KERNELS[dom]]["traffic"] / kb[dom]
                 result["roofline"]["traffic_detail"] = dict(traffic[KERNELS[dom]], note=(
                     "per launch; rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH doubled per the guide's "
                     "gfx950 correction (exact for coalesced streams, an upper bound for gathers); WRITE uncalibrated"))
@@ -597,18 +601,25 @@ def main():
             ms = be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color, profile=True)
             for k_, v_ in ms.items():
                 bacc[k_] = bacc.get(k_, 0.0) + v_ / 20
-        raw_bacc = dict(bacc)
-        # same calibration: the two event-timed stages against the eager (fwd + bwd) - (fwd) difference
-        bgap = max(0.0, (sum(bacc.values()) - (fb_ms - 1e3 * dt / K)) / len(bacc))
-        for k_ in bacc:
-            bacc[k_] = max(bacc[k_] - bgap, 1e-6)
-        bwd_ms = sum(bacc.values())
+        # the training forward (GSR_FLAG_BACKWARD_FOLLOWS: accumulator rows zero-filled, d rgb / d direction saved) event-timed the
+        # same way, so that its cost over the inference forward has a name of its own instead of hiding in a chain difference
+        tacc = {}
+        for _ in range(20):
+            ms = be.run_forward(plan_b, viewbuf, means, cov6, opac, shs, profile=True)
+            be.run_backward(plan_b, viewbuf, means, cov6, opac, shs, None, g_color)
+            for k_, v_ in ms.items():
+                tacc[k_] = tacc.get(k_, 0.0) + v_ / 20
+        bwd_ms = sum(bacc.values())  # the two backward kernels, event readings as measured
         bb = backward_bytes(n, nv, r16, H * W, D_SH)
         result["bwd_ms"] = bwd_ms
         result["fwd_bwd_ms"] = fb_ms
         result["bwd_stage_ms"] = {k_: round(v_, 5) for k_, v_ in bacc.items()}
-        result["bwd_stage_ms_raw"] = {k_: round(v_, 5) for k_, v_ in raw_bacc.items()}
-        result["bwd_ms_chain_difference"] = fb_ms - 1e3 * dt / K  # eager fwd+bwd step minus the eager forward step
+        result["bwd_ms_chain_difference"] = fb_ms - 1e3 * dt / K  # eager fwd+bwd step minus the eager inference forward step
+        result["training_forward_stage_ms"] = {k_: round(tacc[k_], 5) for k_ in chain_stages}
+        result["training_forward_extra_ms"] = sum(tacc[k_] for k_ in chain_stages) - sum(acc[k_] for k_ in chain_stages)
+        result["bwd_note"] = ("bwd_ms = k_blend_bwd + k_preprocess_bwd (event readings); bwd_ms_chain_difference additionally holds "
+                              "training_forward_extra_ms: what the forward pays for a backward that follows (zero-filled accumulator rows, "
+                              "saved colour Jacobians), and is smaller by the event gaps")
         result["roofline_bwd"] = {"bound": "hbm", "achieved": bb / (bwd_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": bb / (bwd_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": bb}
         assert kb["blend_bwd"] + kb["preprocess_bwd"] == bb
@@ -729,7 +740,50 @@ def main():
                 torch.cuda.synchronize()
                 t8 = (time.perf_counter() - t0) / 40
                 assert not be.read_status(plan8)["overflow"]
-                result["batched_8_views"] = {"views_per_s": 8 / t8, "ms_per_launch_chain": 1e3 * t8}
+                result["batched_8_views"] = {"views_per_s": 8 / t8, "ms_per_launch_chain": 1e3 * t8, "us_per_view": 1e6 * t8 / 8}
+                # ---- many views of ONE scene in one call: PF3plat's video rendering makes 46-51 views of a scene per decoder call
+                # (reference src/model/model_wrapper.py:699-778, decoder call at :731; assets/evaluation_index_re10k_video.json).
+                # G = 131 072 (2 context views x 256 x 256), V = 48 cameras on the path between the two context cameras, one launch chain.
+                n_v, v48 = 131072, 48
+                offs48 = torch.linspace(-0.45, 0.45, v48).tolist()
+                sc48 = synthetic.make_scene(50, n_v, (H, W), d_sh=D_SH, num_views=v48, view_offsets=offs48)
+                in48 = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc48))
+                vb48 = synthetic.scene_viewbuf(sc48).to(dev)
+                cfg48 = RasterConfig(v48, 1, v48, n_v, H, W, 4, D_SH, 4, False)
+                plan48 = be.make_plan(cfg48, dev, capacity=8 * v48 * n_v)
+                be.run_forward(plan48, vb48, *in48)
+                st48 = be.read_status(plan48)
+                plan48 = be.make_plan(cfg48, dev, capacity=be.capacity_for(cfg48, st48, headroom=1.1))
+                for _ in range(3):
+                    be.run_forward(plan48, vb48, *in48)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(10):
+                    be.run_forward(plan48, vb48, *in48)
+                torch.cuda.synchronize()
+                t48 = (time.perf_counter() - t0) / 10
+                assert not be.read_status(plan48)["overflow"]
+                # SURVEY 8d bytes of the call: the Gaussians are read once for the set (means, cov, opacity, SH of those some view sees),
+                # everything per-view (projected records, keys, gather, image) once per view
+                g48 = plan48["geom"][: v48 * n_v * 32]
+                r48 = (g48.view(torch.int32).reshape(v48, n_v, 8)[:, :, 7] & 0x0FFFFFFF)
+                nv_any = int((r48 > 0).any(0).sum().item())
+                nv_sum, r16_sum = 0, 0
+                for v_ in range(v48):
+                    sub = dict(plan48, geom=plan48["geom"][v_ * n_v * 32:])
+                    a_, b_ = reference_rect_stats(sub, RasterConfig(1, 1, 1, n_v, H, W, 4, D_SH, 4, False))
+                    nv_sum += a_
+                    r16_sum += b_
+                kc = 12 * D_SH
+                ab48 = 12 * n_v + nv_any * (24 + 4 + kc) + nv_sum * 40 + r16_sum * (16 + 36) + v48 * H * W * (12 + 8)
+                result["video_48_views"] = {
+                    "workload": f"one call, {v48} views of one scene of {n_v} Gaussians (SH degree 4) at {H}x{W}: the reference's video rendering shape",
+                    "ms_per_call": 1e3 * t48, "us_per_view": 1e6 * t48 / v48, "views_per_s": v48 / t48,
+                    "algorithmic_bytes": ab48, "GBps": ab48 / t48 / 1e9, "frac": ab48 / t48 / 1e9 / HBM_PEAK_GBS,
+                    "colour_pass_inside_binning": bool(be.lib.gsr_colour_in_binning(ctypes.byref(plan48["dims"]))),
+                    "num_pairs_8x8": st48["num_pairs"],
+                    "note": "SURVEY 8d bytes with the set's inputs counted once (12 N + N_v(any view)(28 + 12 K)) and every per-view term per view"}
+                del plan48, in48, vb48, sc48
                 sc4 = synthetic.make_scene(50, 131072, (H, W), d_sh=D_SH, num_views=3).to(dev)
                 pf3plat_amd.get_backend().sync_policy = "lazy"  # inference loop: pair-count status verified asynchronously
                 dec = pf3plat_amd.DecoderSplattingCUDA().to(dev)
@@ -782,11 +836,33 @@ def main():
                     leaves = [t.detach().requires_grad_(True) for t in (g4.means, g4.covariances, g4.harmonics, g4.opacities)]
                     (render(Gaussians(*leaves)) * w4).sum().backward()
 
+                def train_step_depth(ext_grad):  # colour + depth every step (config/main.yaml:50); extrinsics from the encoder: require grad
+                    leaves = [t.detach().requires_grad_(True) for t in (g4.means, g4.covariances, g4.harmonics, g4.opacities)]
+                    ext = sc4.extrinsics.detach().requires_grad_(True) if ext_grad else sc4.extrinsics
+                    out = dec.forward(Gaussians(*leaves), ext, sc4.intrinsics, sc4.near, sc4.far, (H, W), depth_mode="depth")
+                    ((out.color * w4).sum() + (out.depth * wd4).sum()).backward()
+
+                wd4 = torch.rand((1, 3, H, W), device=dev)
                 be_pkg.sync_policy = "sync"
+                for _ in range(12):  # (the default policy defers a differentiated call's status once it has seen the shape a few times)
+                    train_step_depth(True)
+                t_cd = bench_call(lambda: train_step_depth(False), 40)
+                t_ref = bench_call(lambda: train_step_depth(True), 40)
+                result["decoder_config4_train_reference_graph"] = {
+                    "workload": "DecoderSplattingCUDA.forward + backward, B=1, G=131072, K=25, V=3, colour + depth, default status policy; "
+                                "reference graph = extrinsics require grad (model_wrapper.py:148-156) with depth rendered (config/main.yaml:50): "
+                                "f(z) stays inside the kernels, the depth term of the camera gradient comes out of the backward preprocess "
+                                "(GsrBackwardOptions.depth_term_only) and reaches extrinsics through gsr_setup_views_backward",
+                    "colour_depth_fwd_bwd_ms": 1e3 * t_cd, "reference_graph_fwd_bwd_ms": 1e3 * t_ref, "ratio": t_ref / t_cd}
                 t_drop = bench_call(dropin_fwd)
                 t_drop_fb = bench_call(lambda: train_step(lambda gg: reference_style_decoder_forward(gg, sc4.extrinsics, sc4.intrinsics, sc4.near, sc4.far, (H, W), bgc)), 10)
                 t_fused_sync = bench_call(lambda: fused_fwd("sync"))
-                t_fused_fb = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 10)
+                for _ in range(12):
+                    train_step(lambda gg: dec.forward(gg, *a4).color)
+                t_fused_fb = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 40)
+                be_pkg.defer_after = 0  # the same step with every forward blocking on its status block (round 3's behaviour)
+                t_fused_fb_blocking = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 20)
+                be_pkg.defer_after = 4
                 t_fused_lazy = bench_call(lambda: fused_fwd("lazy"))
                 be_pkg.check_pending(wait=True)
                 # what the reference's wrapper spends in its OWN torch ops before the operator is called (repeat, pre-scale,
@@ -815,6 +891,7 @@ def main():
                     "reference_style_fwd_bwd_ms": 1e3 * t_drop_fb,
                     "fused_decoder_fwd_ms": {"sync": 1e3 * t_fused_sync, "lazy": 1e3 * t_fused_lazy},
                     "fused_decoder_fwd_ms_per_view": 1e3 * t_fused_sync / 3, "fused_decoder_fwd_bwd_ms": 1e3 * t_fused_fb,
+                    "fused_decoder_fwd_bwd_ms_every_forward_blocking": 1e3 * t_fused_fb_blocking,
                     "operator_per_view_over_fused_per_view": (t_drop - t_wrapper_only) / t_fused_sync,
                 }
                 # ---- a larger image (the reference's test_splatter.py renders 512 x 512; evaluation runs go higher): one 1024 x 1024
@@ -898,7 +975,7 @@ def main():
             except Exception as e:  # extras must never take the headline line down
                 result["extras_error"] = f"{type(e).__name__}: {e}"
         print(json.dumps(result))
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -111,11 +111,16 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // Gaussians per binning workgroup.  The binning kernels are latency/VALU bound per workgroup, so the chip is fullest
 // when one round of workgroups covers all CUs: the chunk (a multiple of 64 in [kChunkMin, kChunkMax]) that minimises
 // rounds x chunk, the larger one on ties (fewer rows in the count matrix).
+// Chunks above kChunkPrefer are not considered: a workgroup stages its pairs in LDS (kStagePairs = 8192) for one linear copy-out,
+// and at the ~4.2 pairs per Gaussian of PF3plat-shaped scenes a 2048-Gaussian chunk lists ~8600 - past the staging area, every
+// pair then leaves as an 8-byte store of its own (measured: 48 views x 131 072 Gaussians chose 2048 by a tie and the binning
+// launch took 2437 us instead of ~600).
+constexpr int kChunkPrefer = 1600;
 static int choose_chunk(const GsrDims& d) {
   const long long V = d.num_views > 0 ? d.num_views : 1, N = d.num_gaussians > 0 ? d.num_gaussians : 1;
   long long best_cost = -1;
-  int best = kChunkMax;
-  for (int c = kChunkMax; c >= kChunkMin; c -= 64) {
+  int best = kChunkPrefer;
+  for (int c = kChunkPrefer; c >= kChunkMin; c -= 64) {
     const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + kCUs - 1) / kCUs) * c;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
   }
@@ -908,7 +913,7 @@ constexpr int kColorLdsFloats = 64 * 75;  // a full unit at M = 25 (row stride 7
 // The camera of a view is wave-uniform: its scale and centre are fetched with scalar loads (readfirstlane on the view index), not
 // with a per-lane global load that every unit's evaluation then waits a full memory round trip for, under the colour stream.
 template <bool kJ, bool kFull>
-__device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
+__device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i, const float* sh, int vbegin, int vstep, int vend,
                                                 float rmx, float rmy, float rmz, const CamLite& cam0) {
   const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = kFull ? 25 : p.d.sh_coeffs;
   const int deg = kFull ? 4 : min(p.d.sh_degree, p.d.max_sh_eval);
@@ -917,7 +922,7 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
   // the 75 LDS addresses occupied 75 registers.
   auto eval_views = [&](auto ks_c, auto cs_c) {
     const int ks = ks_c(), cs = cs_c();
-    for (int vv = vbegin; vv < Vs; vv += vstep) {
+    for (int vv = vbegin; vv < vend; vv += vstep) {
       const int v = __builtin_amdgcn_readfirstlane(set * Vs + vv);
       CamLite cam = cam0;
       if (vv != vbegin) cam = cam_lite(p.views, v);
@@ -969,10 +974,10 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
 // instance - with its loads hoisted it needs ~40 registers more, which the Jacobian variant (twelve accumulators) and the
 // stand-alone k_color (eight workgroups per CU) do not have.
 template <bool kJ, bool kAllowFull>
-__device__ __forceinline__ void color_eval(const Params& p, int set, int i, const float* sh, int vbegin, int vstep,
+__device__ __forceinline__ void color_eval(const Params& p, int set, int i, const float* sh, int vbegin, int vstep, int vend,
                                            float rmx, float rmy, float rmz, const CamLite& cam0) {
-  if (kAllowFull && p.d.sh_coeffs == 25 && min(p.d.sh_degree, p.d.max_sh_eval) == 4) color_eval_lane<kJ, true>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz, cam0);
-  else color_eval_lane<kJ, false>(p, set, i, sh, vbegin, vstep, rmx, rmy, rmz, cam0);
+  if (kAllowFull && p.d.sh_coeffs == 25 && min(p.d.sh_degree, p.d.max_sh_eval) == 4) color_eval_lane<kJ, true>(p, set, i, sh, vbegin, vstep, vend, rmx, rmy, rmz, cam0);
+  else color_eval_lane<kJ, false>(p, set, i, sh, vbegin, vstep, vend, rmx, rmy, rmz, cam0);
 }
 
 // `tid` = thread within the group (0 .. kColorThreads - 1), `lds` = the group's 19 200 B; the one barrier inside is the
@@ -1032,7 +1037,7 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
 #ifndef GSR_KCOLOR_FULL
 #define GSR_KCOLOR_FULL 0  // (the stand-alone colour launch lives on bandwidth at eight workgroups per CU: the compile-time instance buys it nothing)
 #endif
-  color_eval<kJ, GSR_KCOLOR_FULL != 0>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, rmx, rmy, rmz,
+  color_eval<kJ, GSR_KCOLOR_FULL != 0>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, Vs, rmx, rmy, rmz,
                         cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs + min(wave, Vs - 1))));
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1041,14 +1046,14 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
 // instruction, lane l's 16 bytes land at base + 16 l; nothing passes through registers), the wave waits for them and evaluates
 // every view of the set, lane = Gaussian.  `lds`: this wave's own kColorLdsFloats floats - no barrier, no other wave involved.
 template <bool kJ>
-__device__ __forceinline__ void color_unit_wave(const Params& p, int set, int unit, float* lds, int lane) {
+__device__ __forceinline__ void color_unit_wave(const Params& p, int set, int unit, float* lds, int lane, int vbegin, int vend) {
   const int N = p.d.num_gaussians, Vs = p.d.views_per_set, M = p.d.sh_coeffs;
   const int g0 = unit * 64, i = g0 + lane;
   const bool in_range = i < N;
   const size_t gi = (size_t)set * N + (in_range ? i : 0);
   if (M == 0) {  // precomputed colours: copy through (no clamp)
     if (in_range)
-      for (int vv = 0; vv < Vs; ++vv)
+      for (int vv = vbegin; vv < vend; ++vv)
         p.rgbc[(size_t)(set * Vs + vv) * N + i] = make_float4(p.colors[3 * gi], p.colors[3 * gi + 1], p.colors[3 * gi + 2], 0.f);
     return;
   }
@@ -1063,7 +1068,7 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
   // behind them, 3 us of issuing against the stream's back-pressure) are - asked for last, the evaluation waited a round trip for them
   float rmx = 0, rmy = 0, rmz = 0;
   if (in_range) { rmx = p.means[3 * gi + 0]; rmy = p.means[3 * gi + 1]; rmz = p.means[3 * gi + 2]; }
-  const CamLite cam0 = cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs));
+  const CamLite cam0 = cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs + vbegin));
   __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the previous unit's LDS reads have returned before its rows are overwritten
   if ((ldstride == rowf) && ((((uintptr_t)sh_src) & 15) == 0)) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -1091,10 +1096,10 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
 #ifndef GSR_COLOR_FULL_J
 #define GSR_COLOR_FULL_J 1
 #endif
-  if (in_range) color_eval<kJ, !kJ || GSR_COLOR_FULL_J>(p, set, i, lds + lane * ldstride, 0, 1, rmx, rmy, rmz, cam0);
+  if (in_range) color_eval<kJ, !kJ || GSR_COLOR_FULL_J>(p, set, i, lds + lane * ldstride, vbegin, 1, vend, rmx, rmy, rmz, cam0);
   if (GSR_COLOR_EVAL_PRIO) __builtin_amdgcn_s_setprio(0);
 #else
-  if (in_range) p.rgbc[(size_t)(set * p.d.views_per_set) * N + i] = make_float4(lds[lane * ldstride], rmx, rmy, rmz);  // experiment: stream without the arithmetic
+  if (in_range) p.rgbc[(size_t)(set * p.d.views_per_set + vbegin) * N + i] = make_float4(lds[lane * ldstride], rmx, rmy, rmz);  // experiment: stream without the arithmetic
 #endif
   if (dbg) stamp[3] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1133,6 +1138,7 @@ __global__ __launch_bounds__(kColorThreads) void k_color(const Params p) {
 #ifndef GSR_BIN_CB
 #define GSR_BIN_CB (GSR_BIN_CW + 1)
 #endif
+constexpr int kColorViewGroup = 4;  // views a colour task of the binning launch evaluates for its unit
 constexpr int kBinColorWaves = GSR_BIN_CW, kBinColorBufs = GSR_BIN_CB;  // unit buffers: one per colour wave + one for the staged pairs
 #ifndef GSR_CIB_MAX_TILES
 #define GSR_CIB_MAX_TILES 4608
@@ -1182,17 +1188,27 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   // Gaussians of this wave in iteration it (the colour waves have none: `end` for them)
   auto first_of = [&](int it) { return w < kWavesA ? row * p.chunk + w * 64 + it * kWavesA * 64 : end; };
   float* const colbufs = reinterpret_cast<float*>(hist + ((T + 3) & ~3));  // (kColor) the unit buffers; later the pair staging
-  // the row's units with (u - u0) = vv (mod Vs) are this workgroup's; its colour waves take them as they get free
+  // A colour task = one unit of the row x one group of up to kColorViewGroup views of the set.  The row's tasks with task number
+  // = vv (mod Vs) are this workgroup's; its colour waves take them as they get free.  Up to four views per set that is "the
+  // row's units dealt to the row's workgroups, every view of the set per unit" (the harmonics of a set are read once); with more
+  // views a wave that evaluated ALL of them for its unit was a few long tasks for five colour waves (8 views: 379 us against 334
+  // with the colour pass as a launch of its own) - in groups of four a workgroup has ~4.75 tasks whatever Vs is, and the unit's
+  // rows are read once per group (the repeats come out of L2 / the Infinity Cache: the row's workgroups run side by side).
+  // Round 4 measured that form for 8 views (GSR_CIB_MAX_VPS 16): 352.9 us against 342.2 with the separate launch - the binning
+  // launch WITHOUT colour waves has sixteen projecting waves instead of eleven, which is worth more than the launch it saves; the
+  // limit stays at four views per set.
   auto colour_role = [&](int cbuf) {
     float* buf = colbufs + (size_t)cbuf * kColorLdsFloats;
     const int Vs = p.d.views_per_set, set = v / Vs, vv = v - set * Vs;
     const int u0 = row * p.chunk / 64, u1 = (end + 63) / 64;
+    const int groups = (Vs + kColorViewGroup - 1) / kColorViewGroup, ntasks = (u1 - u0) * groups;
     while (true) {
       uint32_t k = 0;
       if (lane == 0) k = atomicAdd(&next_unit, 1u);
-      const int u = u0 + vv + Vs * (int)__builtin_amdgcn_readfirstlane((int)k);
-      if (u >= u1) break;
-      color_unit_wave<kJ>(p, set, u, buf, lane);
+      const int t = vv + Vs * (int)__builtin_amdgcn_readfirstlane((int)k);
+      if (t >= ntasks) break;
+      const int u = u0 + t / groups, g0v = (t - (t / groups) * groups) * kColorViewGroup;
+      color_unit_wave<kJ>(p, set, u, buf, lane, g0v, min(Vs, g0v + kColorViewGroup));
     }
   };  // (s_setprio 3 for these waves, or for the binning waves: no gain once the binning waves no longer wait for them)
   if (kColor && w >= kWavesA) colour_role(w - kWavesA);
@@ -3975,7 +3991,8 @@ static bool color_in_bin_for(const GsrDims& d, const Grid& g, int dev) {
   // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
   // tasks for its five colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
 #ifndef GSR_CIB_MAX_VPS
-#define GSR_CIB_MAX_VPS 4
+#define GSR_CIB_MAX_VPS 4  // (more views per set: colour tasks in groups of <= 4 views exist - colour_role - but measured no better
+                          // than the colour pass as a launch of its own: 8 views of the 300 k scene 352.9 vs 342.2 us)
 #endif
   return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= GSR_CIB_MAX_VPS &&
          ((g_color_bin_ok.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull) &&
@@ -4143,7 +4160,10 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   } while (0)
     // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
     if (!fused_bin) GSR_TILES(false, 4096);
-    else if (p.stride <= 2048u && p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {  // the usual case: cursor gather + prefix rank
+    // the usual case (cursor gather + prefix rank): long lists.  A slot of at most kPrefix (+ 25 %) entries means lists that are
+    // ranked whole anyway - many small tiles, e.g. one 1024 x 1024 view of the 300 k scene: 78 entries per tile - and those are
+    // better off with k_tile_fwd's smaller LDS footprint (five workgroups per CU instead of four: 192 vs 217 us for that view)
+    else if (p.stride <= 2048u && p.stride > (uint32_t)(kPrefix + kPrefix / 4) && p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {
       if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true>), tgrid, dim3(kFwdThreads), 0, st, p);
       else hipLaunchKernelGGL((k_tile_fwd_prefix<false>), tgrid, dim3(kFwdThreads), 0, st, p);
     } else if (p.stride <= 2048u) GSR_TILES(true, 2048);

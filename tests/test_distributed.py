@@ -130,3 +130,31 @@ def test_bench_py_two_ranks_on_one_gpu_real_hip_path():
     assert abs(a - b) > 1.0  # two different scenes
     assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert d["config5"]["views_per_s"] > 0 and "one fused" in d["config5"]["workload"]
+
+
+@pytest.mark.gpu
+def test_bench_py_rccl_communicator_world_size_1():
+    """The real "nccl" (= RCCL) backend meets a communicator before the first 8-GPU node does: bench.py launched the way the driver
+    launches it, ONE rank, BENCH_FORCE_DIST=1 - so `init_process_group("nccl", device_id=...)`, the per-batch
+    `all_gather_into_tensor` destinations with their async handles, `dist.barrier()` inside the timed bracket, the MAX / SUM
+    all-reduces behind `rccl_ranks`, the gather check and the config-5 leg (one fused gather at the end) all run on RCCL.
+    Parallelism mirrored: one scene per GPU (reference src/main.py:109); workload of the config-5 leg:
+    assets/evaluation_index_dl3dv_10view.json (2 context -> 1 target view)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    env.pop("BENCH_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "3",
+           "--preheat-ms", "20", "--gaussians", "60000", "--headline-only"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["dist_backend"] == "nccl" and d["rccl_ranks"] == 1
+    assert d["gather_check"]["ok"], d["gather_check"]
+    assert d["config5"]["views_per_s"] > 0 and "one fused" in d["config5"]["workload"]
+    assert d["value"] > 0 and abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
