@@ -2843,13 +2843,16 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     const int cnt = q8 + (xcd < r8 ? 1 : 0), base = t - k;  // this XCD's tiles: [base, base + cnt)
     if (cnt <= kBalanceMax) {
       if (wave == 0) {
-        // keys (walked + 1) << 8 | (255 - index): distinct, heavier first, equal loads in index order; up to four per lane
+        // keys (walked + 1) << 8 | (255 - index): distinct, heavier first, equal loads in index order; up to four per lane.
+        // CORRECTNESS rests on the low 8 bits alone - they are distinct, so the deal is a bijection of the XCD's tiles whatever
+        // tile_total holds (walked counts after a normal forward; binning totals or anything else after an overflowed one) -
+        // the load only decides the ORDER; it is clamped so that the shift cannot drop its high bits (the order stays monotonic)
         const uint32_t* tot = p.tile_total + (size_t)v * g.T + base;
         uint32_t key[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int i = lane + 64 * c;
-          key[c] = i < cnt ? ((tot[i] + 1u) << 8) | (uint32_t)(255 - i) : 0u;
+          key[c] = i < cnt ? ((min(tot[i], 0xfffffeu) + 1u) << 8) | (uint32_t)(255 - i) : 0u;
         }
         const int round = k >> 5, in = k & 31, len = cnt - (round << 5) < 32 ? cnt - (round << 5) : 32;
         const int want = (round << 5) + ((round & 1) ? len - 1 - in : in);  // position of this block in heaviest-first order

@@ -1,6 +1,8 @@
 """Randomised HIP-vs-oracle parity sweep (MI355X box): random Gaussian counts, image sizes, view / set structure, SH degrees,
 extra channel, scale factors and pair capacities, every case through the same checks as tests/test_gpu_parity.py.
-usage: python tools/fuzz_parity.py [seconds=60] [seed=0]"""
+usage: python tools/fuzz_parity.py [seconds=60] [seed=0]
+       python tools/fuzz_parity.py --cases 1000 --seeds 0,1,2,3,4 --out gpurun_out/fuzz.json   (the margin survey: every case's worst
+       image / gradient rel-L2 and its outlier counts -> histogram; tools/fuzz_report.py turns the file into profiles/*.md)"""
 import os
 import sys
 import time
@@ -68,13 +70,45 @@ def one_case(rng):
             parity_checks.check_preprocess(res, cfg, v)
             parity_checks.check_tile_lists(res, cfg, v, max_tiles=16)
             parity_checks.check_image_state(res, cfg, v)
-    parity_checks.check_image(res, cfg)
-    if n:
-        parity_checks.check_grads(res, cfg)
+    mi = parity_checks.check_image(res, cfg)
+    mg = parity_checks.check_grads(res, cfg) if n else {}
+    # the case's margin: the largest rel-L2 over ALL elements (nothing set aside) of the image and of any gradient tensor
+    one_case.metrics = dict(
+        img=max(mi.get("color_rel_l2_all", 0.0), mi.get("extra_rel_l2_all", 0.0)),
+        img_kept=max(mi.get("color_rel_l2", 0.0), mi.get("extra_rel_l2", 0.0)),
+        grad=max([v for k, v in mg.items() if k.endswith("_rel_l2_all") and mg.get(k.replace("_rel_l2_all", "_norm"), 0) > 0] or [0.0]),
+        grad_kept=max([v for k, v in mg.items() if k.endswith("_rel_l2") and mg.get(k.replace("_rel_l2", "_norm"), 0) > 0] or [0.0]),
+        outlier_px=int(mi.get("outlier_pixels_1e-4", 0)), flipped_px=int(mg.get("flipped_pixels", 0)),
+        set_aside=int(max([v for k, v in mg.items() if k.endswith("_set_aside")] or [0])), pixels=views * h * w, n=n)
     return desc
 
 
+def survey(cases, seeds, out):
+    """`cases` random cases per seed: every case's margins into `out` (JSON): the histogram behind the stated parity margin."""
+    import json
+
+    rows, t0 = [], time.time()
+    for seed in seeds:
+        rng = np.random.default_rng(seed)
+        for k in range(cases):
+            desc = one_case(rng)
+            rows.append(dict(one_case.metrics, seed=seed, case=k, hw=desc["hw"], views=desc["sets"] * desc["vps"], det=desc["det"],
+                             windowed=desc["windowed"]))
+        print(f"seed {seed}: {cases} cases ok ({time.time() - t0:.0f} s so far)", flush=True)
+    os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
+    json.dump(dict(cases_per_seed=cases, seeds=list(seeds), seconds=time.time() - t0, rows=rows), open(out, "w"))
+    g = np.array([r["grad"] for r in rows])
+    im = np.array([r["img"] for r in rows])
+    print(f"{len(rows)} cases, worst image rel-L2 {im.max():.3e}, worst gradient rel-L2 {g.max():.3e}  -> {out}")
+
+
 def main():
+    if "--cases" in sys.argv:
+        a = sys.argv
+        cases = int(a[a.index("--cases") + 1])
+        seeds = [int(x) for x in a[a.index("--seeds") + 1].split(",")] if "--seeds" in a else [0]
+        out = a[a.index("--out") + 1] if "--out" in a else "gpurun_out/fuzz.json"
+        return survey(cases, seeds, out)
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     t0, k = time.time(), 0
