@@ -2963,26 +2963,35 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   auto eval = [&](uint32_t it) {  // stage E
     const int ring = it & 3;
     const uint32_t base = batch_of(it) * kBB + e0;
-    const uint32_t rem = my_last > base ? my_last - base : 0u;  // entry u of the segment is in front of the pixel's last one <=> u < rem
+#ifndef GSR_BWD_REM_FAST
+#define GSR_BWD_REM_FAST 0
+#endif
+    // entry u of the segment is in front of the pixel's last one <=> u < rem.  (GSR_BWD_REM_FAST: a segment that lies in front of EVERY
+    // pixel's last contributor - wave-uniform - is given rem = "all": the per-entry index tests then fold to constants)
+    const uint32_t rem = my_last > base ? my_last - base : 0u;
     int es = e0;  // opaque copy: the three LDS addresses are then formed here, per batch, instead of living in three registers
     if (kExtra) asm volatile("" : "+v"(es));  // across the whole loop (the kExtra instances spilled exactly those)
+    auto entries = [&](auto all_in_front) {
 #pragma unroll
-    for (int u = 0; u < kBS; ++u) {
-      const float4 a = sGeo[ring][es + u], a2 = sGeo2[ring][es + u], c = sCol[ring][es + u];
-      const float dx = a.x - pxf, dy = a.y - pyf;
-      const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
-      const float G = __builtin_amdgcn_exp2f(p2);
-      const float og = a2.y * G;
-      const bool contrib = ((uint32_t)u < rem) && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
-      al[u] = contrib ? fminf(0.99f, og) : 0.f;
-      Gc[u] = contrib ? G : 0.f;
-      float cg = c.x * g0;
-      cg = __builtin_fmaf(c.y, g1, cg);
-      cg = __builtin_fmaf(c.z, g2, cg);
-      if (kExtra) cg = __builtin_fmaf(c.w, ge, cg);
-      cgv[u] = cg;
-      om[u] = 1.f - al[u];
-    }
+      for (int u = 0; u < kBS; ++u) {
+        const float4 a = sGeo[ring][es + u], a2 = sGeo2[ring][es + u], c = sCol[ring][es + u];
+        const float dx = a.x - pxf, dy = a.y - pyf;
+        const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
+        const float G = __builtin_amdgcn_exp2f(p2);
+        const float og = a2.y * G;
+        const bool contrib = (all_in_front() || (uint32_t)u < rem) && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
+        al[u] = contrib ? fminf(0.99f, og) : 0.f;
+        Gc[u] = contrib ? G : 0.f;
+        float cg = c.x * g0;
+        cg = __builtin_fmaf(c.y, g1, cg);
+        cg = __builtin_fmaf(c.z, g2, cg);
+        if (kExtra) cg = __builtin_fmaf(c.w, ge, cg);
+        cgv[u] = cg;
+        om[u] = 1.f - al[u];
+      }
+    };
+    if (GSR_BWD_REM_FAST && __all(rem >= (uint32_t)kBS)) entries([] { return true; });  // (wave-uniform)
+    else entries([] { return false; });
     float Pl = 1.f, ql = 0.f;  // the segment's own product of (1 - alpha) and its replay of Q from 0, back to front
 #pragma unroll
     for (int u = kBS - 1; u >= 0; --u) {
@@ -3136,7 +3145,16 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   __syncthreads();
   const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
   float Tb = T_final;                                              // (T, Q) at the back end of the batch: the same in all four
+#ifndef GSR_BWD_BG_SCALAR
+#define GSR_BWD_BG_SCALAR 0
+#endif
+#if GSR_BWD_BG_SCALAR  // the view's background through scalar loads (constant address space), as the forward does
+  typedef const __attribute__((address_space(4))) float* cfptr_b;
+  cfptr_b camc_b = reinterpret_cast<cfptr_b>(reinterpret_cast<uintptr_t>(p.views + __builtin_amdgcn_readfirstlane(v)));
+  float Qb = camc_b[37] * g0 + camc_b[38] * g1 + camc_b[39] * g2;
+#else
   float Qb = cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2;    // waves (behind the last splat Q = Bg / T_final = bg.g)
+#endif
   if (dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
   // T_final has to have ARRIVED before the loop: a load still counted as pending at the loop's entry makes the compiler wait
   // for "everything" at the first use of Tb inside the loop - on every iteration, right behind the gather just issued

@@ -379,6 +379,89 @@ def test_lazy_policy_backward_refuses_a_poisoned_forward_and_sync_policy_retries
     assert all(torch.isfinite(t).all() for t in grads if t is not None)
 
 
+def test_default_policy_defers_the_status_of_differentiated_calls_and_their_backward_verifies_it():
+    """Default (`sync`) policy, round 4: a forward that WILL be differentiated (GSR_FLAG_BACKWARD_FOLLOWS) stops blocking on its
+    status block once the shape has been read `defer_after` (4) times - it is sized from the running maximum and verified at the
+    end of its own backward.  A scene that then outgrows the workspace gets a NaN image and its backward raises (the hint has
+    grown: the next step fits); calls nothing differentiates keep the blocking read + retry; `defer_after = 0` switches it off."""
+    from pf3plat_amd import _lib, rasterizer
+    from pf3plat_amd.synthetic import scene_operator_inputs, scene_viewbuf
+
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(16, 4000, (64, 64))
+    means, cov6, opac, colors = (t.to(dev) for t in scene_operator_inputs(sc))
+    vb = scene_viewbuf(sc).to(dev)
+    cfg = RasterConfig(1, 1, 1, 4000, 64, 64, 4, 25, 4, False, _lib.FLAG_BACKWARD_FOLLOWS)
+    g = torch.rand((1, 3, 64, 64), device=dev)
+    be = rasterizer.HipBackend()
+    assert be.sync_policy == "sync" and be.defer_after == 4
+    key = (1, 4000, 64, 64)
+    for k in range(4):  # the shape is being learnt: every forward blocks and reads its status
+        c, _, _, saved = be.forward(cfg, vb, means, cov6, opac, colors, None)
+        assert not be.pending and be.seen[key] == k + 1 and torch.isfinite(c).all()
+        grads_sync = be.backward(cfg, saved, vb, means, cov6, opac, colors, None, g, None, True, rows_in_workspace=True)
+    c, _, _, saved = be.forward(cfg, vb, means, cov6, opac, colors, None)  # deferred: returns with the status copy in flight
+    assert len(be.pending) == 1
+    grads = be.backward(cfg, saved, vb, means, cov6, opac, colors, None, g, None, True, rows_in_workspace=True)
+    assert not be.pending and be.seen[key] == 5  # verified at the end of its own backward
+    for a, b in zip(grads, grads_sync):  # (fp32 atomics: equal up to the order of the sums)
+        if a is not None:
+            assert parity_checks.rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    # a call nothing differentiates (no flag) still blocks and retries
+    cfg_inf = RasterConfig(1, 1, 1, 4000, 64, 64, 4, 25, 4, False)
+    c_inf, _, _, _ = be.forward(cfg_inf, vb, means, cov6 * 400.0, opac, colors, None)
+    assert not be.pending and torch.isfinite(c_inf).all() and not be.last_status["overflow"]
+    # deferred call whose lists no longer fit: NaN image, the backward raises, the hint grows, the next step is fine
+    be2 = rasterizer.HipBackend()
+    for _ in range(4):
+        be2.forward(cfg, vb, means, cov6, opac, colors, None)
+    big = cov6 * 400.0
+    c_bad, _, _, saved_bad = be2.forward(cfg, vb, means, big, opac, colors, None)
+    with pytest.raises(RuntimeError, match="poisoned with NaN"):
+        be2.backward(cfg, saved_bad, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
+    assert torch.isnan(c_bad).all()
+    c_ok, _, _, saved_ok = be2.forward(cfg, vb, means, big, opac, colors, None)
+    out = be2.backward(cfg, saved_ok, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
+    assert torch.isfinite(c_ok).all() and all(torch.isfinite(t).all() for t in out if t is not None)
+    # switched off: every forward blocks again
+    be3 = rasterizer.HipBackend()
+    be3.defer_after = 0
+    for _ in range(6):
+        be3.forward(cfg, vb, means, cov6, opac, colors, None)
+        assert not be3.pending
+    # a forward run with reuse_workspaces has no backward
+    _, _, _, none_saved = be3.forward(cfg_inf, vb, means, cov6, opac, colors, None, reuse_workspaces=True)
+    assert none_saved is None
+    with pytest.raises(RuntimeError, match="has no backward"):
+        be3.backward(cfg_inf, none_saved, vb, means, cov6, opac, colors, None, g, None, True)
+    be3.release_workspaces()
+    assert not be3.workspace_cache
+
+
+def test_setup_views_backward_kernel_matches_the_closed_form():
+    """gsr_setup_views_backward (one launch, fp64 inside) == the closed form in fp64 torch ops (tests/oracle_backend.py): random
+    camera-record gradients carried to dL/d extrinsics for perspective cameras with and without the scale-invariant factor."""
+    from pf3plat_amd import rasterizer
+    from tests.oracle_backend import OracleBackend
+
+    gen = torch.Generator().manual_seed(9)
+    v = 5
+    ext = torch.eye(4).repeat(v, 1, 1)
+    q = torch.linalg.qr(torch.randn((v, 3, 3), generator=gen))[0]
+    ext[:, :3, :3] = q
+    ext[:, :3, 3] = torch.randn((v, 3), generator=gen)
+    intr = torch.tensor([[0.8, 0, 0.5], [0, 0.9, 0.5], [0, 0, 1.0]]).repeat(v, 1, 1)
+    near, far = torch.full((v,), 0.7), torch.full((v,), 50.0)
+    dvw = torch.randn((v, 48), generator=gen)
+    dvw[:, 35:] = 0
+    be = rasterizer.get_backend()
+    for scale_invariant in (True, False):
+        vb_cpu = OracleBackend().setup_views(ext, intr, near, far, torch.zeros(3), scale_invariant)
+        want = OracleBackend().setup_views_backward(vb_cpu, dvw).numpy()
+        got = be.setup_views_backward(vb_cpu.to("cuda:0"), dvw.to("cuda:0")).cpu().numpy()
+        assert parity_checks.rel_l2(got, want) < 1e-6, (scale_invariant, parity_checks.rel_l2(got, want))
+
+
 def test_deterministic_backward_is_bit_identical_and_within_tolerance():
     """GSR_FLAG_DETERMINISTIC: per-Gaussian sums in 64-bit fixed point - two runs agree bit for bit (the default fp32-atomic
     mode only to rounding), and the result stays within 1e-4 of the oracle."""
