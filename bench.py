@@ -253,10 +253,11 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():  # synchronize + barrier over the ranks + synchronize, as the contract asks around the timed region
-        device_idle()
+        device_idle()  # (ends with torch.cuda.synchronize())
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()  # (one rank, no process group: the synchronize above is the bracket's - a second one on an
+            #                            idle device is ~8 us of host time inside a 20-step window: tools/window_probe.py)
 
     # ---- optional HIP-graph capture of one step (a plain chain of three kernel launches on one stream)
     graph = None

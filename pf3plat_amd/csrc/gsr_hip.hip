@@ -3481,13 +3481,22 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) dcov[k] += dcv[k] * cam.scale2;
     }  // vis
-    if (kPose) {  // sums over the four 16-lane DPP rows (4 DPP adds per value; a full wave sum costs 6 LDS permutes): 4 partial rows
-      constexpr int kF = kPose == 1 ? kPoseFloats : kPoseZFloats;
-      float* row = p.pose_partials + (((size_t)v * gridDim.x + blockIdx.x) * 4 + (lane >> 4)) * kF;
+    if (kPose == 1) {  // sums over the four 16-lane DPP rows (4 DPP adds per value; a full wave sum costs 6 LDS permutes): 4 partial rows
+      float* row = p.pose_partials + (((size_t)v * gridDim.x + blockIdx.x) * 4 + (lane >> 4)) * kPoseFloats;
 #pragma unroll
-      for (int k = 0; k < kF; ++k) {
+      for (int k = 0; k < kPoseFloats; ++k) {
         const float s = row_allreduce(pose[k]);
         if ((lane & 15) == 0) row[k] = s;
+      }
+    }
+    if (kPose == 2) {  // four values only: the whole wave's sum (DPP rows, then the four row results through scalar registers): ONE row
+      float* row = p.pose_partials + ((size_t)v * gridDim.x + blockIdx.x) * kPoseZFloats;
+#pragma unroll
+      for (int k = 0; k < kPoseZFloats; ++k) {
+        const float s = row_allreduce(pose[k]);
+        auto at = [&](int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), l)); };
+        const float tot = (at(0) + at(16)) + (at(32) + at(48));
+        if (lane == 0) row[k] = tot;
       }
     }
   }
@@ -4290,7 +4299,8 @@ static int backward_impl(const GsrDims* dims, const GsrView* views, const float*
     } else {
       if (p.shj) hipLaunchKernelGGL((k_preprocess_bwd<2, true>), pgrid, dim3(64), shmem, st, p);
       else hipLaunchKernelGGL((k_preprocess_bwd<2, false>), pgrid, dim3(64), shmem, st, p);
-      const int rows1 = (int)pgrid.x * 4, blocks1 = rows1 < 64 ? 1 : 64;
+      // one 16-byte row per (view, 64-Gaussian unit): up to 16 384 rows per view are summed by one block per view in one launch
+      const int rows1 = (int)pgrid.x, blocks1 = rows1 <= 16384 ? 1 : 64;
       float* level1 = pose_partials + (size_t)V * rows1 * kPoseZFloats;  // behind the rows of the first level
       if (blocks1 > 1) {
         hipLaunchKernelGGL(k_pose_reduce_z, dim3((unsigned)V, (unsigned)blocks1), dim3(256), 0, st, pose_partials, rows1, level1, 0);
