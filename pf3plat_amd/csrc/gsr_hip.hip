@@ -1875,7 +1875,14 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
     const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kLds;
     // (the longest list so far, statistics.  Two ways of taking this read off wave 1's path were tried - asked for at the kernel's start:
     // it reads 0 in every tile and a thousand same-address atomics follow, +2 us; asked for here and compared after the run copy: +11 us)
-    if (tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);  // a handful of tiles get this far
+#ifndef GSR_MAXLIST_LATE
+#define GSR_MAXLIST_LATE 1
+#endif
+    // Round 4: for the usual tile (`plain`) the statistic is updated by k_tile_fwd AFTER the tile's image is written - here it sat
+    // in front of a barrier, and a barrier waits for the wave's outstanding memory operations: the load of a word every tile of
+    // the launch goes for and, for the first tiles to arrive, a device-scope atomic queued behind hundreds of others (see
+    // k_tile_fwd_prefix).  A tile that may fail to place its list keeps the early update: the caller sizes its retry from it.
+    if ((!GSR_MAXLIST_LATE || !plain) && tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);
     if (plain) {
       if (tid == 0) p.ranges[tg] = make_uint2((uint32_t)tg * p.stride, (uint32_t)tg * p.stride + (uint32_t)n);
     } else if (tid == 0) {
@@ -2410,6 +2417,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
   const int tg = kGather ? xcd_remap((int)bid, (int)p.sort_blocks) : (int)bid;
   const int v = tg / p.g.T;
   blend_tile<kExtra>(p, v, tg - v * p.g.T, rg, *reinterpret_cast<BlendLds*>(smem));
+  if (kGather && GSR_MAXLIST_LATE && threadIdx.x == 64 && rg.y - rg.x > p.status->max_list) atomicMax(&p.status->max_list, rg.y - rg.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3037,18 +3045,19 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     // (Two pixels per packed-fp32 instruction was tried here: 5 % fewer instructions, but the register pairs it needs push
     // the kernel past its 128 registers - the spills cost more than the packing saves.)
     float v6 = 0, v7 = 0, v8 = 0, v9 = 0;
-    const float dx0 = a.x - (float)rpx0, dy = a.y - (float)rpy;
-    // moments of q along the row about its first pixel (weights k and k^2 are instruction literals), shifted to the splat centre
-    // afterwards: sum q (dx0 - k)^n for n = 1, 2 from S0, S1 = sum k q, S2 = sum k^2 q - 22 instructions instead of 39
-    float S0 = qk[0] + qk[1], S1 = qk[1], S2 = qk[1];
-#pragma unroll
-    for (int k = 2; k < 8; ++k) {
-      S0 += qk[k];
-      S1 = __builtin_fmaf(qk[k], (float)k, S1);
-      S2 = __builtin_fmaf(qk[k], (float)(k * k), S2);
-    }
-    float Sx = __builtin_fmaf(dx0, S0, -S1);               // sum q (dx0 - k)
-    float Sxx = __builtin_fmaf(dx0, Sx - S1, S2);          // sum q (dx0 - k)^2 = dx0 (dx0 S0 - 2 S1) + S2
+    // moments of q along the row about the row's CENTRE (pixel 3.5), shifted to the splat centre afterwards:
+    // sum q (dxc - j)^n, j = k - 3.5, for n = 1, 2 from S0, S1 = sum j q, S2 = sum j^2 q.  The weights pair up (j = -+3.5, -+2.5,
+    // -+1.5, -+0.5), so the four pair sums feed S0 and S2 and the four pair differences S1: 19 instructions, as many as about the
+    // row's first pixel (round 3) - but the terms that cancel in the shift are a quarter the size (|j| <= 3.5 instead of 7: for
+    // the narrowest splats, whose centre lies inside the row, that is two more bits of the conic gradient)
+    const float dxc = a.x - ((float)rpx0 + 3.5f), dy = a.y - (float)rpy;
+    const float p07 = qk[0] + qk[7], p16 = qk[1] + qk[6], p25 = qk[2] + qk[5], p34 = qk[3] + qk[4];
+    const float m70 = qk[7] - qk[0], m61 = qk[6] - qk[1], m52 = qk[5] - qk[2], m43 = qk[4] - qk[3];
+    const float S0 = (p07 + p16) + (p25 + p34);
+    const float S1 = __builtin_fmaf(m70, 3.5f, __builtin_fmaf(m61, 2.5f, __builtin_fmaf(m52, 1.5f, 0.5f * m43)));
+    const float S2 = __builtin_fmaf(p07, 12.25f, __builtin_fmaf(p16, 6.25f, __builtin_fmaf(p25, 2.25f, 0.25f * p34)));
+    float Sx = __builtin_fmaf(dxc, S0, -S1);               // sum q (dxc - j)
+    float Sxx = __builtin_fmaf(dxc, Sx - S1, S2);          // sum q (dxc - j)^2 = dxc (dxc S0 - 2 S1) + S2
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       v6 = __builtin_fmaf(wk[k], rg0[k], v6);

@@ -80,3 +80,38 @@ def test_segmented_q_recurrence_equals_the_sequential_replay(n):
     d_seg, w_seg = segmented_replay(alpha, cg, bgg)
     np.testing.assert_allclose(w_seg, w_ref, rtol=1e-10, atol=1e-13)
     np.testing.assert_allclose(d_seg, d_ref, rtol=1e-9, atol=1e-11)
+
+
+def test_row_moments_about_the_row_centre_equal_the_direct_sums_and_lose_less_in_fp32():
+    """Stage R of k_blend_bwd: the moments of q = G dL/dalpha along a pixel row are taken about the row's CENTRE with paired
+    weights (S0, S1 = sum j q, S2 = sum j^2 q, j = k - 3.5) and shifted to the splat centre:
+        sum q (dxc - j) = dxc S0 - S1,      sum q (dxc - j)^2 = dxc (dxc S0 - 2 S1) + S2.
+    Exact in fp64; in fp32 the shift cancels terms of size |j|^2 S0 down to sigma^2 S0 - about the centre (|j| <= 3.5) that loses
+    less than about the row's first pixel (|k| <= 7: round 3's form) for narrow splats centred inside the row."""
+    rng = np.random.default_rng(0)
+    worst = {"centre": 0.0, "first": 0.0}
+    for _ in range(400):
+        x = rng.uniform(0.0, 7.0)  # splat centre inside the row (pixel units from the row's first pixel)
+        k = np.arange(8.0)
+        q = np.exp(-0.5 * (x - k) ** 2 / 0.3) * rng.uniform(0.5, 1.5, 8)  # weights of a sigma^2 = 0.3 px splat
+        direct_x, direct_xx = np.sum(q * (x - k)), np.sum(q * (x - k) ** 2)
+        j = k - 3.5
+        S0, S1, S2 = q.sum(), (q * j).sum(), (q * j * j).sum()
+        dxc = x - 3.5
+        assert abs(dxc * S0 - S1 - direct_x) < 1e-12 and abs(dxc * (dxc * S0 - 2 * S1) + S2 - direct_xx) < 1e-12
+        f = np.float32
+        q32 = q.astype(f)
+        ref = float(np.sum(q32.astype(np.float64) * (x - k) ** 2))
+        for name, (org, wts) in {"centre": (3.5, j), "first": (0.0, k)}.items():
+            s0 = f(0)
+            s1 = f(0)
+            s2 = f(0)
+            for qi, wi in zip(q32, wts.astype(f)):
+                s0 = f(s0 + qi)
+                s1 = f(s1 + f(qi * wi))
+                s2 = f(s2 + f(qi * f(wi * wi)))
+            d = f(f(x) - f(org))
+            sx = f(f(d * s0) - s1)
+            sxx = f(f(d * f(sx - s1)) + s2)
+            worst[name] = max(worst[name], abs(float(sxx) - ref) / ref)
+    assert worst["centre"] < 0.6 * worst["first"], worst
