@@ -812,8 +812,8 @@ def main():
                 be_pkg.check_pending(wait=True)
                 bgc = torch.zeros(3, device=dev)
 
-                def bench_call(fn, reps=20):
-                    for _ in range(3):
+                def bench_call(fn, reps=20, warm=3):
+                    for _ in range(warm):
                         fn()
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
@@ -847,8 +847,8 @@ def main():
                 be_pkg.sync_policy = "sync"
                 for _ in range(12):  # (the default policy defers a differentiated call's status once it has seen the shape a few times)
                     train_step_depth(True)
-                t_cd = bench_call(lambda: train_step_depth(False), 40)
-                t_ref = bench_call(lambda: train_step_depth(True), 40)
+                t_cd = bench_call(lambda: train_step_depth(False), 100, 40)  # (host-paced legs: enough steps for the clocks to settle)
+                t_ref = bench_call(lambda: train_step_depth(True), 100, 40)
                 result["decoder_config4_train_reference_graph"] = {
                     "workload": "DecoderSplattingCUDA.forward + backward, B=1, G=131072, K=25, V=3, colour + depth, default status policy; "
                                 "reference graph = extrinsics require grad (model_wrapper.py:148-156) with depth rendered (config/main.yaml:50): "
@@ -860,9 +860,9 @@ def main():
                 t_fused_sync = bench_call(lambda: fused_fwd("sync"))
                 for _ in range(12):
                     train_step(lambda gg: dec.forward(gg, *a4).color)
-                t_fused_fb = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 40)
+                t_fused_fb = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 100, 40)
                 be_pkg.defer_after = 0  # the same step with every forward blocking on its status block (round 3's behaviour)
-                t_fused_fb_blocking = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 20)
+                t_fused_fb_blocking = bench_call(lambda: train_step(lambda gg: dec.forward(gg, *a4).color), 60, 20)
                 be_pkg.defer_after = 4
                 t_fused_lazy = bench_call(lambda: fused_fwd("lazy"))
                 be_pkg.check_pending(wait=True)
