@@ -1761,6 +1761,16 @@ __device__ __forceinline__ void bitonic_block(KeyPtr a, int n, int lgnp, int tid
 constexpr int kSpanMax = 48;      // most keys in one depth bucket the rank finish accepts (else bitonic fallback)
 
 // Exclusive scan over the kSortThreads per-thread values of a workgroup (wave scan + 4 wave totals through LDS).
+// Workgroup-wide OR of a predicate with its barrier (four waves).  Own version of __syncthreads_or: the device library's keeps a
+// 256-byte LDS scratch per kernel and k_tile_fwd_prefix sits 120 bytes above the size at which five workgroups share a CU (LDS is
+// handed out in 1280-byte units on gfx950).  `slot`: four LDS words of this call site's own.
+__device__ __forceinline__ bool block_any(const bool pred, uint32_t* slot) {
+  const bool w = __any((int)pred) != 0;
+  if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = w ? 1u : 0u;
+  __syncthreads();
+  return (slot[0] | slot[1] | slot[2] | slot[3]) != 0u;
+}
+
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* wave_tot /*[4] LDS*/, int tid, uint32_t& total) {
   const int lane = tid & 63, w = tid >> 6;
   const uint32_t s = wave_inclusive_scan_u32(v);
@@ -1867,7 +1877,8 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
     GSR_STAMP2(0);
     uint32_t total;
     const uint32_t start0 = block_exclusive_scan(cnt_sum, red, tid, total);
-    const bool any_missing = __syncthreads_or((int)missing) != 0;
+    __shared__ uint32_t sAnyMissing[kSortThreads / 64];
+    const bool any_missing = block_any(missing, sAnyMissing);
     n = (int)total;
     // The tile's range of the index list: its own fixed slot of `stride` entries (no counter shared with other tiles), or -
     // a list longer than that - a run of the tail region behind the slots, taken from a bump counter.  The usual case
@@ -2018,7 +2029,8 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
   uint32_t start = block_exclusive_scan(span, red, tid, total);
 #pragma unroll
   for (int q = 0; q < kBpt; ++q) { cur[kBpt * tid + q] = start; start += c[q]; }
-  const bool big = __syncthreads_or(cmax > (uint32_t)kSpanMax) != 0;
+  __shared__ uint32_t sAnyBig[kSortThreads / 64];
+  const bool big = block_any(cmax > (uint32_t)kSpanMax, sAnyBig);
   GSR_STAMP(3);
   // scatter into bucket order
 #pragma unroll
@@ -2135,6 +2147,10 @@ struct BlendLds {
   // operands of two packed-fp32 instructions: [x x' y y'], [a2 a2' b2 b2'], [c2 c2' o o'], [r r' g g'], [b b' ex ex']
   float4 sXY[4][kFB / 2], sAB[4][kFB / 2], sCO[4][kFB / 2], sRG[4][kFB / 2], sBE[4][kFB / 2];
   float sP[2][kFwdWaves][64];  // segment products of batch b in sP[b & 1]
+};
+// the four waves' partial results on their way to wave 0 (blend_finish): used once, after the last batch - k_tile_fwd_prefix lays
+// it over its key array, which is dead by then (6 KB less: five workgroups per CU instead of four)
+struct BlendFin {
   float sPart[kFwdWaves][5][64];
   uint32_t sLast[kFwdWaves][64];
 };
@@ -2304,7 +2320,8 @@ template <bool kExtra>
 __device__ __forceinline__ bool blend_poisoned(const Params& p, const int v, const int pxi, const int pyi, const bool inside,
                                                const bool known = false) {
   // (the flag may be raised by another tile while this workgroup's waves read it: the decision is taken once for the workgroup)
-  if (!known && !__syncthreads_or((int)(p.status->overflow != 0u))) return false;
+  __shared__ uint32_t sAnyOverflow[kFwdThreads / 64];
+  if (!known && !block_any(p.status->overflow != 0u, sAnyOverflow)) return false;
   const Grid& g = p.g;
   if (threadIdx.x < 64 && inside) {
     const size_t HW = (size_t)g.H * g.W, pix = (size_t)pyi * g.W + pxi;
@@ -2320,7 +2337,7 @@ __device__ __forceinline__ bool blend_poisoned(const Params& p, const int v, con
 
 // The four waves' partial results -> the pixel: image, final transmittance, contributor count; the entries the tile walked.
 template <bool kExtra>
-__device__ __forceinline__ void blend_finish(const Params& p, const int v, const int t, const uint32_t n, BlendLds& lds, const BlendAcc& s,
+__device__ __forceinline__ void blend_finish(const Params& p, const int v, const int t, const uint32_t n, BlendFin& lds, const BlendAcc& s,
                                              const int pxi, const int pyi, const bool inside, const float bg0, const float bg1,
                                              const float bg2) {
   auto& sPart = lds.sPart; auto& sLast = lds.sLast;
@@ -2390,7 +2407,7 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
     o[0] = tm0; o[1] = ((unsigned long long)hw << 32); o[2] = __builtin_readcyclecounter();
     o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
   }
-  blend_finish<kExtra>(p, v, t, n, lds, acc, pxi, pyi, inside, bg0, bg1, bg2);
+  blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(&lds + 1), acc, pxi, pyi, inside, bg0, bg1, bg2);
 }
 
 // One launch per tile for both: the tile's sort (its gather latency under the blend arithmetic of the other tiles of the CU),
@@ -2398,7 +2415,7 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
 template <bool kGather, int kLds, bool kExtra>
 __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
   static_assert(kSortThreads == kFwdThreads, "one workgroup shape for the two phases");
-  constexpr int kSortWords = SortLds<kLds>::kWords, kBlendWords = (int)((sizeof(BlendLds) + 7) / 8);
+  constexpr int kSortWords = SortLds<kLds>::kWords, kBlendWords = (int)((sizeof(BlendLds) + sizeof(BlendFin) + 7) / 8);
   __shared__ __attribute__((aligned(16))) unsigned long long smem[kSortWords > kBlendWords ? kSortWords : kBlendWords];
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
@@ -2573,7 +2590,8 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
   lo = ~wave_max_u32(~lo);
   if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
   if (tid == 0) sInfo[3] = overflow_early;
-  const bool bad = __syncthreads_or((int)(miss || (has && !fits))) != 0;
+  __shared__ uint32_t sAnyBad[kSortThreads / 64];
+  const bool bad = block_any(miss || (has && !fits), sAnyBad);
   GSR_STAMP2(2);
   GSR_STAMP(1);
   uint32_t n = sCount, ranked = 0, obase = (uint32_t)tg * p.stride;
@@ -2631,7 +2649,8 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
       uint32_t start = block_exclusive_scan(span, red, tid, total);
 #pragma unroll
       for (int q = 0; q < kBpt; ++q) { cur[kBpt * tid + q] = start; start += c[q]; }
-      const bool big = __syncthreads_or(cmax > (uint32_t)kSpanMax) != 0;
+      __shared__ uint32_t sAnyBig2[kSortThreads / 64];
+      const bool big = block_any(cmax > (uint32_t)kSpanMax, sAnyBig2);
       GSR_STAMP(3);
       if (big) {  // degenerate depth distribution: the bitonic network on the same array, whole list
 #ifdef GSR_PREFIX_NOGENERAL
@@ -2684,7 +2703,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
 #ifdef GSR_PF_OLDBLEND  // (experiment: the one-range blend of k_tile_fwd behind the new gather / sort)
   rank_positions(ranked, n);
   __syncthreads();
-  blend_tile<kExtra>(p, v, t, make_uint2(obase, obase + n), blds);
+  blend_tile<kExtra>(p, v, t, make_uint2(obase, obase + n), *reinterpret_cast<BlendLds*>(smem));
   return;
 #endif
   // ---- blend: the ranked prefix (whole batches of it), then - only if some pixel is still open - the rest
@@ -2749,7 +2768,12 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
     o[0] = tm0; o[1] = ((unsigned long long)hw << 32); o[2] = __builtin_readcyclecounter();
     o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
   }
-  blend_finish<kExtra>(p, v, t, n, blds, acc, pxi, pyi, inside, bg0, bg1, bg2);
+#if GSR_PREFIX_ALIAS
+  blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(&blds + 1), acc, pxi, pyi, inside, bg0, bg1, bg2);
+#else
+  // (the keys are dead: their last reader is rank_positions, a barrier ago at least)
+  blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(smem), acc, pxi, pyi, inside, bg0, bg1, bg2);
+#endif
   report_length();
 #undef GSR_STAMP
 #undef GSR_STAMP2
