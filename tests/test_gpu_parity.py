@@ -319,6 +319,40 @@ def test_forward_is_deterministic_and_backward_nearly():
         assert d <= 1e-5 * np.abs(a["hip"]["grads"][k]).max(), k  # fp32 atomics: order-dependent rounding only
 
 
+@pytest.mark.parametrize("n, hw, extra", [(400, (40, 48), False), (20000, (128, 128), False), (60000, (256, 256), True)])
+def test_image_bits_do_not_depend_on_the_size_of_the_pair_workspace(n, hw, extra):
+    """The per-tile slot of the index list follows from the pair capacity, and the slot length selects the tile launch
+    (k_tile_fwd<., 2048, .> for short slots, k_tile_fwd_prefix for slots of 641 ... 2048 entries, k_tile_fwd<., 4096, .> above):
+    all of them blend with the same arithmetic in the same order, so a first call (sized by a guess) and the calls after it (sized
+    from the first one's statistics) return the same bits."""
+    from pf3plat_amd.rasterizer import HipBackend
+
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(7, n, hw)
+    ins = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
+    vb = synthetic.scene_viewbuf(sc).to(dev)
+    ex = torch.rand((1, n), generator=torch.Generator().manual_seed(1)).to(dev) if extra else None
+    cfg = RasterConfig(1, 1, 1, n, hw[0], hw[1], 4, 25, 4, extra)
+    be = HipBackend()
+    tiles = ((hw[0] + 7) // 8) * ((hw[1] + 7) // 8)
+    plan = be.make_plan(cfg, dev, capacity=8 * n)
+    be.run_forward(plan, vb, *ins, extra=ex)
+    fitted = be.capacity_for(cfg, be.read_status(plan), headroom=1.1)
+    images, strides = [], []
+    for cap in (fitted, fitted, 2 * tiles * 700, 2 * tiles * 2100):
+        plan = be.make_plan(cfg, dev, capacity=cap)
+        be.run_forward(plan, vb, *ins, extra=ex)
+        st = be.read_status(plan)
+        assert st["overflow"] == 0
+        images.append((plan["color"].cpu().numpy().copy(), plan["extra_img"].cpu().numpy().copy() if extra else None))
+        strides.append(int(plan["dims"].pair_capacity) // (2 * tiles))
+    assert strides[0] <= 640 < strides[2] <= 2048 < strides[3], strides  # three different tile launches
+    for img, eimg in images[1:]:
+        np.testing.assert_array_equal(img, images[0][0])
+        if extra:
+            np.testing.assert_array_equal(eimg, images[0][1])
+
+
 def test_lazy_status_policy_poisons_and_raises_on_late_overflow():
     """Default policy: status read synchronously only the first time a shape is seen, verified asynchronously afterwards.
     If the pair count then outgrows the 1.25x workspace, that call's image is NaN and the next check raises (never silent)."""
