@@ -2412,8 +2412,14 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
 
 // One launch per tile for both: the tile's sort (its gather latency under the blend arithmetic of the other tiles of the CU),
 // then - the index list written and a barrier later - its blend, over the same LDS.
+#ifndef GSR_TF_WAVES
+#define GSR_TF_WAVES 6
+#endif
+#ifndef GSR_WINDOWED_SHORT
+#define GSR_WINDOWED_SHORT 600  // pair capacity per tile up to which the windowed chain sorts with the 2048-key variant
+#endif
 template <bool kGather, int kLds, bool kExtra>
-__global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd(const Params p) {
+__global__ __launch_bounds__(kFwdThreads, (kLds == 2048 && kGather && !kExtra) ? GSR_TF_WAVES : 4) void k_tile_fwd(const Params p) {
   static_assert(kSortThreads == kFwdThreads, "one workgroup shape for the two phases");
   constexpr int kSortWords = SortLds<kLds>::kWords, kBlendWords = (int)((sizeof(BlendLds) + sizeof(BlendFin) + 7) / 8);
   __shared__ __attribute__((aligned(16))) unsigned long long smem[kSortWords > kBlendWords ? kSortWords : kBlendWords];
@@ -4222,7 +4228,12 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     else hipLaunchKernelGGL((k_tile_fwd<G, L, false>), tgrid, dim3(kFwdThreads), 0, st, p);              \
   } while (0)
     // every list that sits in its slot is at most `stride` long: a small slot means short lists, and the 2048-key variant
-    if (!fused_bin) GSR_TILES(false, 4096);
+    // (windowed chain: lists are contiguous ranges of any length; short ones on average - a large image - sort in the 2048-key
+    // variant, whose smaller LDS footprint lets six workgroups share a CU; a list longer than the LDS array sorts in memory either way)
+    if (!fused_bin) {
+      if (VT > 0 && (size_t)d.pair_capacity / VT <= (size_t)GSR_WINDOWED_SHORT) GSR_TILES(false, 2048);
+      else GSR_TILES(false, 4096);
+    }
     // the usual case (cursor gather + prefix rank): long lists.  A slot of at most kPrefix (+ 25 %) entries means lists that are
     // ranked whole anyway - many small tiles, e.g. one 1024 x 1024 view of the 300 k scene: 78 entries per tile - and those are
     // better off with k_tile_fwd's smaller LDS footprint (five workgroups per CU instead of four: 192 vs 217 us for that view)
