@@ -2167,7 +2167,7 @@ struct BlendAcc {
 
 // Batches [b0, nbat) of the list `plist` (entries at positions >= n read as null records), 256 threads.  Returns true when every
 // pixel's loop has stopped (workgroup-uniform: the decision is taken on bit-identical values in all four waves).
-template <bool kExtra>
+template <bool kExtra, bool kTight = false>  // kTight: an instance built for 80 registers (see put_records)
 __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* rgbc, const uint32_t* plist, const uint32_t n,
                                             const uint32_t b0, const uint32_t nbat, BlendLds& lds, BlendAcc& s, const float pxf,
                                             const float pyf) {
@@ -2251,7 +2251,11 @@ __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* r
   };
   auto put_records = [&](int sb, float4 q, float2 q2, const float4& c) {  // lane = entry of the batch
     q.z = (-0.5f * kLog2e) * q.z; q.w = (-kLog2e) * q.w; q2.x = (-0.5f * kLog2e) * q2.x;  // to_exp2_domain
-    const int o = (lane >> 1) * 4 + (lane & 1);
+    // (kTight: the offset formed here, from an opaque copy of the lane number, every time - held across the loops it was the one
+    // value the 80-register instance spilled, and its reload a trip to memory in every tile's blend prologue)
+    int ln = lane;
+    if (kTight) asm volatile("" : "+v"(ln));
+    const int o = (ln >> 1) * 4 + (ln & 1);
     float* xy = reinterpret_cast<float*>(sXY[sb]); float* ab = reinterpret_cast<float*>(sAB[sb]);
     float* co = reinterpret_cast<float*>(sCO[sb]); float* rg2 = reinterpret_cast<float*>(sRG[sb]);
     float* be = reinterpret_cast<float*>(sBE[sb]);
@@ -2270,8 +2274,11 @@ __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* r
     float4 sg = make_float4(0, 0, 0, 0), sc = sg;
     float2 sg2 = make_float2(0, 0);
     uint32_t id_next = 0;
-    const auto list_id = [&](uint32_t b) { return (b * kFB + lane < n) ? plist[b * kFB + lane] : 0u; };
-    if (lane < kFB) {
+    // (kTight: the lane number from an opaque copy where the prologue needs it, so that it does not occupy a register across the loop)
+    int lp = lane;
+    if (kTight) asm volatile("" : "+v"(lp));
+    const auto list_id = [&](uint32_t b) { return (b * kFB + lp < n) ? plist[b * kFB + lp] : 0u; };
+    if (lp < kFB) {
       const uint32_t w = (uint32_t)(wave - (int)b0) & 3u, bw = b0 + w;
       if (w < 2) {
         const uint32_t id0 = list_id(bw), id4 = list_id(bw + 4);
@@ -2492,19 +2499,36 @@ GSR_COLD __device__ void bitonic_whole_list(unsigned long long* sk, uint32_t* ou
   for (int k = threadIdx.x; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
 }
 
-template <bool kExtra>
-__global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params p) {
+#ifndef GSR_PF_COMPACT
+#define GSR_PF_COMPACT 1  // 0: measurement builds without the compact instance
+#endif
+#ifndef GSR_PF_COMPACT_EXTRA
+#define GSR_PF_COMPACT_EXTRA 0
+#endif
+// kCompact (calls with more tiles than the chip holds at once: many views): 1024 depth buckets instead of 2048, their counters /
+// cursors packed two to a 32-bit word (a cursor is at most 2048: sixteen bits; the LDS atomic adds 1 or 1 << 16) - 25.7 KB of LDS
+// instead of 31.9, and the instance is built for six waves per SIMD (80 VGPRs): SIX workgroups per CU instead of five.  The single
+// view (1024 tiles = four per CU) has nothing to gain from that and keeps its instance untouched.
+template <bool kExtra, bool kCompact>
+__global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_prefix(const Params p) {
   constexpr int kLds = 2048;
-  constexpr int kBk = SortLds<kLds>::kBuckets, kBkBits = SortLds<kLds>::kBucketBits, kBpt = kBk / kSortThreads;
+  constexpr int kBk = kCompact ? 1024 : SortLds<kLds>::kBuckets, kBkBits = kCompact ? 10 : SortLds<kLds>::kBucketBits, kBpt = kBk / kSortThreads;
   constexpr int Q = kLds / kSortThreads;
-  __shared__ __attribute__((aligned(16))) unsigned long long smem[SortLds<kLds>::kWords];  // keys | bucket counters, then cursors
 #ifndef GSR_PREFIX_ALIAS
 #define GSR_PREFIX_ALIAS 0  // 1 (measurement): the blend's area over the keys as in k_tile_fwd, every list ranked to its end
 #endif
+  // keys | bucket counters, then cursors | (kCompact) the blend's area - one array, so that the general path (sort_tile: 24 KB from
+  // the start, its blend over its dead keys) finds its room in it
+  constexpr int kCounterWords = kCompact ? kBk / 4 : kBk / 2;  // 8-byte words
+  constexpr int kBlendWordsP = (int)((sizeof(BlendLds) + 7) / 8);
+  constexpr int kFastWords = kLds + kCounterWords + ((kCompact && !GSR_PREFIX_ALIAS) ? kBlendWordsP : 0);
+  __shared__ __attribute__((aligned(16))) unsigned long long smem[kFastWords > SortLds<kLds>::kWords ? kFastWords : SortLds<kLds>::kWords];
 #if GSR_PREFIX_ALIAS
   BlendLds& blds = *reinterpret_cast<BlendLds*>(smem);
 #else
-  __shared__ __attribute__((aligned(16))) BlendLds blds;  // NOT over the keys: a tile may come back to rank the rest of its list
+  // NOT over the keys: a tile may come back to rank the rest of its list
+  __shared__ __attribute__((aligned(16))) unsigned long long blds_own[kCompact ? 2 : kBlendWordsP];
+  BlendLds& blds = *reinterpret_cast<BlendLds*>(kCompact ? smem + kLds + kCounterWords : blds_own);
 #endif
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
@@ -2521,6 +2545,13 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
   unsigned long long* sk = smem;
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kLds);
   uint32_t* cur = hist;
+  // bucket b's counter / cursor: a word of its own, or (kCompact) half of word b >> 1
+  auto bump = [&](uint32_t b) -> uint32_t {  // returns the value before
+    if (!kCompact) return atomicAdd(&cur[b], 1u);
+    const uint32_t sh = (b & 1u) * 16u;
+    return (atomicAdd(&cur[b >> 1], 1u << sh) >> sh) & 0xffffu;
+  };
+  auto cur_of = [&](uint32_t b) -> uint32_t { return kCompact ? (cur[b >> 1] >> ((b & 1u) * 16u)) & 0xffffu : cur[b]; };
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
   unsigned long long* stamp = dbg_stamps(p, 8192 + bid);
   unsigned long long* stamp2 = dbg_stamps(p, 8192 + p.sort_blocks + bid);
@@ -2545,7 +2576,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
     e0 = p.pair_mat[((size_t)v * R + tid) * ((size_t)T + 8) + t];
     bb0 = p.blk_base[(size_t)v * R + tid];
   }
-  for (int k = tid; k < kBk; k += kSortThreads) hist[k] = 0;  // (while the column is on its way)
+  for (int k = tid; k < (kCompact ? kBk / 2 : kBk); k += kSortThreads) hist[k] = 0;  // (while the column is on its way)
   if (tid == 0) sCount = 0;
   __syncthreads();
   GSR_STAMP2(0);
@@ -2636,13 +2667,13 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < Q; ++q)
-        if (tid + q * kSortThreads < (int)n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - dlo) >> shift], 1u);
+        if (tid + q * kSortThreads < (int)n) (void)bump(((uint32_t)(kreg[q] >> 32) - dlo) >> shift);
 #else
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int k = tid + q * kSortThreads;
         kreg[q] = (k < (int)n) ? sk[k] : ~0ull;
-        if (k < (int)n) atomicAdd(&hist[((uint32_t)(kreg[q] >> 32) - dlo) >> shift], 1u);
+        if (k < (int)n) (void)bump(((uint32_t)(kreg[q] >> 32) - dlo) >> shift);
       }
 #endif
       __syncthreads();
@@ -2650,11 +2681,20 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
       // exclusive scan of the bucket counts: thread t owns kBpt consecutive buckets
       uint32_t c[kBpt], span = 0, cmax = 0;
 #pragma unroll
-      for (int q = 0; q < kBpt; ++q) { c[q] = hist[kBpt * tid + q]; span += c[q]; cmax = max(cmax, c[q]); }
+      for (int q = 0; q < kBpt; ++q) { c[q] = cur_of((uint32_t)(kBpt * tid + q)); span += c[q]; cmax = max(cmax, c[q]); }
       uint32_t total;
       uint32_t start = block_exclusive_scan(span, red, tid, total);
+      if (kCompact) {  // (a thread's kBpt buckets are whole words; nobody else touches them between the two barriers)
 #pragma unroll
-      for (int q = 0; q < kBpt; ++q) { cur[kBpt * tid + q] = start; start += c[q]; }
+        for (int q = 0; q < kBpt; q += 2) {
+          const uint32_t s0 = start, s1 = start + c[q];
+          cur[(kBpt * tid + q) >> 1] = s0 | (s1 << 16);
+          start = s1 + c[q + 1];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kBpt; ++q) { cur[kBpt * tid + q] = start; start += c[q]; }
+      }
       __shared__ uint32_t sAnyBig2[kSortThreads / 64];
       const bool big = block_any(cmax > (uint32_t)kSpanMax, sAnyBig2);
       GSR_STAMP(3);
@@ -2670,7 +2710,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
 #pragma unroll
         for (int q = 0; q < Q; ++q)
           if (tid + q * kSortThreads < (int)n) {
-            const uint32_t slot = atomicAdd(&cur[((uint32_t)(kreg[q] >> 32) - dlo) >> shift], 1u);
+            const uint32_t slot = bump(((uint32_t)(kreg[q] >> 32) - dlo) >> shift);
             sk[slot] = kreg[q];
           }
         __syncthreads();
@@ -2678,7 +2718,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
         // after the scatter cur[b] is the END of bucket b.  Rank the buckets that reach into the first kPrefix positions
         ranked = n;
         if (!GSR_PREFIX_ALIAS && !(p.d.flags & GSR_FLAG_FULL_LISTS) && n > (uint32_t)(kPrefix + kPrefix / 4))
-          ranked = cur[((uint32_t)(sk[kPrefix - 1] >> 32) - dlo) >> shift];
+          ranked = cur_of(((uint32_t)(sk[kPrefix - 1] >> 32) - dlo) >> shift);
         bucketed = true;
       }
     }
@@ -2690,7 +2730,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
     for (int k = (int)k0 + tid; k < (int)k1; k += kSortThreads) {
       const unsigned long long key = sk[k];
       const uint32_t b = ((uint32_t)(key >> 32) - dlo) >> shift;
-      const int bs = b ? (int)cur[b - 1] : 0, be = (int)cur[b];
+      const int bs = b ? (int)cur_of(b - 1) : 0, be = (int)cur_of(b);
       int rank = bs;
       for (int j = bs; j < be; j += 4) {
         const unsigned long long k0_ = sk[j], k1_ = sk[min(j + 1, be - 1)], k2_ = sk[min(j + 2, be - 1)], k3_ = sk[min(j + 3, be - 1)];
@@ -2757,7 +2797,7 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
     // pass 0: the whole batches inside the ranked prefix (all of the list when everything was ranked); pass 1: from there to the end
     const bool whole = ranked >= n;
     const uint32_t b1 = whole ? nbat : ranked / kFB;
-    bool done = blend_range<kExtra>(geom, rgbc, plist, whole ? n : b1 * kFB, b0, b1, blds, acc, (float)pxi, (float)pyi);
+    bool done = blend_range<kExtra, kCompact>(geom, rgbc, plist, whole ? n : b1 * kFB, b0, b1, blds, acc, (float)pxi, (float)pyi);
     done = done || whole || __all(acc.Tb < 0.0001f);  // (Tb: the same bits in all four waves)
     if (done) break;
     if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(GSR_SORT_PRIO);
@@ -2778,7 +2818,14 @@ __global__ __launch_bounds__(kFwdThreads, 4) void k_tile_fwd_prefix(const Params
   blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(&blds + 1), acc, pxi, pyi, inside, bg0, bg1, bg2);
 #else
   // (the keys are dead: their last reader is rank_positions, a barrier ago at least)
-  blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(smem), acc, pxi, pyi, inside, bg0, bg1, bg2);
+  if (kCompact) {  // the pixel's coordinates formed again (opaque lane number) instead of held across the loops: 80 registers
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    const int qx = tx * 8 + (ln & 7), qy = ty * 8 + (ln >> 3);
+    blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(smem), acc, qx, qy, qx < g.W && qy < g.H, bg0, bg1, bg2);
+  } else {
+    blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(smem), acc, pxi, pyi, inside, bg0, bg1, bg2);
+  }
 #endif
   report_length();
 #undef GSR_STAMP
@@ -4238,8 +4285,14 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     // ranked whole anyway - many small tiles, e.g. one 1024 x 1024 view of the 300 k scene: 78 entries per tile - and those are
     // better off with k_tile_fwd's smaller LDS footprint (five workgroups per CU instead of four: 192 vs 217 us for that view)
     else if (p.stride <= 2048u && p.stride > (uint32_t)(kPrefix + kPrefix / 4) && p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {
-      if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true>), tgrid, dim3(kFwdThreads), 0, st, p);
-      else hipLaunchKernelGGL((k_tile_fwd_prefix<false>), tgrid, dim3(kFwdThreads), 0, st, p);
+      // (more tiles than five workgroups per CU hold at once: the compact instance, six per CU; with the extra channel it would spill)
+#if GSR_PF_COMPACT_EXTRA  // (measured: at 80 registers the instance with the extra channel spills the record in flight, 20 B - 48 views 27.7 vs 24.7 us per view)
+      if (d.has_extra && VT > (size_t)(5 * kCUs)) hipLaunchKernelGGL((k_tile_fwd_prefix<true, true>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else
+#endif
+      if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true, false>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else if (VT > (size_t)(5 * kCUs) && GSR_PF_COMPACT) hipLaunchKernelGGL((k_tile_fwd_prefix<false, true>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else hipLaunchKernelGGL((k_tile_fwd_prefix<false, false>), tgrid, dim3(kFwdThreads), 0, st, p);
     } else if (p.stride <= 2048u) GSR_TILES(true, 2048);
     else GSR_TILES(true, 4096);
 #undef GSR_TILES

@@ -152,6 +152,13 @@ def test_config2_batched_8_jittered_views_one_launch_chain():
     assert res["hip"]["status"]["num_pairs"] > 8 * 1_000_000
 
 
+def test_two_views_300k_without_the_extra_channel_take_the_compact_tile_instance_fwd_bwd():
+    """More tiles than five workgroups per CU hold (2 x 1024 > 1280), long lists, no extra channel: k_tile_fwd_prefix<false, true> -
+    1024 depth buckets with 16-bit cursors packed two to a word, six workgroups per CU; forward, lists, saved state and gradients."""
+    cfg, res = _scene_case(2, 300000, (256, 256), views=2, with_extra=False, view_offsets=[-0.03, 0.04])
+    _all_checks(cfg, res, max_tiles=48, strict=True)
+
+
 def test_config4_full_size_131072_gaussians_3_views_colour_and_depth():
     """BASELINE configs[3] at its real size through the C ABI: one scene of G = 2 x 256 x 256 Gaussians, K = 25, three
     target views sharing the set, colour + built-in depth channel in one pass (the <extra> variants of both blend kernels),
