@@ -2502,6 +2502,9 @@ GSR_COLD __device__ void bitonic_whole_list(unsigned long long* sk, uint32_t* ou
 #ifndef GSR_PF_COMPACT
 #define GSR_PF_COMPACT 1  // 0: measurement builds without the compact instance
 #endif
+#ifndef GSR_PF_COMPACT_MIN_TILES
+#define GSR_PF_COMPACT_MIN_TILES (5 * kCUs)  // calls with more tiles than this take the compact instance
+#endif
 #ifndef GSR_PF_COMPACT_EXTRA
 #define GSR_PF_COMPACT_EXTRA 0
 #endif
@@ -4291,7 +4294,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
       else
 #endif
       if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true, false>), tgrid, dim3(kFwdThreads), 0, st, p);
-      else if (VT > (size_t)(5 * kCUs) && GSR_PF_COMPACT) hipLaunchKernelGGL((k_tile_fwd_prefix<false, true>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else if (VT > (size_t)GSR_PF_COMPACT_MIN_TILES && GSR_PF_COMPACT) hipLaunchKernelGGL((k_tile_fwd_prefix<false, true>), tgrid, dim3(kFwdThreads), 0, st, p);
       else hipLaunchKernelGGL((k_tile_fwd_prefix<false, false>), tgrid, dim3(kFwdThreads), 0, st, p);
     } else if (p.stride <= 2048u) GSR_TILES(true, 2048);
     else GSR_TILES(true, 4096);
