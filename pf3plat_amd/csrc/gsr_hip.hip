@@ -1154,8 +1154,18 @@ constexpr size_t bin_lds_bytes(int T, bool color) {
   return color ? (size_t)kBinStageBytes + (((size_t)T * 4 + 15) & ~(size_t)15) + (size_t)kBinColorBufs * kColorLdsFloats * 4
                : (size_t)(kBinThreads / 64) * 4096 + (size_t)T * 4;
 }
-template <bool kColor, bool kJ>
-__global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) {
+// kMaxT: most tiles of the image the instance is built for.  The plain launch (no colour waves) of an image of at most
+// kBinTwoMaxT tiles needs 78-80 KB of LDS, so TWO of its workgroups fit a CU - if they also fit its registers: that instance is
+// built for eight waves per SIMD (64 VGPRs; with the per-thread tile counters sized for its own image it does not spill), and the
+// VALU-bound launch (0.20 of 0.25 at one workgroup per CU) runs 15 % faster: 8 views 39.1 -> 37.3 us per view, 48 views 23.3 -> 22.2.
+// Larger images have room for one workgroup per CU whatever the registers: the 85-register instance (at 64 it spills: one
+// 1024 x 1024 view 182 -> 201 us).
+#ifndef GSR_BIN_TWO
+#define GSR_BIN_TWO 1  // 0: measurement builds without the two-per-CU instance
+#endif
+constexpr int kBinTwoMaxT = 2048;
+template <bool kColor, bool kJ, int kMaxT = kFusedMaxTiles>
+__global__ __launch_bounds__(kBinThreads, (!kColor && kMaxT == kBinTwoMaxT) ? 8 : 4) void k_preprocess_bin(const Params p) {
   extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters;
                                          // then (kColor) one 19 200-byte unit buffer per colour wave
   uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + (kColor ? kBinStageBytes / 16 : (kBinThreads / 64) * 256));
@@ -1368,11 +1378,11 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   __syncthreads();
   GSR_STAMP(1);
   // ---- 2. exclusive scan of the histogram over the tiles (thread t owns `per` consecutive tiles)
-  const int per = (T + kBinThreads - 1) / kBinThreads;  // <= kFusedMaxTiles / kBinThreads
+  const int per = (T + kBinThreads - 1) / kBinThreads;  // <= kMaxT / kBinThreads
   const int b0 = tid * per;
-  uint32_t cnt[kFusedMaxTiles / kBinThreads], sum = 0;
+  uint32_t cnt[kMaxT / kBinThreads], sum = 0;
 #pragma unroll
-  for (int q = 0; q < kFusedMaxTiles / kBinThreads; ++q) {
+  for (int q = 0; q < kMaxT / kBinThreads; ++q) {
     cnt[q] = (q < per && b0 + q < T) ? hist[b0 + q] : 0u;
     sum += cnt[q];
   }
@@ -1402,7 +1412,7 @@ __global__ __launch_bounds__(kBinThreads) void k_preprocess_bin(const Params p) 
   uint2* mrow = p.pair_mat + ((size_t)v * p.rows + row) * (T + 8);  // + 8: a column must not sit on one memory channel
   uint32_t run = basew + incl - sum;
 #pragma unroll
-  for (int q = 0; q < kFusedMaxTiles / kBinThreads; ++q)
+  for (int q = 0; q < kMaxT / kBinThreads; ++q)
     if (q < per && b0 + q < T) {
       mrow[b0 + q] = make_uint2(run, cnt[q]);
       hist[b0 + q] = run;  // from here on: the tile's cursor inside the region
@@ -1533,43 +1543,58 @@ __global__ __launch_bounds__(1024) void k_tile_prefix(const Params p) {
   }
 }
 
+// One workgroup per 1024 consecutive (view, tile) totals.  Every workgroup reads ALL the totals once, coalesced (at most a few
+// hundred KB out of L2) and so knows the grand total - which decides the overflow flag every range depends on - and the sum in
+// front of its own chunk without waiting for anybody; then an exclusive scan of its chunk.  (Until round 4 this was ONE
+// workgroup whose threads each walked 64 consecutive totals - uncoalesced - twice: 115 us for the 65 536 tiles of a 2048 x 2048
+// image, a fifth of that call.)
 __global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
-  __shared__ unsigned long long part[1024];
-  __shared__ uint32_t smax;
-  const int tid = threadIdx.x;
+  __shared__ unsigned long long sTot[16], sBefore[16], sScan[16];
+  __shared__ uint32_t sMax[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t n = (size_t)p.d.num_views * p.g.T;
-  const size_t per = (n + 1023) / 1024;
-  const size_t b = (size_t)tid * per, e = b + per < n ? b + per : n;
-  if (tid == 0) smax = 0;
-  unsigned long long sum = 0;
+  const size_t c0 = (size_t)blockIdx.x * 1024;  // this workgroup's chunk: [c0, c0 + 1024)
+  unsigned long long tot = 0, before = 0;
   uint32_t mx = 0;
-  for (size_t k = b; k < e; ++k) {
+  for (size_t k = tid; k < n; k += 1024) {
     const uint32_t t = p.tile_total[k];
-    sum += t;
+    tot += t;
+    before += k < c0 ? t : 0u;
     mx = t > mx ? t : mx;
   }
-  part[tid] = sum;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const unsigned long long t = tid >= o ? part[tid - o] : 0ull;
-    __syncthreads();
-    part[tid] += t;
-    __syncthreads();
+  for (int o = 32; o > 0; o >>= 1) {
+    tot += __shfl_down(tot, o, 64);
+    before += __shfl_down(before, o, 64);
+    mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
   }
-  atomicMax(&smax, mx);
-  const unsigned long long total = part[1023];
+  const size_t k = c0 + tid;
+  const uint32_t mine = k < n ? p.tile_total[k] : 0u;
+  // inclusive scan of the chunk inside the wave (64-bit: a chunk of long lists can pass 2^32 only in theory, the total can)
+  unsigned long long incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, 64);
+    if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
+  }
+  if (lane == 0) { sTot[w] = tot; sBefore[w] = before; sMax[w] = mx; }
+  if (lane == 63) sScan[w] = incl;
+  __syncthreads();
+  unsigned long long total = 0, run = 0;
+  uint32_t gmax = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    total += sTot[q];
+    run += sBefore[q];
+    run += q < w ? sScan[q] : 0ull;
+    gmax = max(gmax, sMax[q]);
+  }
   const bool overflow = total > (unsigned long long)p.d.pair_capacity;
-  unsigned long long run = part[tid] - sum;
-  for (size_t k = b; k < e; ++k) {
-    const uint32_t t = p.tile_total[k];
-    p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + t));
-    run += t;
-  }
-  __syncthreads();
-  if (tid == 0) {
+  run += incl - mine;
+  if (k < n) p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + mine));
+  if (blockIdx.x == 0 && tid == 0) {
     p.status->num_pairs = total;
     p.status->overflow = overflow ? 1u : 0u;
-    p.status->max_list = smax;
+    p.status->max_list = gmax;
   }
 }
 
@@ -4098,6 +4123,8 @@ static int ensure_bin_attributes(int* dev_out) {
   if (g_lds_set.load(std::memory_order_acquire) & bit) return GSR_OK;
   const int plain = (int)bin_lds_bytes(kFusedMaxTiles, false), with_color = 160 * 1024 - 10400;
   GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, plain));
+  GSR_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<false, false, kBinTwoMaxT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)bin_lds_bytes(kBinTwoMaxT, false)));
   const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess &&
                   hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess;
   if (ok) g_color_bin_ok.fetch_or(bit, std::memory_order_relaxed);
@@ -4247,7 +4274,10 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
   if (fused_bin) {
     const dim3 bgrid((unsigned)p.rows, (unsigned)V);
     const size_t shmem = bin_lds_bytes(p.g.T, color_in_bin);
-    if (!color_in_bin) hipLaunchKernelGGL((k_preprocess_bin<false, false>), bgrid, dim3(kBinThreads), shmem, st, p);
+    // (two plain workgroups per CU where the image's tile counters leave the LDS for it: LDS comes in 1280-byte steps)
+    const bool two_per_cu = GSR_BIN_TWO && p.g.T <= kBinTwoMaxT && 2 * align_up(shmem + 10400, 1280) <= (size_t)160 * 1024;
+    if (!color_in_bin && two_per_cu) hipLaunchKernelGGL((k_preprocess_bin<false, false, kBinTwoMaxT>), bgrid, dim3(kBinThreads), shmem, st, p);
+    else if (!color_in_bin) hipLaunchKernelGGL((k_preprocess_bin<false, false>), bgrid, dim3(kBinThreads), shmem, st, p);
     else if (p.shj) hipLaunchKernelGGL((k_preprocess_bin<true, true>), bgrid, dim3(kBinThreads), shmem, st, p);
     else hipLaunchKernelGGL((k_preprocess_bin<true, false>), bgrid, dim3(kBinThreads), shmem, st, p);
   } else {
@@ -4260,7 +4290,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 15) / 16)), dim3(1024), 0, st, p);
   }
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
-  if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, p);
+  if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((VT + 1023) / 1024)), dim3(1024), 0, st, p);
   GSR_STAGE_DONE(2);
   GSR_MARK();
   if (!fused_bin) {
