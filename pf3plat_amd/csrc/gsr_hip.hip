@@ -1491,7 +1491,10 @@ __global__ __launch_bounds__(kBinThreads) void k_count(const Params p) {
 // segment of every row), so a 1024-tile image spreads over 64 workgroups; a thread keeps its <= kPrefixRegs rows in
 // registers between the sum and the write-back (one trip to memory), partial sums are exchanged through LDS.
 constexpr int kPrefixRegs = 8;
-__global__ __launch_bounds__(1024) void k_tile_prefix(const Params p) {
+#ifndef GSR_TP_WAVES
+#define GSR_TP_WAVES 8
+#endif
+__global__ __launch_bounds__(1024, GSR_TP_WAVES) void k_tile_prefix(const Params p) {
   __shared__ uint32_t part[64][17];
   const int cx = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const size_t VT = (size_t)p.d.num_views * p.g.T;
