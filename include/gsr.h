@@ -289,6 +289,11 @@ int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float*
 size_t gsr_image_loss_partials(int num_images, int height, int width);
 int gsr_image_loss(int num_images, int height, int width, const float* prediction, const float* target, float mse_weight,
                    float ssim_weight, float* dL_dprediction, float* partials, void* stream);
+/* The slots of gsr_image_loss added up on the device, in a fixed order (one more launch instead of the caller's reductions):
+ * sums (num_images, 4) - per image the three sums and a 0 - and totals[0..2] = L as defined above, mean squared error, mean SSIM
+ * over the batch (`totals`: four floats, the fourth 0).  One workgroup, no atomics: the same bits every time. */
+int gsr_image_loss_finish(int num_images, int height, int width, const float* partials, float mse_weight, float ssim_weight,
+                          float* sums, float* totals, void* stream);
 
 /* Measurement aids for bench.py (never on the product path): the same launch chains with a HIP event recorded on
  * `stream` between stages; they synchronise the stream and return per-stage milliseconds.

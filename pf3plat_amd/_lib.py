@@ -133,6 +133,8 @@ def load():
     lib.gsr_image_loss_partials.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     lib.gsr_image_loss.restype = ctypes.c_int
     lib.gsr_image_loss.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
+    lib.gsr_image_loss_finish.restype = ctypes.c_int
+    lib.gsr_image_loss_finish.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_float, ctypes.c_float, vp, vp, vp]
     lib.gsr_pack_view.restype = ctypes.c_int
     lib.gsr_pack_view.argtypes = [vp, vp, vp, ctypes.c_int, vp, ctypes.c_float, ctypes.c_float, vp, vp, ctypes.c_float, vp, vp]
     lib.gsr_mark_visible.restype = ctypes.c_int
@@ -159,7 +161,7 @@ EXPORTED_SYMBOLS = (
     "gsr_backward", "gsr_mark_visible", "gsr_forward_profile", "gsr_backward_profile", "gsr_setup_views",
     "gsr_capacity_for", "gsr_cov_from_scale_rot", "gsr_cov_from_scale_rot_backward", "gsr_last_failed_stage",
     "gsr_colour_in_binning", "gsr_geom_layout", "gsr_backward_ex", "gsr_pose_partials_bytes", "gsr_backward_scratch_bytes", "gsr_setup_views_orthographic", "gsr_forward_scale_rot", "gsr_backward_scale_rot",
-    "gsr_image_loss", "gsr_image_loss_partials", "gsr_pack_view", "gsr_setup_views_backward",
+    "gsr_image_loss", "gsr_image_loss_partials", "gsr_image_loss_finish", "gsr_pack_view", "gsr_setup_views_backward",
 )
 # gsr_forward_profile's stages.  On images of up to 20 480 tiles (the fused binning path) "preprocess" is the whole binning
 # kernel and "count_scan" / "emit" have no launch (their entries are one empty event gap each).

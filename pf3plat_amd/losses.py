@@ -6,7 +6,6 @@ exists) instead of five depthwise convolutions and their transposes.  No CPU fal
 """
 from __future__ import annotations
 
-import ctypes
 from dataclasses import dataclass
 from typing import Optional
 
@@ -14,39 +13,53 @@ import torch
 from torch import Tensor
 
 from . import _lib
+from .rasterizer import _on_device, _stream_ptr
 
 
 def _launch(prediction: Tensor, target: Tensor, mse_weight: float, ssim_weight: float, want_grad: bool):
+    """-> (sums (n, 4): per image squared error, clipped squared error, SSIM map, 0; totals (4,): loss, mse, mean ssim, 0;
+    dL/dprediction or None; elements per image).  Two launches (gsr_image_loss, gsr_image_loss_finish), no torch op."""
     if not (prediction.is_cuda and target.is_cuda):
         raise RuntimeError("pf3plat_amd losses: tensors must be on a ROCm device (there is no CPU fallback path)")
     if prediction.shape != target.shape or prediction.dim() != 4 or prediction.shape[1] != 3:
         raise ValueError(f"expected two (n, 3, h, w) images, got {tuple(prediction.shape)} and {tuple(target.shape)}")
     lib = _lib.load()
-    pred, tgt = prediction.detach().to(torch.float32).contiguous(), target.detach().to(torch.float32).contiguous()
+    f32 = torch.float32
+    pred = prediction.detach()
+    tgt = target.detach()
+    if pred.dtype != f32 or not pred.is_contiguous():
+        pred = pred.to(f32).contiguous()
+    if tgt.dtype != f32 or not tgt.is_contiguous():
+        tgt = tgt.to(f32).contiguous()
     n, _, h, w = pred.shape
+    dev = pred.device
+    if n == 0:
+        z = torch.zeros((1, 4), dtype=f32, device=dev)
+        return z[:0], z[0], (torch.empty_like(pred) if want_grad else None), 3 * h * w
     slots = int(lib.gsr_image_loss_partials(n, h, w))
-    partials = torch.empty((n, max(slots // max(n, 1), 1), 4), dtype=torch.float32, device=pred.device)
+    partials = torch.empty((slots, 4), dtype=f32, device=dev)
+    out = torch.empty((n + 1, 4), dtype=f32, device=dev)  # the images' sums, then the batch's totals
     grad = torch.empty_like(pred) if want_grad else None
-    ptr = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
-    with torch.cuda.device(pred.device):
-        rc = lib.gsr_image_loss(n, h, w, ptr(pred), ptr(tgt), float(mse_weight), float(ssim_weight), ptr(grad), ptr(partials),
-                                ctypes.c_void_p(torch.cuda.current_stream(pred.device).cuda_stream))
+    stream = _stream_ptr(dev)
+    pp = partials.data_ptr()
+    with _on_device(dev):
+        rc = lib.gsr_image_loss(n, h, w, pred.data_ptr(), tgt.data_ptr(), float(mse_weight), float(ssim_weight),
+                                None if grad is None else grad.data_ptr(), pp, stream)
+        if rc == 0:
+            rc = lib.gsr_image_loss_finish(n, h, w, pp, float(mse_weight), float(ssim_weight), out.data_ptr(), out[n].data_ptr(), stream)
     if rc != 0:
         raise RuntimeError(f"gsr_image_loss failed with code {rc}")
-    sums = partials.sum(dim=1)  # (n, 4): squared error, clipped squared error, SSIM map, -
-    return sums, grad, 3 * h * w
+    return out[:n], out[n], grad, 3 * h * w
 
 
 class _Photometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, prediction, target, mse_weight, ssim_weight):
-        sums, grad, per_image = _launch(prediction, target, mse_weight, ssim_weight, prediction.requires_grad)
-        count = prediction.shape[0] * per_image
-        mse = sums[:, 0].sum() / count
-        ssim = sums[:, 2].sum() / count
+        _sums, totals, grad, _per_image = _launch(prediction, target, mse_weight, ssim_weight, prediction.requires_grad)
         ctx.grad = grad
+        loss, mse, ssim = totals[0], totals[1], totals[2]
         ctx.mark_non_differentiable(mse, ssim)
-        return mse_weight * mse + ssim_weight * (1 - ssim), mse, ssim
+        return loss, mse, ssim
 
     @staticmethod
     def backward(ctx, g_loss, _g_mse, _g_ssim):
@@ -67,7 +80,7 @@ def ssim(img1: Tensor, img2: Tensor) -> Tensor:
 @torch.no_grad()
 def compute_psnr(ground_truth: Tensor, predicted: Tensor) -> Tensor:
     """(batch, 3, h, w) x 2 -> (batch,): -10 log10 of the mean squared error of the inputs clipped to [0, 1]."""
-    sums, _, per_image = _launch(predicted, ground_truth, 0.0, 0.0, False)
+    sums, _totals, _, per_image = _launch(predicted, ground_truth, 0.0, 0.0, False)
     return -10 * (sums[:, 1] / per_image).log10()
 
 
