@@ -4631,24 +4631,22 @@ int gsr_cov_from_scale_rot_backward(int64_t n, const float* scales, const float*
 namespace gsr {
 constexpr int kLossTile = 16, kLossR = 5, kLossMid = kLossTile + 2 * kLossR, kLossIn = kLossTile + 4 * kLossR;  // 16, 26, 36
 
+// LDS planes, row strides multiples of four floats so that a thread reads the 14 inputs of FOUR adjacent outputs of an 11-tap pass
+// as four 16-byte words (the first form read every tap as a float of its own: 80 k LDS reads per workgroup, 33 us for three
+// 256 x 256 images): inputs 36 x 40 (two planes), first horizontal pass 36 x 28 (five planes), a / b / dmu 26 x 28 (three planes,
+// over the inputs - dead by then, a thread keeps its own pixel's two values), second horizontal pass 26 x 16 (three planes, over
+// the first one's).  31.7 KB: five workgroups per CU.
+constexpr int kLossXS = 40, kLossHS = 28, kLossBS = 16;
 __global__ __launch_bounds__(256) void k_image_loss(int H, int W, const float* __restrict__ pred, const float* __restrict__ target,
                                                     float mse_scale, float ssim_scale, float* __restrict__ grad, float* __restrict__ partials) {
-  // 30 KB instead of 44 (five workgroups per CU instead of three): the inputs are dead once their horizontal pass is done (a
-  // thread keeps its own pixel's two values in registers) and a / b / dmu take their place; the horizontal pass of those three
-  // takes the place of the first one's five planes, dead after the vertical pass.
-  typedef float XPlane[kLossIn][kLossIn + 1];
-  typedef float MPlane[kLossMid][kLossMid + 1];
-  typedef float HPlane[kLossIn][kLossMid + 1];
-  typedef float BPlane[kLossMid][kLossTile + 1];
-  static_assert(3 * sizeof(MPlane) <= 2 * sizeof(XPlane) && 3 * sizeof(BPlane) <= 5 * sizeof(HPlane), "aliased planes fit");
-  __shared__ __attribute__((aligned(16))) float sX[2 * sizeof(XPlane) / sizeof(float)];
-  __shared__ __attribute__((aligned(16))) float sH[5 * sizeof(HPlane) / sizeof(float)];
-  XPlane* xin = reinterpret_cast<XPlane*>(sX);
-  XPlane& x1 = xin[0];
-  XPlane& x2 = xin[1];
-  HPlane* hz = reinterpret_cast<HPlane*>(sH);   // horizontal pass of x1, x2, x1^2, x2^2, x1 x2 (rows: 36, columns: 26)
-  MPlane* mp = reinterpret_cast<MPlane*>(sX);   // a, b, dmu on the 26 x 26 region (over the inputs)
-  BPlane* hb = reinterpret_cast<BPlane*>(sH);   // their horizontal pass (rows: 26, columns: 16; over hz)
+  __shared__ __attribute__((aligned(16))) float sX[2 * kLossIn * kLossXS];
+  __shared__ __attribute__((aligned(16))) float sH[5 * kLossIn * kLossHS];
+  static_assert(3 * kLossMid * kLossHS <= 2 * kLossIn * kLossXS && 3 * kLossMid * kLossBS <= 5 * kLossIn * kLossHS, "aliased planes fit");
+  float* const x1 = sX;
+  float* const x2 = sX + kLossIn * kLossXS;
+  auto hz = [&](int k, int r) { return sH + (k * kLossIn + r) * kLossHS; };   // x1, x2, x1^2, x2^2, x1 x2 after the horizontal pass
+  auto mp = [&](int k, int r) { return sX + (k * kLossMid + r) * kLossHS; };  // a, b, dmu on the 26 x 26 region
+  auto hb = [&](int k, int r) { return sH + (k * kLossMid + r) * kLossBS; };  // their horizontal pass
   __shared__ float red[3][4];
   const int tid = threadIdx.x, img_c = blockIdx.z;   // image * 3 + channel
   const int ox = blockIdx.x * kLossTile, oy = blockIdx.y * kLossTile;
@@ -4663,55 +4661,101 @@ __global__ __launch_bounds__(256) void k_image_loss(int H, int W, const float* _
 #pragma unroll
     for (int k = 0; k < 11; ++k) wgt[k] /= s;
   }
-  for (int e = tid; e < kLossIn * kLossIn; e += 256) {
-    const int r = e / kLossIn, c = e - r * kLossIn, y = oy - 2 * kLossR + r, x = ox - 2 * kLossR + c;
-    const bool in = x >= 0 && x < W && y >= 0 && y < H;
-    x1[r][c] = in ? p1[(size_t)y * W + x] : 0.f;
-    x2[r][c] = in ? p2[(size_t)y * W + x] : 0.f;
+  for (int e = tid; e < kLossIn * kLossXS; e += 256) {
+    const int r = e / kLossXS, c = e - r * kLossXS, y = oy - 2 * kLossR + r, x = ox - 2 * kLossR + c;
+    const bool in = c < kLossIn && x >= 0 && x < W && y >= 0 && y < H;
+    x1[e] = in ? p1[(size_t)y * W + x] : 0.f;
+    x2[e] = in ? p2[(size_t)y * W + x] : 0.f;
   }
   __syncthreads();
-  for (int e = tid; e < kLossIn * kLossMid; e += 256) {
-    const int r = e / kLossMid, c = e - r * kLossMid;
-    float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
+  // ---- horizontal pass of the five products: row r, output columns 4 j .. 4 j + 3 (columns 26, 27 are padding)
+  if (tid < kLossIn * (kLossHS / 4)) {
+    const int r = tid / (kLossHS / 4), j = tid - r * (kLossHS / 4);
+    float a[16], b[16];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float a = x1[r][c + k], b = x2[r][c + k], w = wgt[k];
-      s1 += w * a; s2 += w * b; s11 += w * (a * a); s22 += w * (b * b); s12 += w * (a * b);
+    for (int q = 0; q < 4; ++q) {
+      const float4 va = *reinterpret_cast<const float4*>(x1 + r * kLossXS + 4 * j + 4 * q);
+      const float4 vb = *reinterpret_cast<const float4*>(x2 + r * kLossXS + 4 * j + 4 * q);
+      a[4 * q] = va.x; a[4 * q + 1] = va.y; a[4 * q + 2] = va.z; a[4 * q + 3] = va.w;
+      b[4 * q] = vb.x; b[4 * q + 1] = vb.y; b[4 * q + 2] = vb.z; b[4 * q + 3] = vb.w;
     }
-    hz[0][r][c] = s1; hz[1][r][c] = s2; hz[2][r][c] = s11; hz[3][r][c] = s22; hz[4][r][c] = s12;
+    float o[5][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float s1 = 0, s2 = 0, s11 = 0, s22 = 0, s12 = 0;
+#pragma unroll
+      for (int k = 0; k < 11; ++k) {
+        const float av = a[u + k], bv = b[u + k], w = wgt[k];
+        s1 += w * av; s2 += w * bv; s11 += w * (av * av); s22 += w * (bv * bv); s12 += w * (av * bv);
+      }
+      o[0][u] = s1; o[1][u] = s2; o[2][u] = s11; o[3][u] = s22; o[4][u] = s12;
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) *reinterpret_cast<float4*>(hz(k, r) + 4 * j) = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
   }
   // this thread's own pixel of the tile (the last phase needs it; the inputs' planes are overwritten before)
-  const float own1 = x1[tid / kLossTile + 2 * kLossR][tid % kLossTile + 2 * kLossR], own2 = x2[tid / kLossTile + 2 * kLossR][tid % kLossTile + 2 * kLossR];
+  const float own1 = x1[(tid / kLossTile + 2 * kLossR) * kLossXS + tid % kLossTile + 2 * kLossR];
+  const float own2 = x2[(tid / kLossTile + 2 * kLossR) * kLossXS + tid % kLossTile + 2 * kLossR];
   __syncthreads();
+  // ---- vertical pass + the SSIM terms: column c, output rows 4 g .. 4 g + 3 (rows >= 26 do not exist)
   float sum_s = 0.f;
   constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-  for (int e = tid; e < kLossMid * kLossMid; e += 256) {
-    const int r = e / kLossMid, c = e - r * kLossMid, y = oy - kLossR + r, x = ox - kLossR + c;
-    float mu1 = 0, mu2 = 0, s11 = 0, s22 = 0, s12 = 0;
+  if (tid < ((kLossMid + 3) / 4) * kLossMid) {
+    const int g = tid / kLossMid, c = tid - g * kLossMid;
+    float acc[5][4];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) {
-      const float w = wgt[k];
-      mu1 += w * hz[0][r + k][c]; mu2 += w * hz[1][r + k][c]; s11 += w * hz[2][r + k][c]; s22 += w * hz[3][r + k][c]; s12 += w * hz[4][r + k][c];
+    for (int k = 0; k < 5; ++k) {
+      float col[14];
+#pragma unroll
+      for (int q = 0; q < 14; ++q) col[q] = hz(k, min(4 * g + q, kLossIn - 1))[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) t += wgt[q] * col[u + q];
+        acc[k][u] = t;
+      }
     }
-    float a = 0.f, b = 0.f, dmu = 0.f;
-    if (x >= 0 && x < W && y >= 0 && y < H) {
-      const float A = 2.f * mu1 * mu2 + C1, B = 2.f * (s12 - mu1 * mu2) + C2;
-      const float C = mu1 * mu1 + mu2 * mu2 + C1, D = (s11 - mu1 * mu1) + (s22 - mu2 * mu2) + C2;
-      const float iC = 1.f / C, iD = 1.f / D, AB = A * B;
-      a = -AB * iC * iD * iD;
-      b = 2.f * A * iC * iD;
-      dmu = 2.f * mu2 * (B - A) * iC * iD - 2.f * mu1 * AB * iC * iC * iD + 2.f * mu1 * AB * iC * iD * iD;
-      if (r >= kLossR && r < kLossR + kLossTile && c >= kLossR && c < kLossR + kLossTile) sum_s += AB * iC * iD;  // this tile's own pixels
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = 4 * g + u, y = oy - kLossR + r, x = ox - kLossR + c;
+      if (r >= kLossMid) continue;
+      const float mu1 = acc[0][u], mu2 = acc[1][u], s11 = acc[2][u], s22 = acc[3][u], s12 = acc[4][u];
+      float a = 0.f, b = 0.f, dmu = 0.f;
+      if (x >= 0 && x < W && y >= 0 && y < H) {
+        const float A = 2.f * mu1 * mu2 + C1, B = 2.f * (s12 - mu1 * mu2) + C2;
+        const float C = mu1 * mu1 + mu2 * mu2 + C1, D = (s11 - mu1 * mu1) + (s22 - mu2 * mu2) + C2;
+        const float iC = 1.f / C, iD = 1.f / D, AB = A * B;
+        a = -AB * iC * iD * iD;
+        b = 2.f * A * iC * iD;
+        dmu = 2.f * mu2 * (B - A) * iC * iD - 2.f * mu1 * AB * iC * iC * iD + 2.f * mu1 * AB * iC * iD * iD;
+        if (r >= kLossR && r < kLossR + kLossTile && c >= kLossR && c < kLossR + kLossTile) sum_s += AB * iC * iD;  // this tile's own pixels
+      }
+      mp(0, r)[c] = a; mp(1, r)[c] = b; mp(2, r)[c] = dmu;
     }
-    mp[0][r][c] = a; mp[1][r][c] = b; mp[2][r][c] = dmu;
   }
   __syncthreads();
-  for (int e = tid; e < kLossMid * kLossTile; e += 256) {
-    const int r = e / kLossTile, c = e - r * kLossTile;
-    float s0 = 0, s1 = 0, s2 = 0;
+  // ---- horizontal pass of a, b, dmu: row r, output columns 4 j .. 4 j + 3 (hb lies over hz: dead since the barrier)
+  if (tid < kLossMid * (kLossTile / 4)) {
+    const int r = tid / (kLossTile / 4), j = tid - r * (kLossTile / 4);
 #pragma unroll
-    for (int k = 0; k < 11; ++k) { const float w = wgt[k]; s0 += w * mp[0][r][c + k]; s1 += w * mp[1][r][c + k]; s2 += w * mp[2][r][c + k]; }
-    hb[0][r][c] = s0; hb[1][r][c] = s1; hb[2][r][c] = s2;
+    for (int k = 0; k < 3; ++k) {
+      float v[16];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(mp(k, r) + 4 * j + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+      float o[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 11; ++q) t += wgt[q] * v[u + q];
+        o[u] = t;
+      }
+      *reinterpret_cast<float4*>(hb(k, r) + 4 * j) = make_float4(o[0], o[1], o[2], o[3]);
+    }
   }
   __syncthreads();
   float sum_se = 0.f, sum_ce = 0.f;
@@ -4720,7 +4764,7 @@ __global__ __launch_bounds__(256) void k_image_loss(int H, int W, const float* _
     if (x < W && y < H) {
       float wa = 0, wb = 0, wm = 0;
 #pragma unroll
-      for (int k = 0; k < 11; ++k) { const float w = wgt[k]; wa += w * hb[0][r + k][c]; wb += w * hb[1][r + k][c]; wm += w * hb[2][r + k][c]; }
+      for (int k = 0; k < 11; ++k) { const float w = wgt[k]; wa += w * hb(0, r + k)[c]; wb += w * hb(1, r + k)[c]; wm += w * hb(2, r + k)[c]; }
       const float v1 = own1, v2 = own2;
       const float d = v1 - v2;
       sum_se = d * d;
@@ -4738,6 +4782,7 @@ __global__ __launch_bounds__(256) void k_image_loss(int H, int W, const float* _
     if (tid == 0) partials[slot * 4 + 3] = 0.f;
   }
 }
+
 // The slots of k_image_loss added up in a fixed order by ONE workgroup (a few thousand slots: a 256 x 256 image has 768): per image
 // (sums[i][0..3]: squared error, clipped squared error, SSIM map, 0) and over the batch -> totals[0..2] = loss, mean squared
 // error, mean SSIM.  No atomics, nothing between workgroups: the result is the same bits every time.
