@@ -5,7 +5,7 @@ from tests import tile_walk_sim
 
 def test_headline_scene_tiles_walk_a_quarter_of_their_lists_and_no_orderfree_sum_predicts_it():
     r = tile_walk_sim.report(2, 300000)
-    # the same scene the device bins: its status block says 1 252 130 pairs, longest list 1663 (profiles/r04_l_bench.json); the
+    # the same scene the device bins: its status block says 1 252 130 pairs, longest list 1663 (profiles/r04_m_bench.json); the
     # replay's membership test is the library's up to hardware rcp / sqrt rounding
     assert abs(r["pairs_8x8"] - 1252130) < 1e-3 * 1252130 and r["list_max"] == 1663
     assert (r["n_visible"], r["r16"]) == (262939, 852214)
