@@ -127,6 +127,18 @@ static int choose_chunk(const GsrDims& d) {
   return best;
 }
 
+// Does a forward that announces its backward (GSR_FLAG_BACKWARD_FOLLOWS) save d rgb / d direction per (view, Gaussian) for it?
+// The rows are 48 bytes per view and Gaussian, written by the colour pass and read back by k_preprocess_bwd; the alternative - the
+// backward reads the harmonics again and re-derives them - is 12 K bytes per Gaussian ONCE for all views of its set, fewer bytes from
+// three views per set on.  Measured (fwd + bwd, saved / re-derived): one view 124.8 / 135.8 us, two 107 / 116 per view, three views of
+// 131 072 Gaussians 73.0 / 75.0, eight views 86.4 / 89.7 - the re-derivation is arithmetic in a launch that has none to spare; always saved.
+#ifndef GSR_SHJ_MAX_VIEWS
+#define GSR_SHJ_MAX_VIEWS (1 << 30)
+#endif
+static inline bool saves_jacobian(const GsrDims& d) {
+  return (d.flags & GSR_FLAG_BACKWARD_FOLLOWS) && d.sh_coeffs > 0 && d.views_per_set <= GSR_SHJ_MAX_VIEWS;
+}
+
 static Layout make_layout(const GsrDims& d) {
   Layout L;
   const Grid g = make_grid(d.width, d.height);
@@ -146,7 +158,7 @@ static Layout make_layout(const GsrDims& d) {
   L.o_rows = L.o_rgbc + align_up(V * N * sizeof(float4), kGA);
   L.o_shj = L.o_rows + ((d.flags & GSR_FLAG_BACKWARD_FOLLOWS)
                             ? align_up(V * N * GSR_SCREEN_GRAD_FLOATS * ((d.flags & GSR_FLAG_DETERMINISTIC) ? 8 : 4), kGA) : 0);
-  L.geom_bytes = L.o_shj + (((d.flags & GSR_FLAG_BACKWARD_FOLLOWS) && d.sh_coeffs > 0) ? align_up(V * N * 3 * sizeof(float4), 256) : 0);
+  L.geom_bytes = L.o_shj + (saves_jacobian(d) ? align_up(V * N * 3 * sizeof(float4), 256) : 0);
   size_t o = 0;
   L.o_status = o; o = align_up(o + sizeof(GsrStatus), 256);
   const size_t rows = (N + choose_chunk(d) - 1) / choose_chunk(d);
@@ -3999,7 +4011,7 @@ static Params base_params(const GsrDims* d, const GsrView* views, const float* m
   p.aux = (geom && L.o_aux) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_aux) : nullptr;
   p.rgbc = geom ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rgbc) : nullptr;
   p.grad_rows = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS)) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_rows) : nullptr;
-  p.shj = (geom && (d->flags & GSR_FLAG_BACKWARD_FOLLOWS) && d->sh_coeffs > 0) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_shj) : nullptr;
+  p.shj = (geom && saves_jacobian(*d)) ? reinterpret_cast<float4*>(static_cast<char*>(geom) + L.o_shj) : nullptr;
   p.status = reinterpret_cast<GsrStatus*>(b + L.o_status);
   p.counts = reinterpret_cast<uint32_t*>(b + L.o_counts);
   p.pair_mat = reinterpret_cast<uint2*>(b + L.o_counts);
