@@ -53,11 +53,30 @@ def find_hipcc() -> str:
     raise RuntimeError("hipcc not found (looked at $HIPCC, /opt/rocm/bin/hipcc, PATH)")
 
 
+def _source_stamp(extra_flags=()) -> str:
+    """What a built library was made from: a hash of the kernel source, the header and the compiler flags."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for path in (SRC, HEADER):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join([*HIPCC_FLAGS, *extra_flags]).encode())
+    return h.hexdigest()
+
+
 def is_stale() -> bool:
+    """The library is missing or was built from other sources.  By CONTENT (a stamp file next to the .so), not by modification
+    time: a copy of the tree - the snapshot a GPU box receives - keeps the files and not necessarily the order of their times,
+    and a library that is in fact current should not be compiled again there."""
     if not os.path.exists(LIB_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(s) > t for s in (SRC, HEADER))
+    try:
+        with open(LIB_PATH + ".stamp") as f:
+            return f.read().strip() != _source_stamp()
+    except OSError:
+        t = os.path.getmtime(LIB_PATH)  # (a library from before the stamp file existed)
+        return any(os.path.getmtime(s) > t for s in (SRC, HEADER))
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:
@@ -71,8 +90,14 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
         if res.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + res.stdout + res.stderr)
         os.replace(out + ".tmp", out)
+        if out == LIB_PATH:
+            with open(LIB_PATH + ".stamp", "w") as f:
+                f.write(_source_stamp(extra_flags) + "\n")
         if verbose:
             print("built", out)
+    elif out == LIB_PATH and not os.path.exists(LIB_PATH + ".stamp"):  # current by its times: from now on by its content
+        with open(LIB_PATH + ".stamp", "w") as f:
+            f.write(_source_stamp() + "\n")
     return out
 
 
