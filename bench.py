@@ -476,7 +476,13 @@ def main():
         gap = max(0.0, (sum(acc[k_] for k_ in chain_stages) - 1e3 * (eager_dt if eager_dt is not None else dt) / K) / len(chain_stages))
         dom = max(chain_stages, key=lambda k_: acc[k_])
         ach = kb[dom] / (acc[dom] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "kernel": KERNELS[dom], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # (KERNELS holds name fragments, matched against the profiler's kernel names; the tile launch of this workload - a
+        # fused-binning call with index-list slots of 641 .. 2048 entries - is the instance k_tile_fwd_prefix<false, false>)
+        slot = int(plan["dims"].pair_capacity) // (2 * (H // 8) * (W // 8))
+        instance = {"tiles": "gsr::k_tile_fwd_prefix<false, false>" if 640 < slot <= 2048 else "gsr::k_tile_fwd<true, ...>",
+                    "preprocess": "gsr::k_preprocess_bin<true, false>" if color_in_bin else "gsr::k_preprocess_bin<false, false>"}
+        result["roofline"] = {"bound": "hbm", "kernel": KERNELS[dom], "kernel_instance": instance.get(dom, KERNELS[dom]),
+                              "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach / HBM_PEAK_GBS, "traffic": None, "traffic_over_algorithmic": None,
                               "algorithmic_bytes": kb[dom], "avg_ms": acc[dom], "event_gap_ms": gap}
         result["roofline_chain"] = {"bound": "hbm", "achieved": ab["total"] / (dt / K) / 1e9,
