@@ -116,12 +116,24 @@ static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; 
 // pair then leaves as an 8-byte store of its own (measured: 48 views x 131 072 Gaussians chose 2048 by a tie and the binning
 // launch took 2437 us instead of ~600).
 constexpr int kChunkPrefer = 1600;
+#ifndef GSR_BIN_TWO
+#define GSR_BIN_TWO 1  // 0: measurement builds without the two-per-CU instance of the plain binning launch
+#endif
+#ifndef GSR_CIB_MAX_VPS
+#define GSR_CIB_MAX_VPS 4  // most views per set whose colour pass runs inside the binning launch (see color_in_bin_for)
+#endif
+// (a launch whose workgroups sit two to a CU - the plain binning launch of a small image, k_preprocess_bin<false, false, 2048> - has
+// twice the slots per round: 8 views of 300 k Gaussians then take 1600-Gaussian chunks, three rounds, instead of 1344, four)
+constexpr int kBinTwoTiles = 1496;  // most tiles of an image whose plain binning workgroups fit a CU twice (LDS; see the launch)
 static int choose_chunk(const GsrDims& d) {
   const long long V = d.num_views > 0 ? d.num_views : 1, N = d.num_gaussians > 0 ? d.num_gaussians : 1;
+  const Grid g = make_grid(d.width, d.height);
+  const bool plain_two = GSR_BIN_TWO && g.T <= kBinTwoTiles && (d.views_per_set > GSR_CIB_MAX_VPS || d.sh_coeffs == 0);
+  const long long slots = plain_two ? 2 * kCUs : kCUs;
   long long best_cost = -1;
   int best = kChunkPrefer;
   for (int c = kChunkPrefer; c >= kChunkMin; c -= 64) {
-    const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + kCUs - 1) / kCUs) * c;
+    const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + slots - 1) / slots) * c;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
@@ -1172,9 +1184,6 @@ constexpr size_t bin_lds_bytes(int T, bool color) {
 // VALU-bound launch (0.20 of 0.25 at one workgroup per CU) runs 15 % faster: 8 views 39.1 -> 37.3 us per view, 48 views 23.3 -> 22.2.
 // Larger images have room for one workgroup per CU whatever the registers: the 85-register instance (at 64 it spills: one
 // 1024 x 1024 view 182 -> 201 us).
-#ifndef GSR_BIN_TWO
-#define GSR_BIN_TWO 1  // 0: measurement builds without the two-per-CU instance
-#endif
 constexpr int kBinTwoMaxT = 2048;
 template <bool kColor, bool kJ, int kMaxT = kFusedMaxTiles>
 __global__ __launch_bounds__(kBinThreads, (!kColor && kMaxT == kBinTwoMaxT) ? 8 : 4) void k_preprocess_bin(const Params p) {

@@ -32,7 +32,8 @@ for _ in range(4):
     be.run_forward(plan, vb, *ins)
 torch.cuda.synchronize()
 lay = be.workspace_layout(plan["dims"])
-chunk = min(range(1600, 1023, -64), key=lambda c: ((V * ((n + c - 1) // c) + 255) // 256) * c)
+slots = 512 if V > 4 else 256  # (two plain binning workgroups per CU for images of up to 1496 tiles: choose_chunk in gsr_hip.hip)
+chunk = min(range(1600, 1023, -64), key=lambda c: ((V * ((n + c - 1) // c) + slots - 1) // slots) * c)
 rows = (n + chunk - 1) // chunk
 cap = int(plan["dims"].pair_capacity)
 end = lay["keys"] + (V * rows * (8192 + 136) + ((cap + 1023) // 1024 + 64) * 1024) * 8
