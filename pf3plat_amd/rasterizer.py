@@ -15,6 +15,8 @@ from __future__ import annotations
 import ctypes
 import struct
 import threading
+import time
+import warnings
 from dataclasses import dataclass
 from typing import NamedTuple, Optional
 
@@ -144,8 +146,17 @@ class HipBackend:
         # call is sized from the running maximum and its status is verified at the end of its own backward instead of in the
         # forward (0: never - every forward blocks until its status has been read)
         self.defer_after = 4
+        # what a DEFERRED forward of the default policy does when its workspace turns out too small (its image is NaN by then,
+        # so is the loss): "nan" (default) - its backward hands out NaN gradients with a one-line warning and raises nothing:
+        # the reference's training loop skips such a step by itself (model_wrapper.py:224-238 looks for NaN gradients) and every
+        # rank of a DDP job still enters the gradient all-reduce; "raise" - RuntimeError from that backward (round 4's behaviour).
+        # The opt-in "lazy" policy always raises at verification: its callers (inference loops, benchmarks) asked for that contract.
+        self.on_overflow = "nan"
         self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
-        self.pending = []  # (pinned status copy, event, shape key, cfg, workspace id) of lazy forwards not yet verified
+        self.pending = []  # (pinned status copy, shape key, cfg, token, raises) of lazy / deferred forwards not yet verified
+        self.poisoned = set()  # tokens of deferred forwards found overflowed whose backward has not run yet
+        self._token = 0  # forwards handed a token so far (a workspace address is not an identity: freed memory is handed out again)
+        self.spin_us = 300.0  # longest busy-wait on a status copy before falling back to a blocking, error-reporting synchronize
         self._pinned = []  # 16-byte pinned status buffers not in use
         self._sizes = {}  # (cfg, capacity) -> (GsrDims, geom bytes, bin bytes, img bytes, backward scratch bytes)
         self._lock = threading.Lock()  # pending / pools / caches: the process-wide backend may be called from several threads
@@ -284,11 +295,14 @@ class HipBackend:
         return hit
 
     def release_workspaces(self):
-        """Drop the cached workspaces of the no-autograd path (up to 8 sets of geom / bin / img stay alive otherwise) and the
-        size cache."""
+        """Drop the cached workspaces of the no-autograd path (up to 8 sets of geom / bin / img stay alive otherwise), the size
+        cache, and - after verifying them - the status copies still pending."""
+        if self.pending:
+            self.check_pending(wait=True)
         with self._lock:
             self.workspace_cache.clear()
             self._sizes.clear()
+            self.poisoned.clear()
 
     # ---- plans: outputs + workspaces allocated once, launch chains enqueued many times (bench / HIP-graph capture)
     def make_plan(self, cfg: RasterConfig, device, capacity: int, backward: bool = False, colors_shape=None,
@@ -441,11 +455,25 @@ class HipBackend:
             self._pinned.append(host)
         return st
 
-    def read_status(self, plan: dict) -> dict:
-        """The status block of the plan's last forward, waited for (polling): the one host sync of the default policy."""
-        host = self._status_copy(plan["bin"])
+    def _wait_status(self, host, dev=None):
+        """Wait for a status copy: a short poll of the pinned buffer (a blocking call sleeps and wakes up 30-60 us late), bounded -
+        after `spin_us` the wait becomes a device synchronize, which sleeps instead of holding the GIL and REPORTS a device fault
+        or a stream error (the poll alone would spin on the sentinel for ever)."""
+        if self._arrived(host):
+            return
+        deadline = time.perf_counter() + self.spin_us * 1e-6
         while not self._arrived(host):
-            pass
+            if time.perf_counter() > deadline:
+                torch.cuda.synchronize(dev)  # raises on a device error
+                if not self._arrived(host):
+                    raise RuntimeError("gsr_forward: the status block's copy did not execute (was the forward issued under "
+                                       "stream capture? pass a `capacity` and do not read the status there)")
+                return
+
+    def read_status(self, plan: dict) -> dict:
+        """The status block of the plan's last forward, waited for (bounded poll): the one host sync of the default policy."""
+        host = self._status_copy(plan["bin"])
+        self._wait_status(host, plan["bin"].device)
         return self._take_status(host)
 
     # ---- autograd-facing calls: fresh outputs per call; fresh workspaces too (kept alive for the backward) unless the caller says
@@ -466,7 +494,9 @@ class HipBackend:
                   is sized from the running maximum (x 1.25) and does NOT block: its status is verified at the end of its own
                   backward - the host then runs ahead of the device through the whole training step instead of idling the
                   device between forward and backward.  Should the workspace turn out too small, that call's image is NaN
-                  (so is the loss) and its backward raises; the capacity hint has grown by then;
+                  (so is the loss), its backward hands out NaN gradients with a warning - the reference's training loop
+                  skips a step with NaN gradients (model_wrapper.py:224-238) - and the capacity hint has grown by then
+                  (`on_overflow = "raise"`: the backward raises instead);
         "lazy"  - opt-in (inference loops, benchmarks): block only the first time a (views, N, H, W) shape is seen;
                   afterwards size the workspace at 1.25x the largest pair count seen, copy the status block asynchronously
                   and verify it at the next call, at `check_pending()`, and - for a call that is differentiated - at the
@@ -476,6 +506,12 @@ class HipBackend:
         if self.pending:
             self.check_pending()
         dev = viewbuf.device
+        if torch.cuda.is_current_stream_capturing():  # nothing can be read back while a graph is being captured: the caller sizes
+            if capacity is None and (cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width) not in self.capacity_hint:
+                raise RuntimeError("gsr_forward under stream capture: pass `capacity` (or run the shape once outside the capture)")
+            plan = self.make_plan(cfg, dev, self._default_capacity(cfg) if capacity is None else int(capacity))
+            self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
+            return plan["color"], plan["extra_img"], plan["radii"], (plan["dims"], plan["geom"], plan["bin"], plan["img"], 0)
         v, h, w, n = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians
         key = (v, n, h, w)
         known = capacity is None and key in self.capacity_hint
@@ -487,15 +523,24 @@ class HipBackend:
         for attempt in range(3):
             plan = self.make_plan(cfg, dev, cap, reuse_workspaces=reuse_workspaces and not lazy)
             self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
-            saved = None if reuse_workspaces else (plan["dims"], plan["geom"], plan["bin"], plan["img"])
+            with self._lock:
+                self._token += 1
+                token = self._token
+            saved = None if reuse_workspaces else (plan["dims"], plan["geom"], plan["bin"], plan["img"], token)
             out = (plan["color"], plan["extra_img"], plan["radii"], saved)
             if n == 0 or v == 0:
                 return out
             if lazy:
-                self.pending.append((self._status_copy(plan["bin"]), key, cfg, plan["bin"].data_ptr(), plan["bin"]))
+                # (the 16 bytes are copied behind the forward on its stream; the caching allocator hands freed memory to later
+                # work of that stream only, so nothing here needs to keep the workspace alive)
+                raises = self.sync_policy == "lazy" or self.defer_status or self.on_overflow == "raise"
+                item = (self._status_copy(plan["bin"]), key, cfg, token, raises)
+                with self._lock:
+                    self.pending.append(item)
                 return out
             self.last_status = st = self.read_status(plan)
-            self.seen[key] = self.seen.get(key, 0) + 1
+            with self._lock:
+                self.seen[key] = self.seen.get(key, 0) + 1
             self._raise_hint(key, self.capacity_for(cfg, st))
             if not st["overflow"]:
                 return out
@@ -503,42 +548,64 @@ class HipBackend:
         raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
 
     def _raise_hint(self, key, need: int):
-        self.capacity_hint[key] = max(int(need), int(self.capacity_hint.get(key, 0)))  # a running maximum: it never shrinks
+        with self._lock:
+            self.capacity_hint[key] = max(int(need), int(self.capacity_hint.get(key, 0)))  # a running maximum: it never shrinks
 
-    def check_pending(self, wait: bool = False, only_ws: Optional[int] = None):
-        """Verify the status blocks of earlier lazy/deferred forwards (those whose async copy has landed; all if `wait`;
-        `only_ws`: just the forward that owns that workspace, waiting for it)."""
-        keep, failed = [], None
-        for item in self.pending:
-            host, key, cfg, ws, _keepalive = item
-            mine = only_ws is not None and ws == only_ws
-            if only_ws is not None and not mine:
+    def check_pending(self, wait: bool = False, only_token: Optional[int] = None):
+        """Verify the status blocks of earlier lazy / deferred forwards (those whose async copy has landed; all if `wait`;
+        `only_token`: just that forward, waiting for it).  An overflowed forward of the lazy policy (or with
+        `on_overflow = "raise"`) raises here; an overflowed DEFERRED forward of the default policy is remembered in
+        `self.poisoned` - its backward returns NaN gradients - and a warning is issued."""
+        with self._lock:
+            items, self.pending = self.pending, []
+        keep, failed, warned = [], None, None
+        for item in items:
+            host, key, cfg, token, raises = item
+            mine = only_token is not None and token == only_token
+            if only_token is not None and not mine:
                 keep.append(item)
                 continue
             if wait or mine:
-                while not self._arrived(host):  # (polling: a blocking synchronize sleeps and wakes up 30-60 us late)
-                    pass
+                self._wait_status(host)
             elif not self._arrived(host):
                 keep.append(item)
                 continue
             self.last_status = st = self._take_status(host)
-            self.seen[key] = self.seen.get(key, 0) + 1
+            with self._lock:
+                self.seen[key] = self.seen.get(key, 0) + 1
             self._raise_hint(key, self.capacity_for(cfg, st))
-            if st["overflow"] and failed is None:
-                failed = st["num_pairs"]
-        self.pending = keep
+            if st["overflow"]:
+                if raises:
+                    failed = st["num_pairs"] if failed is None else failed
+                else:
+                    warned = st["num_pairs"]
+                    with self._lock:
+                        self.poisoned.add(token)
+        if keep:
+            with self._lock:
+                self.pending = keep + self.pending
+        if warned is not None:
+            warnings.warn(f"pf3plat_amd rasterizer: a training forward needed {warned} (tile, Gaussian) pairs, more than 1.25x the "
+                          "largest count seen for its shape: its image is NaN and its backward returns NaN gradients (the step is "
+                          "skipped by a NaN-gradient guard such as the reference's); the workspace has been enlarged for the next step.",
+                          RuntimeWarning, stacklevel=3)
         if failed is not None:
             raise RuntimeError(
                 f"an earlier gsr_forward needed {failed} pairs but its workspace was smaller; that call's image was "
                 "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync' with "
                 "defer_after = 0).")
 
-    def _verify_own_forward(self, binb):
-        """Backward of a lazily sized forward: its status must be known to be good before its gradients are handed out (an
-        overflowed forward binned nothing; the backward kernels over it are harmless - no pixel has a contributor - but
-        their result means nothing)."""
+    def _verify_own_forward(self, token: int) -> bool:
+        """Backward of a lazily sized forward: its status must be known before its gradients are handed out (an overflowed
+        forward binned nothing; the backward kernels over it are harmless - no pixel has a contributor - but their result means
+        nothing).  -> True when that forward overflowed and the policy is to answer with NaN gradients instead of raising."""
         if self.pending:
-            self.check_pending(only_ws=binb.data_ptr())
+            self.check_pending(only_token=token)
+        if self.poisoned and token in self.poisoned:
+            with self._lock:
+                self.poisoned.discard(token)
+            return True
+        return False
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
                  want_means2d: bool, rows_in_workspace: bool = False, frames=None, want_views=False):
@@ -548,7 +615,7 @@ class HipBackend:
         the built-in depth channel contributes (the z row of the view matrix: the reference graph's camera gradient)."""
         if saved is None:
             raise RuntimeError("this forward ran with reuse_workspaces=True (nothing was to be differentiated): it has no backward")
-        dims, geom, binb, img = saved
+        dims, geom, binb, img, token = saved
         dev = viewbuf.device
         v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
         f32 = torch.float32
@@ -572,9 +639,13 @@ class HipBackend:
         else:
             d_views = torch.zeros((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
         # (after the launches: the device works on the backward while the host waits for the forward's status, if it has to)
-        self._verify_own_forward(binb)
         out = plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
-        return out + (d_views,) if want_views else out
+        out = out + (d_views,) if want_views else out
+        if self._verify_own_forward(token):  # the forward had overflowed (deferred status, default policy): NaN, not numbers
+            for t in out:
+                if t is not None:
+                    t.fill_(float("nan"))
+        return out
 
     def setup_views(self, extrinsics, intrinsics, near, far, background, scale_invariant: bool = True) -> Tensor:
         """(V,4,4) c2w, (V,3,3), (V,), (V,), (3,) or (V,3) -> (V,48) camera records, one kernel launch (gsr_setup_views)."""

@@ -25,7 +25,7 @@ def viewbuf_from_cams(cams, bgs, scales=None, device="cpu"):
 
 def decode_workspaces(backend, cfg: RasterConfig, saved):
     """-> dict of numpy arrays: geom (V,N,8 f32, word 7 = radius bits), depth (V,N) or None, ranges (V,T,2), point_list, keys, final_T, n_contrib, status."""
-    dims, geom, binb, img = saved
+    dims, geom, binb, img = saved[:4]
     lay = backend.workspace_layout(dims)
     V, N, H, W = cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width
     sgx, sgy = 2 * ((W + 15) // 16), 2 * ((H + 15) // 16)

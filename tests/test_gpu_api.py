@@ -349,6 +349,66 @@ def test_reference_unchanged_decoder_path_at_config4_size():
     _cmp_grads(fl, gl, tol=2e-5)
 
 
+def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on():
+    """Eight training steps through the reference's own call structure (tests/reference_style.py: per-view operator, fresh
+    settings + rasterizer + `means2D` leaf per view) with the reference's optimizer step around them (model_wrapper.py:210-241: a
+    step whose gradients hold a NaN is skipped).  Default status policy: steps 0-3 read their status, steps 4-5 are deferred, at
+    step 6 the scene's footprints grow ninefold (> 3x the pairs): NO exception - a warning, a NaN image, all-NaN gradients, the
+    guard skips the step - and step 7 (same large scene) is finite and matches the oracle-driven same code."""
+    import warnings
+
+    from tests.reference_style import reference_style_decoder_forward
+
+    n, hw = 6000, (64, 64)
+    sc = synthetic.make_scene(61, n, hw, num_views=1)
+    w = torch.rand((1, 1, 3, *hw), generator=torch.Generator().manual_seed(6))
+    bgc = torch.tensor([0.1, 0.2, 0.3])
+    be = rasterizer.HipBackend()
+    old = install_backend(be)
+    try:
+        assert be.sync_policy == "sync" and be.defer_after == 4 and be.on_overflow == "nan"
+        leaves = _leafs(sc, DEV)
+        opt = torch.optim.SGD(leaves, lr=1e-4)
+        t = lambda x: x.to(DEV)
+
+        def step(k, leaves_, device):
+            m, c, h, o = leaves_
+            grow = 9.0 if k >= 6 else 1.0
+            tt = lambda x: x.to(device)
+            img = reference_style_decoder_forward(Gaussians(m, c * grow, h, o), tt(sc.extrinsics), tt(sc.intrinsics), tt(sc.near),
+                                                  tt(sc.far), hw, tt(bgc))
+            (img * tt(w)).sum().backward()
+            return img.detach()
+
+        pairs = []
+        for k in range(8):
+            before = [x.detach().clone() for x in leaves]
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter("always")
+                img = step(k, leaves, DEV)  # (no exception at any step)
+            pairs.append(be.last_status["num_pairs"])
+            nan_grad = any(torch.isnan(x.grad).any().item() for x in leaves)  # the reference's guard
+            if k == 6:
+                assert any("returns NaN gradients" in str(c.message) for c in caught)
+                assert torch.isnan(img).all() and all(torch.isnan(x.grad).all() for x in leaves) and nan_grad
+            else:
+                assert not caught and torch.isfinite(img).all() and not nan_grad, k
+            if k == 7:  # against the oracle-driven same code on the same parameter values
+                cpu_leaves = [x.detach().clone().cpu().requires_grad_(True) for x in leaves]
+                oi = _with_oracle(lambda: step(7, cpu_leaves, "cpu"))
+                assert rel_l2(img.cpu().numpy(), oi.numpy()) < 1e-4
+                _cmp_grads(leaves, cpu_leaves)
+            if not nan_grad:
+                opt.step()
+            else:
+                assert all(torch.equal(a, b.detach()) for a, b in zip(before, leaves))
+            opt.zero_grad()
+        assert be.seen[(1, n, *hw)] == 8 and not be.pending and not be.poisoned
+        assert pairs[7] > 3 * pairs[5], pairs  # the jump was a real one (pairs[6] is step 6's own count, read at its backward)
+    finally:
+        install_backend(old)
+
+
 def test_pack_view_matches_the_torch_assembly_of_the_record():
     """gsr_pack_view (one launch per settings object) == pack_views (the torch assembly): strided campos, float and tensor tan-fovs."""
     from pf3plat_amd.rasterizer import GaussianRasterizationSettings, pack_views

@@ -423,8 +423,9 @@ def test_lazy_policy_backward_refuses_a_poisoned_forward_and_sync_policy_retries
 def test_default_policy_defers_the_status_of_differentiated_calls_and_their_backward_verifies_it():
     """Default (`sync`) policy, round 4: a forward that WILL be differentiated (GSR_FLAG_BACKWARD_FOLLOWS) stops blocking on its
     status block once the shape has been read `defer_after` (4) times - it is sized from the running maximum and verified at the
-    end of its own backward.  A scene that then outgrows the workspace gets a NaN image and its backward raises (the hint has
-    grown: the next step fits); calls nothing differentiates keep the blocking read + retry; `defer_after = 0` switches it off."""
+    end of its own backward.  A scene that then outgrows the workspace gets a NaN image and NaN gradients with a warning (the hint
+    has grown: the next step fits; `on_overflow = "raise"`: its backward raises instead); calls nothing differentiates keep the
+    blocking read + retry; `defer_after = 0` switches the deferral off."""
     from pf3plat_amd import _lib, rasterizer
     from pf3plat_amd.synthetic import scene_operator_inputs, scene_viewbuf
 
@@ -458,12 +459,22 @@ def test_default_policy_defers_the_status_of_differentiated_calls_and_their_back
         be2.forward(cfg, vb, means, cov6, opac, colors, None)
     big = cov6 * 400.0
     c_bad, _, _, saved_bad = be2.forward(cfg, vb, means, big, opac, colors, None)
-    with pytest.raises(RuntimeError, match="poisoned with NaN"):
-        be2.backward(cfg, saved_bad, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
-    assert torch.isnan(c_bad).all()
+    assert be2.on_overflow == "nan"  # the default: nothing is raised inside a training step (the reference's loop could not catch it)
+    with pytest.warns(RuntimeWarning, match="returns NaN gradients"):
+        bad = be2.backward(cfg, saved_bad, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
+    assert torch.isnan(c_bad).all() and all(torch.isnan(t).all() for t in bad if t is not None)
+    assert not be2.pending and not be2.poisoned
     c_ok, _, _, saved_ok = be2.forward(cfg, vb, means, big, opac, colors, None)
     out = be2.backward(cfg, saved_ok, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
     assert torch.isfinite(c_ok).all() and all(torch.isfinite(t).all() for t in out if t is not None)
+    # opt-in: the same overflow raises from the backward (round 4's behaviour)
+    be4 = rasterizer.HipBackend()
+    be4.on_overflow = "raise"
+    for _ in range(4):
+        be4.forward(cfg, vb, means, cov6, opac, colors, None)
+    c_bad, _, _, saved_bad = be4.forward(cfg, vb, means, big, opac, colors, None)
+    with pytest.raises(RuntimeError, match="poisoned with NaN"):
+        be4.backward(cfg, saved_bad, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
     # switched off: every forward blocks again
     be3 = rasterizer.HipBackend()
     be3.defer_after = 0
