@@ -70,6 +70,33 @@ def backward_bytes(n, nv, r16, hw, k_sh):
     return hw * (12 + 8) + r16 * (8 + 36) + nv * 80 + nv * (12 + 24 + kc) + n * (12 + 24 + 4 + kc)
 
 
+def multi_view_stats(plan, n, v, h, w):
+    """Per-view N_v and R16 of a V-views-of-one-set call from the records its forward left in HBM, and N_v(any view)."""
+    from pf3plat_amd.rasterizer import RasterConfig
+
+    g = plan["geom"][: v * n * 32]
+    radius = (g.view(torch.int32).reshape(v, n, 8)[:, :, 7] & 0x0FFFFFFF)
+    nv_any = int((radius > 0).any(0).sum().item())
+    per_view = []
+    for v_ in range(v):
+        sub = dict(plan, geom=plan["geom"][v_ * n * 32:])
+        per_view.append(reference_rect_stats(sub, RasterConfig(1, 1, 1, n, h, w, 4, D_SH, 4, False)))
+    return nv_any, per_view
+
+
+def multi_view_bytes(n, nv_any, per_view, hw, k_sh, extra=False):
+    """SURVEY.md 8d's bytes for V views of ONE set: the set's inputs are read once (means of all, covariance + opacity + SH of the
+    Gaussians some view sees), every per-view term once per view; `extra`: + the depth image out (4 B / pixel and view) and its
+    gradient image in.  -> (forward bytes, backward bytes)."""
+    kc = 12 * k_sh
+    fwd = 12 * n + nv_any * (24 + 4 + kc)
+    bwd = nv_any * (12 + 24 + kc) + n * (12 + 24 + 4 + kc)
+    for nv_k, r16_k in per_view:
+        fwd += nv_k * 40 + r16_k * (16 + 36) + hw * (12 + 8 + (4 if extra else 0))
+        bwd += hw * (12 + 8 + (4 if extra else 0)) + r16_k * (8 + 36) + nv_k * 80
+    return fwd, bwd
+
+
 # kernel of every stage of the two chains (images of up to 8192 tiles: the fused binning path), and SURVEY.md 8d's algorithmic
 # bytes split over them: the terms of FWD_BYTES / BWD_BYTES, each attributed to the kernel that has to move it
 KERNELS = {"color": "gsr::k_color", "preprocess": "gsr::k_preprocess_bin", "tiles": "gsr::k_tile_fwd",
@@ -175,8 +202,13 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="stop after the timed region (for rocprofv3 runs of the headline loop alone)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gaussians", type=int, default=N_GAUSS, help=argparse.SUPPRESS)
+    ap.add_argument("--windows", type=int, default=5,
+                    help="R: the timed region is repeated R times (each window = EXACTLY --steps steps between the same barriers, MAX over "
+                         "ranks); ms_per_step / value report the MEDIAN window, every window is listed in config.windows")
+    ap.add_argument("--config5-gaussians", type=int, default=131072, help=argparse.SUPPRESS)  # (tests: the config-5 leg at a small size)
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
-    ap.add_argument("--traffic-child", choices=("fwd", "train"), default=None, help=argparse.SUPPRESS)  # the run those passes profile
+    ap.add_argument("--traffic-child", choices=("fwd", "train", "cfg4_fwd", "cfg4_train", "views8", "views48"), default=None,
+                    help=argparse.SUPPRESS)  # the runs the PMC passes / tools/profile_round.sh profile
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,6 +257,44 @@ def main():
 
     def step():
         be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+
+    from pf3plat_amd import _lib as _gl0
+
+    def many_view_call(seed, n_g, n_views, offsets, extra_mode=0, train=False):
+        """V views of ONE scene in one launch chain through the plan API, workspace sized from a first call's status:
+        -> dict(plan, ins, vb, cfg, status).  extra_mode 1: colour + depth (GSR_EXTRA_DEPTH built in), train: a backward follows."""
+        sc_m = synthetic.make_scene(seed, n_g, (H, W), d_sh=D_SH, num_views=n_views, view_offsets=offsets)
+        ins_m = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc_m))
+        vb_m = synthetic.scene_viewbuf(sc_m).to(dev)
+        fl = (_gl0.FLAG_BACKWARD_FOLLOWS if train else 0) | (extra_mode << 4)
+        cfg_m = RasterConfig(n_views, 1, n_views, n_g, H, W, 4, D_SH, 4, bool(extra_mode), fl)
+        plan_m = be.make_plan(cfg_m, dev, capacity=8 * n_views * n_g, backward=train)
+        be.run_forward(plan_m, vb_m, *ins_m)
+        st_m = be.read_status(plan_m)
+        plan_m = be.make_plan(cfg_m, dev, capacity=be.capacity_for(cfg_m, st_m, headroom=1.1), backward=train)
+        return dict(plan=plan_m, ins=ins_m, vb=vb_m, cfg=cfg_m, status=st_m)
+
+    def config4_call(train):  # BASELINE configs[3]: B = 1, G = 131 072, V = 3 target views, colour + depth (decoder_splatting_cuda.py:35-67)
+        return many_view_call(50, 131072, 3, None, extra_mode=1, train=train)
+
+    def views8_call():
+        offs8 = torch.randn(8, generator=torch.Generator().manual_seed(8)).mul(0.05).tolist()
+        return many_view_call(2, n, 8, offs8)
+
+    def views48_call():
+        return many_view_call(50, 131072, 48, torch.linspace(-0.45, 0.45, 48).tolist())
+
+    if args.traffic_child in ("cfg4_fwd", "cfg4_train", "views8", "views48"):  # profiled by tools/profile_round.sh (rocprofv3)
+        c = {"cfg4_fwd": lambda: config4_call(False), "cfg4_train": lambda: config4_call(True), "views8": views8_call,
+             "views48": views48_call}[args.traffic_child]()
+        gc_c = torch.rand((c["cfg"].num_views, 3, H, W), device=dev)
+        ge_c = torch.rand((c["cfg"].num_views, H, W), device=dev)
+        for _ in range(150 if c["cfg"].num_views < 48 else 40):
+            be.run_forward(c["plan"], c["vb"], *c["ins"])
+            if args.traffic_child == "cfg4_train":
+                be.run_backward(c["plan"], c["vb"], *c["ins"], None, gc_c, ge_c)
+        torch.cuda.synchronize()
+        return
 
     if args.traffic_child:  # profiled by pmc_traffic(): a dozen eager passes of the headline workload - the forward as timed
         n_child = 150  # (enough steps for the shader clock to ramp: a dozen steps run ~15 % slow, profiles/r03_j_clock_probe.txt)
@@ -348,7 +418,18 @@ def main():
             step()
     for _ in range(Wm):
         step()
-    dt = timed(step, K, dist_on)  # the headline: eager launches
+    # the headline: eager launches.  R windows of exactly K steps each, back to back (a 20-step window is 1.1 ms long and reads 4 %
+    # differently from one lease / clock state to the next: profiles/r04_m_clock_probe.txt); the MEDIAN window is reported
+    R = max(1, args.windows)
+    window_dts = []
+    for _ in range(R):
+        gathered.clear()
+        window_dts.append(timed(step, K, dist_on))
+    if dist_on:  # MAX over ranks, window by window
+        tw = torch.tensor(window_dts, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        window_dts = [float(x) for x in tw.tolist()]
+    dt = sorted(window_dts)[(R - 1) // 2]  # the median window (the lower one of the two middle windows when R is even)
     graph_dt = None
     if graph is not None:  # --graph: the same protocol over replays of the captured step, reported beside the headline
         for _ in range(min(Wm, 5)):
@@ -356,9 +437,6 @@ def main():
         graph_dt = timed(graph.replay, K, False)
     ranks_seen = 1
     if dist_on:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
         ones = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)  # how many ranks the collective itself saw
         ranks_seen = int(round(float(ones.item())))
@@ -387,7 +465,7 @@ def main():
         """BASELINE configs[4] next to the weak-scaled headline: 8 scenes of 131 072 Gaussians (seed 50 + rank), one target view each,
         K views per rank rendered into one buffer, ONE fused all_gather_into_tensor at the end (reference parallelism: one scene per
         GPU, src/main.py:109).  Same protocol (W warm-ups, K timed, barriers, MAX over ranks)."""
-        n5 = 131072
+        n5 = args.config5_gaussians
         sc5 = synthetic.make_scene(50 + rank, n5, (H, W), d_sh=D_SH)
         in5 = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc5))
         vb5 = synthetic.scene_viewbuf(sc5).to(dev)
@@ -429,6 +507,8 @@ def main():
                    "launch": launch_mode,
                    "parallelism": f"views sharded 1 scene/GPU x{world}" + (f", RCCL all-gather of the {K} x {world} rendered views in {n_chunks} batches overlapped with rendering, the last one at the end" if world > 1 else ""),
                    "camera_setup": "excluded (gsr_setup_views runs once before the loop; ~4 us per batch of views)",
+                   "windows": {"R": R, "steps_per_window": K, "ms_per_step_of_each_window": [round(1e3 * x / K, 6) for x in window_dts],
+                               "reported": "median window (ms_per_step, value); every window is K steps between barrier + synchronize, MAX over ranks"},
                    "num_pairs_8x8": status["num_pairs"], "max_tile_list": status["max_list"]},
     }
     if dist_on:
@@ -596,12 +676,15 @@ def main():
         n_fb = max(50, K // 4)
         for _ in range(5 + (400 if args.preheat_ms > 0 else 0)):  # (untimed: the legs before this one end in blocking reads - clocks, as above)
             fb()
-        device_idle()  # (rank 0 only runs this leg: no collective here)
-        t0 = time.perf_counter()
-        for _ in range(n_fb):
-            fb()
-        device_idle()
-        fb_ms = 1e3 * (time.perf_counter() - t0) / n_fb
+        fb_windows = []
+        for _ in range(R):  # (same protocol as the headline: R windows, the median one reported)
+            device_idle()  # (rank 0 only runs this leg: no collective here)
+            t0 = time.perf_counter()
+            for _ in range(n_fb):
+                fb()
+            device_idle()
+            fb_windows.append(1e3 * (time.perf_counter() - t0) / n_fb)
+        fb_ms = sorted(fb_windows)[(R - 1) // 2]
         bacc = {}
         for _ in range(20):
             be.run_forward(plan_b, viewbuf, means, cov6, opac, shs)  # (the rows are good for one backward)
@@ -620,6 +703,7 @@ def main():
         bb = backward_bytes(n, nv, r16, H * W, D_SH)
         result["bwd_ms"] = bwd_ms
         result["fwd_bwd_ms"] = fb_ms
+        result["fwd_bwd_ms_windows"] = [round(x, 6) for x in fb_windows]
         result["bwd_stage_ms"] = {k_: round(v_, 5) for k_, v_ in bacc.items()}
         result["bwd_ms_chain_difference"] = fb_ms - 1e3 * dt / K  # eager fwd+bwd step minus the eager inference forward step
         result["training_forward_stage_ms"] = {k_: round(tacc[k_], 5) for k_ in chain_stages}
@@ -733,21 +817,74 @@ def main():
                 import pf3plat_amd
                 from pf3plat_amd.types import Gaussians
 
-                offs = torch.randn(8, generator=torch.Generator().manual_seed(8)).mul(0.05).tolist()
-                sc8 = synthetic.make_scene(2, n, (H, W), d_sh=D_SH, num_views=8, view_offsets=offs)
-                vb8 = synthetic.scene_viewbuf(sc8).to(dev)
-                cfg8 = RasterConfig(8, 1, 8, n, H, W, 4, D_SH, 4, False)
-                plan8 = be.make_plan(cfg8, dev, capacity=be.capacity_for(cfg8, {"num_pairs": 8 * status["num_pairs"], "max_list": status["max_list"]}, headroom=1.2))
-                for _ in range(5):
-                    be.run_forward(plan8, vb8, means, cov6, opac, shs)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(40):
-                    be.run_forward(plan8, vb8, means, cov6, opac, shs)
-                torch.cuda.synchronize()
-                t8 = (time.perf_counter() - t0) / 40
-                assert not be.read_status(plan8)["overflow"]
-                result["batched_8_views"] = {"views_per_s": 8 / t8, "ms_per_launch_chain": 1e3 * t8, "us_per_view": 1e6 * t8 / 8}
+                def time_calls(fn, reps, warm):
+                    for _ in range(warm):
+                        fn()
+                    torch.cuda.synchronize()
+                    t0_ = time.perf_counter()
+                    for _ in range(reps):
+                        fn()
+                    torch.cuda.synchronize()
+                    return (time.perf_counter() - t0_) / reps
+
+                c8 = views8_call()
+                t8 = time_calls(lambda: be.run_forward(c8["plan"], c8["vb"], *c8["ins"]), 40, 5)
+                assert not be.read_status(c8["plan"])["overflow"]
+                nv_any8, pv8 = multi_view_stats(c8["plan"], n, 8, H, W)
+                ab8, _ = multi_view_bytes(n, nv_any8, pv8, H * W, D_SH)
+                result["batched_8_views"] = {
+                    "views_per_s": 8 / t8, "ms_per_launch_chain": 1e3 * t8, "us_per_view": 1e6 * t8 / 8,
+                    "algorithmic_bytes": ab8, "GBps": ab8 / t8 / 1e9, "frac": ab8 / t8 / 1e9 / HBM_PEAK_GBS,
+                    "num_pairs_8x8": c8["status"]["num_pairs"],
+                    "note": "SURVEY 8d bytes with the set's inputs counted once (12 N + N_v(any view)(28 + 12 K)) and every per-view term per view"}
+                del c8
+                # ---- BASELINE configs[3], the call PF3plat's decoder makes every step (decoder_splatting_cuda.py:35-67, depth rendered
+                # with the colour: config/main.yaml:50): 3 views of 131 072 Gaussians, colour + depth, through the plan API - the
+                # kernels alone, with SURVEY 8d's bytes (inputs once per set), the fraction of the roofline, and the dominant kernel
+                def config4_roofline(train):
+                    c4 = config4_call(train)
+                    gc4 = torch.rand((3, 3, H, W), device=dev)
+                    ge4 = torch.rand((3, H, W), device=dev)
+
+                    def one():
+                        be.run_forward(c4["plan"], c4["vb"], *c4["ins"])
+                        if train:
+                            be.run_backward(c4["plan"], c4["vb"], *c4["ins"], None, gc4, ge4)
+
+                    t4_ = time_calls(one, 200, 200)
+                    assert not be.read_status(c4["plan"])["overflow"]
+                    nv_any4, pv4 = multi_view_stats(c4["plan"], 131072, 3, H, W)
+                    fwd_b, bwd_b = multi_view_bytes(131072, nv_any4, pv4, H * W, D_SH, extra=True)
+                    total_b = fwd_b + (bwd_b if train else 0)
+                    stages = {}
+                    for _ in range(20):
+                        ms_f = be.run_forward(c4["plan"], c4["vb"], *c4["ins"], profile=True)
+                        ms_b = be.run_backward(c4["plan"], c4["vb"], *c4["ins"], None, gc4, ge4, profile=True) if train else {}
+                        for k_, v_ in list(ms_f.items()) + list(ms_b.items()):
+                            stages[k_] = stages.get(k_, 0.0) + v_ / 20
+                    stages = {k_: v_ for k_, v_ in stages.items() if v_ > 1e-3}
+                    dom4 = max(stages, key=stages.get)
+                    r16_4 = sum(b_ for _, b_ in pv4)
+                    nv_4 = sum(a_ for a_, _ in pv4)
+                    kc4 = 12 * D_SH
+                    share = {"tiles": r16_4 * (8 + 36) + 3 * H * W * 24, "preprocess": 12 * 131072 + nv_any4 * (28 + kc4) + nv_4 * 40 + 8 * r16_4,
+                             "blend_bwd": 3 * H * W * 24 + r16_4 * 44 + nv_4 * 40,
+                             "preprocess_bwd": nv_4 * 40 + nv_any4 * (36 + kc4) + 131072 * (40 + kc4)}
+                    return {"workload": "BASELINE configs[3] through the plan API: B = 1, G = 131072 (seed 50), V = 3 views 256x256 of one set, colour + "
+                                        "built-in depth channel" + (", forward (GSR_FLAG_BACKWARD_FOLLOWS) + backward" if train else ", forward only"),
+                            "ms_per_call": 1e3 * t4_, "N_v_any": nv_any4, "N_v_per_view": [a_ for a_, _ in pv4], "R16_per_view": [b_ for _, b_ in pv4],
+                            "num_pairs_8x8": c4["status"]["num_pairs"], "max_tile_list": c4["status"]["max_list"],
+                            "algorithmic_bytes": total_b, "forward_bytes": fwd_b, "backward_bytes": bwd_b if train else None,
+                            "bound": "hbm", "achieved": total_b / t4_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": total_b / t4_ / 1e9 / HBM_PEAK_GBS,
+                            "stage_ms_event_timed": {k_: round(v_, 5) for k_, v_ in stages.items()},
+                            "dominant_kernel": {"stage": dom4, "kernel": KERNELS.get(dom4, dom4), "avg_ms": stages[dom4],
+                                                "algorithmic_bytes": share.get(dom4),
+                                                "frac": None if dom4 not in share else share[dom4] / (stages[dom4] * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                            "note": "bytes: SURVEY 8d with the set's inputs once (12 N + N_v(any)(28 + 12 K); backward: N_v(any)(36 + 12 K) + N (40 + 12 K)) "
+                                    "and per view N_v 40 + R16 52 + HW 24 forward (HW 24 + R16 44 + N_v 80 backward); rocprofv3 averages of the same "
+                                    "child run: profiles/r05_*_kernel_stats_config4_{fwd,train}.md"}
+
+                result["roofline_config4"] = {"fwd": config4_roofline(False), "train": config4_roofline(True)}
                 # ---- many views of ONE scene in one call: PF3plat's video rendering makes 46-51 views of a scene per decoder call
                 # (reference src/model/model_wrapper.py:699-778, decoder call at :731; assets/evaluation_index_re10k_video.json).
                 # G = 131 072 (2 context views x 256 x 256), V = 48 cameras on the path between the two context cameras, one launch chain.

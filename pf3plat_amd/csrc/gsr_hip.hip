@@ -25,6 +25,7 @@
 // trees as the fp32 oracle (IEEE +,-,*,/ and sqrt are correctly rounded on both sides).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <atomic>
 
 #include "../../include/gsr.h"
@@ -124,11 +125,16 @@ constexpr int kChunkPrefer = 1600;
 #endif
 // (a launch whose workgroups sit two to a CU - the plain binning launch of a small image, k_preprocess_bin<false, false, 2048> - has
 // twice the slots per round: 8 views of 300 k Gaussians then take 1600-Gaussian chunks, three rounds, instead of 1344, four)
-constexpr int kBinTwoTiles = 1496;  // most tiles of an image whose plain binning workgroups fit a CU twice (LDS; see the launch)
+// ONE statement of "which binning launch will this call take", shared by the chunk choice (host arithmetic at sizing time) and by
+// forward_impl (defined behind bin_lds_bytes, next to the launch): the colour pass inside the binning launch as far as the call's
+// dims say (forward_impl adds what only the device knows: whether it granted the LDS attribute), and whether the plain launch's
+// workgroups sit two to a CU (LDS in 1280-byte steps: images of up to 1496 tiles).
+static bool color_in_bin_by_dims(const GsrDims& d, const Grid& g);
+static bool bin_two_per_cu(const Grid& g, bool color_in_bin);
 static int choose_chunk(const GsrDims& d) {
   const long long V = d.num_views > 0 ? d.num_views : 1, N = d.num_gaussians > 0 ? d.num_gaussians : 1;
   const Grid g = make_grid(d.width, d.height);
-  const bool plain_two = GSR_BIN_TWO && g.T <= kBinTwoTiles && (d.views_per_set > GSR_CIB_MAX_VPS || d.sh_coeffs == 0);
+  const bool plain_two = bin_two_per_cu(g, color_in_bin_by_dims(d, g));
   const long long slots = plain_two ? 2 * kCUs : kCUs;
   long long best_cost = -1;
   int best = kChunkPrefer;
@@ -1185,6 +1191,17 @@ constexpr size_t bin_lds_bytes(int T, bool color) {
 // Larger images have room for one workgroup per CU whatever the registers: the 85-register instance (at 64 it spills: one
 // 1024 x 1024 view 182 -> 201 us).
 constexpr int kBinTwoMaxT = 2048;
+static bool bin_two_per_cu(const Grid& g, bool color_in_bin) {
+  return GSR_BIN_TWO && !color_in_bin && g.T <= kBinTwoMaxT && 2 * align_up(bin_lds_bytes(g.T, false) + 10400, 1280) <= (size_t)160 * 1024;
+}
+static bool color_in_bin_by_dims(const GsrDims& d, const Grid& g) {
+  // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
+  // tasks for its five colour waves - 8 views in one chain were 7 % slower that way than with the separate launch; colour tasks in
+  // groups of <= 4 views exist - colour_role - but measured no better than the colour pass as a launch of its own: 352.9 vs 342.2 us)
+  const bool fused_bin = g.T <= kFusedMaxTiles && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
+  return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= GSR_CIB_MAX_VPS &&
+         g.T <= kColorBinMaxTiles && bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
+}
 template <bool kColor, bool kJ, int kMaxT = kFusedMaxTiles>
 __global__ __launch_bounds__(kBinThreads, (!kColor && kMaxT == kBinTwoMaxT) ? 8 : 4) void k_preprocess_bin(const Params p) {
   extern __shared__ float4 dyn_stage[];  // kBinThreads / 64 waves x 4 KB: record transpose, then pair staging; then T counters;
@@ -1567,17 +1584,22 @@ __global__ __launch_bounds__(1024, GSR_TP_WAVES) void k_tile_prefix(const Params
   }
 }
 
-// One workgroup per 1024 consecutive (view, tile) totals.  Every workgroup reads ALL the totals once, coalesced (at most a few
-// hundred KB out of L2) and so knows the grand total - which decides the overflow flag every range depends on - and the sum in
-// front of its own chunk without waiting for anybody; then an exclusive scan of its chunk.  (Until round 4 this was ONE
-// workgroup whose threads each walked 64 consecutive totals - uncoalesced - twice: 115 us for the 65 536 tiles of a 2048 x 2048
-// image, a fifth of that call.)
+// One workgroup per chunk of consecutive (view, tile) totals (a multiple of 1024; at most kTileScanBlocks workgroups).  Every workgroup
+// reads ALL the totals once, coalesced (a few hundred KB out of L2) and so knows the grand total - which decides the overflow flag
+// every range depends on - and the sum in front of its own chunk without waiting for anybody; then an exclusive scan of its chunk,
+// 1024 totals at a time.  (Until round 4 this was ONE workgroup whose threads each walked 64 consecutive totals - uncoalesced -
+// twice: 115 us for the 65 536 tiles of a 2048 x 2048 image, a fifth of that call.  The number of workgroups is capped because the
+// redundant read grows with workgroups x totals: 48 views of 2048 x 2048 are 3 M totals - one workgroup per 1024 of them would move
+// 36 GB through the L2s, 128 workgroups move 1.5 GB.)
+constexpr int kTileScanBlocks = 128;
+static inline unsigned tile_scan_blocks(size_t n) { return (unsigned)std::min<size_t>((n + 1023) / 1024, (size_t)kTileScanBlocks); }
 __global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
   __shared__ unsigned long long sTot[16], sBefore[16], sScan[16];
   __shared__ uint32_t sMax[16];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const size_t n = (size_t)p.d.num_views * p.g.T;
-  const size_t c0 = (size_t)blockIdx.x * 1024;  // this workgroup's chunk: [c0, c0 + 1024)
+  const size_t chunk = ((n + gridDim.x - 1) / gridDim.x + 1023) / 1024 * 1024;
+  const size_t c0 = (size_t)blockIdx.x * chunk, c1 = c0 + chunk < n ? c0 + chunk : n;  // this workgroup's chunk: [c0, c1)
   unsigned long long tot = 0, before = 0;
   uint32_t mx = 0;
   for (size_t k = tid; k < n; k += 1024) {
@@ -1591,30 +1613,40 @@ __global__ __launch_bounds__(1024) void k_tile_scan(const Params p) {
     before += __shfl_down(before, o, 64);
     mx = max(mx, (uint32_t)__shfl_down((int)mx, o, 64));
   }
-  const size_t k = c0 + tid;
-  const uint32_t mine = k < n ? p.tile_total[k] : 0u;
-  // inclusive scan of the chunk inside the wave (64-bit: a chunk of long lists can pass 2^32 only in theory, the total can)
-  unsigned long long incl = mine;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, 64);
-    if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
-  }
   if (lane == 0) { sTot[w] = tot; sBefore[w] = before; sMax[w] = mx; }
-  if (lane == 63) sScan[w] = incl;
   __syncthreads();
-  unsigned long long total = 0, run = 0;
+  unsigned long long total = 0, carry = 0;
   uint32_t gmax = 0;
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
     total += sTot[q];
-    run += sBefore[q];
-    run += q < w ? sScan[q] : 0ull;
+    carry += sBefore[q];
     gmax = max(gmax, sMax[q]);
   }
   const bool overflow = total > (unsigned long long)p.d.pair_capacity;
-  run += incl - mine;
-  if (k < n) p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + mine));
+  for (size_t s0 = c0; s0 < c1; s0 += 1024) {  // (workgroup-uniform bounds)
+    const size_t k = s0 + tid;
+    const uint32_t mine = k < n ? p.tile_total[k] : 0u;
+    // inclusive scan inside the wave (64-bit: 1024 long lists can pass 2^32 only in theory, the running sum can)
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o, 64), hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, 64);
+      if (lane >= o) incl += ((unsigned long long)hi << 32) | lo;
+    }
+    if (lane == 63) sScan[w] = incl;
+    __syncthreads();
+    unsigned long long run = carry, step = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      run += q < w ? sScan[q] : 0ull;
+      step += sScan[q];
+    }
+    run += incl - mine;
+    if (k < n) p.ranges[k] = overflow ? make_uint2(0u, 0u) : make_uint2((uint32_t)run, (uint32_t)(run + mine));
+    carry += step;
+    __syncthreads();  // sScan is written again by the next 1024 totals
+  }
   if (blockIdx.x == 0 && tid == 0) {
     p.status->num_pairs = total;
     p.status->overflow = overflow ? 1u : 0u;
@@ -2526,22 +2558,12 @@ __global__ __launch_bounds__(kFwdThreads, (kLds == 2048 && kGather && !kExtra) ?
 constexpr int kPrefix = GSR_PREFIX;  // list positions ranked before the blend starts (a multiple of kFB)
 static_assert(kPrefix % kFB == 0 && kPrefix >= 2 * kFB, "the prefix is whole batches");
 
-// The rare paths of k_tile_fwd_prefix as real calls (s_swappc), NOT inlined: with them inline the kernel was 22.7 KB of code with the
-// usual path scattered through it, and every phase of every tile ran 2-3 x slower (forward 65 us against 56) - four tiles per CU
-// in four different phases fetch four different parts of the kernel, and the instruction cache (shared by two CUs) no longer
-// held them.  The usual path is one compact run of code.
-#ifndef GSR_PREFIX_NOINLINE
-#define GSR_PREFIX_NOINLINE 0
-#endif
-#if GSR_PREFIX_NOINLINE
-#define GSR_COLD __attribute__((noinline))
-#else
-#define GSR_COLD __forceinline__
-#endif
-GSR_COLD __device__ uint2 sort_tile_general_2048(const Params& p, const uint32_t bid, unsigned long long* smem, uint32_t* red, uint32_t* sInfo) {
+// The rare paths of k_tile_fwd_prefix (inlined: as real calls - `noinline` - `Params` travels by reference, 480 B of scratch per lane
+// and 108-112 VGPRs for a path that is almost never taken: forward 84 us)
+__device__ __forceinline__ uint2 sort_tile_general_2048(const Params& p, const uint32_t bid, unsigned long long* smem, uint32_t* red, uint32_t* sInfo) {
   return sort_tile<true, 2048>(p, bid, smem, red, sInfo);
 }
-GSR_COLD __device__ void bitonic_whole_list(unsigned long long* sk, uint32_t* out, const int n) {
+__device__ __forceinline__ void bitonic_whole_list(unsigned long long* sk, uint32_t* out, const int n) {
   int lgnp = 1;
   while ((1 << lgnp) < n) ++lgnp;
   bitonic_block(sk, n, lgnp, (int)threadIdx.x);
@@ -2566,22 +2588,15 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   constexpr int kLds = 2048;
   constexpr int kBk = kCompact ? 1024 : SortLds<kLds>::kBuckets, kBkBits = kCompact ? 10 : SortLds<kLds>::kBucketBits, kBpt = kBk / kSortThreads;
   constexpr int Q = kLds / kSortThreads;
-#ifndef GSR_PREFIX_ALIAS
-#define GSR_PREFIX_ALIAS 0  // 1 (measurement): the blend's area over the keys as in k_tile_fwd, every list ranked to its end
-#endif
   // keys | bucket counters, then cursors | (kCompact) the blend's area - one array, so that the general path (sort_tile: 24 KB from
   // the start, its blend over its dead keys) finds its room in it
   constexpr int kCounterWords = kCompact ? kBk / 4 : kBk / 2;  // 8-byte words
   constexpr int kBlendWordsP = (int)((sizeof(BlendLds) + 7) / 8);
-  constexpr int kFastWords = kLds + kCounterWords + ((kCompact && !GSR_PREFIX_ALIAS) ? kBlendWordsP : 0);
+  constexpr int kFastWords = kLds + kCounterWords + (kCompact ? kBlendWordsP : 0);
   __shared__ __attribute__((aligned(16))) unsigned long long smem[kFastWords > SortLds<kLds>::kWords ? kFastWords : SortLds<kLds>::kWords];
-#if GSR_PREFIX_ALIAS
-  BlendLds& blds = *reinterpret_cast<BlendLds*>(smem);
-#else
   // NOT over the keys: a tile may come back to rank the rest of its list
   __shared__ __attribute__((aligned(16))) unsigned long long blds_own[kCompact ? 2 : kBlendWordsP];
   BlendLds& blds = *reinterpret_cast<BlendLds*>(kCompact ? smem + kLds + kCounterWords : blds_own);
-#endif
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
   __shared__ uint32_t sCount;
@@ -2636,18 +2651,11 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   // a run's place in the key array: the wave's runs side by side (DPP scan of the counts), the wave's block from ONE atomic on
   // the cursor - 247 lanes adding to the same LDS word are processed one lane after the other and hold up the LDS pipeline of
   // the whole CU while they are (measured: the per-lane form made every LDS phase of every tile on the CU 2-3 x slower)
-#ifdef GSR_PF_SCAN  // (experiment: the rows' places from a block scan, as sort_tile does)
-  uint32_t tot_scan;
-  const uint32_t start0 = block_exclusive_scan(e0.y, red, tid, tot_scan);
-  if (tid == 0) sCount = tot_scan;
-  __syncthreads();
-#else
   const uint32_t incl = wave_inclusive_scan_u32(e0.y);
   uint32_t wbase = 0;
   if (lane == 63 && incl) wbase = atomicAdd(&sCount, incl);
   wbase = (uint32_t)__builtin_amdgcn_readlane((int)wbase, 63);
   const uint32_t start0 = wbase + incl - e0.y;
-#endif
   const bool fits = start0 + e0.y <= (uint32_t)kLds;
   GSR_STAMP2(1);
   uint32_t lo = 0xffffffffu, hi = 0u;
@@ -2690,13 +2698,8 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   bool bucketed = false;  // the keys sit in bucket order in `sk`, cur[b] = end of bucket b: positions are ranked on demand
   if (bad || n > p.stride) {  // workgroup-uniform: the general path, from the start
     __syncthreads();
-#ifdef GSR_PREFIX_NOGENERAL  // (experiment: how much of the kernel's time is the SIZE of its code?)
-    if (tid == 0) { p.status->overflow = 1u; p.ranges[tg] = make_uint2(0u, 0u); }
-    n = 0; ranked = 0;
-#else
     const uint2 rg = sort_tile_general_2048(p, bid, smem, red, sInfo);
     obase = rg.x; n = rg.y - rg.x; ranked = n;
-#endif
   } else {
     if (tid == 0) p.ranges[tg] = make_uint2(obase, obase + n);
     fast_path = true;
@@ -2710,24 +2713,12 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
       const uint32_t range = dhi - dlo;
       shift = range < (uint32_t)kBk ? 0 : (32 - __clz((int)range)) - kBkBits;
       unsigned long long kreg[Q];
-#ifdef GSR_PF_SPLIT  // (experiment: keys to registers, barrier, then the histogram - as sort_tile does)
-#pragma unroll
-      for (int q = 0; q < Q; ++q) {
-        const int k = tid + q * kSortThreads;
-        kreg[q] = (k < (int)n) ? sk[k] : ~0ull;
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < Q; ++q)
-        if (tid + q * kSortThreads < (int)n) (void)bump(((uint32_t)(kreg[q] >> 32) - dlo) >> shift);
-#else
 #pragma unroll
       for (int q = 0; q < Q; ++q) {
         const int k = tid + q * kSortThreads;
         kreg[q] = (k < (int)n) ? sk[k] : ~0ull;
         if (k < (int)n) (void)bump(((uint32_t)(kreg[q] >> 32) - dlo) >> shift);
       }
-#endif
       __syncthreads();
       GSR_STAMP(2);
       // exclusive scan of the bucket counts: thread t owns kBpt consecutive buckets
@@ -2751,11 +2742,7 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
       const bool big = block_any(cmax > (uint32_t)kSpanMax, sAnyBig2);
       GSR_STAMP(3);
       if (big) {  // degenerate depth distribution: the bitonic network on the same array, whole list
-#ifdef GSR_PREFIX_NOGENERAL
-        if (tid == 0) p.status->overflow = 1u;
-#else
         bitonic_whole_list(sk, out, (int)n);
-#endif
         ranked = n;
       } else {
         // scatter into bucket order (every key is in a register: in place)
@@ -2769,7 +2756,7 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
         GSR_STAMP(4);
         // after the scatter cur[b] is the END of bucket b.  Rank the buckets that reach into the first kPrefix positions
         ranked = n;
-        if (!GSR_PREFIX_ALIAS && !(p.d.flags & GSR_FLAG_FULL_LISTS) && n > (uint32_t)(kPrefix + kPrefix / 4))
+        if (!(p.d.flags & GSR_FLAG_FULL_LISTS) && n > (uint32_t)(kPrefix + kPrefix / 4))
           ranked = cur_of(((uint32_t)(sk[kPrefix - 1] >> 32) - dlo) >> shift);
         bucketed = true;
       }
@@ -2798,12 +2785,6 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(0);
   if (bid == 0 && tid == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;  // the binning launch's (take_pages)
   __syncthreads();  // the list is this workgroup's own: its stores are visible to its waves from here on
-#ifdef GSR_PF_OLDBLEND  // (experiment: the one-range blend of k_tile_fwd behind the new gather / sort)
-  rank_positions(ranked, n);
-  __syncthreads();
-  blend_tile<kExtra>(p, v, t, make_uint2(obase, obase + n), *reinterpret_cast<BlendLds*>(smem));
-  return;
-#endif
   // ---- blend: the ranked prefix (whole batches of it), then - only if some pixel is still open - the rest
   const Grid& g = p.g;
   const int tx = t % g.sgx, ty = t / g.sgx;
@@ -2866,9 +2847,6 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
     o[0] = tm0; o[1] = ((unsigned long long)hw << 32); o[2] = __builtin_readcyclecounter();
     o[3] = (rt0 << 32) | (__builtin_amdgcn_s_memrealtime() & 0xffffffffull);  // 100 MHz wall clock: start | end
   }
-#if GSR_PREFIX_ALIAS
-  blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(&blds + 1), acc, pxi, pyi, inside, bg0, bg1, bg2);
-#else
   // (the keys are dead: their last reader is rank_positions, a barrier ago at least)
   if (kCompact) {  // the pixel's coordinates formed again (opaque lane number) instead of held across the loops: 80 registers
     int ln = lane;
@@ -2878,7 +2856,6 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   } else {
     blend_finish<kExtra>(p, v, t, n, *reinterpret_cast<BlendFin*>(smem), acc, pxi, pyi, inside, bg0, bg1, bg2);
   }
-#endif
   report_length();
 #undef GSR_STAMP
 #undef GSR_STAMP2
@@ -3100,15 +3077,12 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   auto eval = [&](uint32_t it) {  // stage E
     const int ring = it & 3;
     const uint32_t base = batch_of(it) * kBB + e0;
-#ifndef GSR_BWD_REM_FAST
-#define GSR_BWD_REM_FAST 0
-#endif
-    // entry u of the segment is in front of the pixel's last one <=> u < rem.  (GSR_BWD_REM_FAST: a segment that lies in front of EVERY
-    // pixel's last contributor - wave-uniform - is given rem = "all": the per-entry index tests then fold to constants)
+    // entry u of the segment is in front of the pixel's last one <=> u < rem.  (A wave-uniform second copy of the loop for segments
+    // in front of EVERY pixel's last contributor, its index tests folded away, costs more instruction fetch than it saves: DESIGN 8)
     const uint32_t rem = my_last > base ? my_last - base : 0u;
     int es = e0;  // opaque copy: the three LDS addresses are then formed here, per batch, instead of living in three registers
     if (kExtra) asm volatile("" : "+v"(es));  // across the whole loop (the kExtra instances spilled exactly those)
-    auto entries = [&](auto all_in_front) {
+    {
 #pragma unroll
       for (int u = 0; u < kBS; ++u) {
         const float4 a = sGeo[ring][es + u], a2 = sGeo2[ring][es + u], c = sCol[ring][es + u];
@@ -3116,7 +3090,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
         const float p2 = splat_p2(a.z, a.w, a2.x, dx, dy);
         const float G = __builtin_amdgcn_exp2f(p2);
         const float og = a2.y * G;
-        const bool contrib = (all_in_front() || (uint32_t)u < rem) && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
+        const bool contrib = (uint32_t)u < rem && !(p2 > 0.f) && !(og < 1.0f / 255.0f);  // alpha < 1/255 <=> o G < 1/255
         al[u] = contrib ? fminf(0.99f, og) : 0.f;
         Gc[u] = contrib ? G : 0.f;
         float cg = c.x * g0;
@@ -3126,9 +3100,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
         cgv[u] = cg;
         om[u] = 1.f - al[u];
       }
-    };
-    if (GSR_BWD_REM_FAST && __all(rem >= (uint32_t)kBS)) entries([] { return true; });  // (wave-uniform)
-    else entries([] { return false; });
+    }
     float Pl = 1.f, ql = 0.f;  // the segment's own product of (1 - alpha) and its replay of Q from 0, back to front
 #pragma unroll
     for (int u = kBS - 1; u >= 0; --u) {
@@ -3283,16 +3255,7 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   __syncthreads();
   const float T_final = inside ? p.final_T[(size_t)v * HW + pix] : 0.f;
   float Tb = T_final;                                              // (T, Q) at the back end of the batch: the same in all four
-#ifndef GSR_BWD_BG_SCALAR
-#define GSR_BWD_BG_SCALAR 0
-#endif
-#if GSR_BWD_BG_SCALAR  // the view's background through scalar loads (constant address space), as the forward does
-  typedef const __attribute__((address_space(4))) float* cfptr_b;
-  cfptr_b camc_b = reinterpret_cast<cfptr_b>(reinterpret_cast<uintptr_t>(p.views + __builtin_amdgcn_readfirstlane(v)));
-  float Qb = camc_b[37] * g0 + camc_b[38] * g1 + camc_b[39] * g2;
-#else
   float Qb = cam.bg[0] * g0 + cam.bg[1] * g1 + cam.bg[2] * g2;    // waves (behind the last splat Q = Bg / T_final = bg.g)
-#endif
   if (dbg) stamp[1] = __builtin_amdgcn_s_memrealtime();
   // T_final has to have ARRIVED before the loop: a load still counted as pending at the loop's entry makes the compiler wait
   // for "everything" at the first use of Tb inside the loop - on every iteration, right behind the gather just issued
@@ -4157,16 +4120,7 @@ static int ensure_bin_attributes(int* dev_out) {
   return GSR_OK;
 }
 static bool color_in_bin_for(const GsrDims& d, const Grid& g, int dev) {
-  const bool fused_bin = g.T <= kFusedMaxTiles && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_COUNT) && !(d.flags & GSR_FLAG_WINDOWED_BINNING);
-  // (views_per_set: one colour wave evaluates every view of its unit, so with many views a workgroup's 19 / V units are a few long
-  // tasks for its five colour waves - 8 views in one chain were 7 % slower that way than with the separate launch)
-#ifndef GSR_CIB_MAX_VPS
-#define GSR_CIB_MAX_VPS 4  // (more views per set: colour tasks in groups of <= 4 views exist - colour_role - but measured no better
-                          // than the colour pass as a launch of its own: 8 views of the 300 k scene 352.9 vs 342.2 us)
-#endif
-  return fused_bin && !GSR_ABL(d.flags, GSR_FLAG_ABLATE_NO_SH) && d.views_per_set <= GSR_CIB_MAX_VPS &&
-         ((g_color_bin_ok.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull) &&
-         g.T <= kColorBinMaxTiles && bin_lds_bytes(g.T, true) + 10400u <= 160u * 1024u;  // (+ 10.1 KB static)
+  return color_in_bin_by_dims(d, g) && ((g_color_bin_ok.load(std::memory_order_relaxed) >> (dev & 63)) & 1ull);
 }
 int gsr_colour_in_binning(const GsrDims* dims) {
   if (!dims_ok(dims)) return GSR_ERR_INVALID_ARGUMENT;
@@ -4299,8 +4253,8 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     const dim3 bgrid((unsigned)p.rows, (unsigned)V);
     const size_t shmem = bin_lds_bytes(p.g.T, color_in_bin);
     // (two plain workgroups per CU where the image's tile counters leave the LDS for it: LDS comes in 1280-byte steps)
-    const bool two_per_cu = GSR_BIN_TWO && p.g.T <= kBinTwoMaxT && 2 * align_up(shmem + 10400, 1280) <= (size_t)160 * 1024;
-    if (!color_in_bin && two_per_cu) hipLaunchKernelGGL((k_preprocess_bin<false, false, kBinTwoMaxT>), bgrid, dim3(kBinThreads), shmem, st, p);
+    const bool two_per_cu = bin_two_per_cu(p.g, color_in_bin);
+    if (two_per_cu) hipLaunchKernelGGL((k_preprocess_bin<false, false, kBinTwoMaxT>), bgrid, dim3(kBinThreads), shmem, st, p);
     else if (!color_in_bin) hipLaunchKernelGGL((k_preprocess_bin<false, false>), bgrid, dim3(kBinThreads), shmem, st, p);
     else if (p.shj) hipLaunchKernelGGL((k_preprocess_bin<true, true>), bgrid, dim3(kBinThreads), shmem, st, p);
     else hipLaunchKernelGGL((k_preprocess_bin<true, false>), bgrid, dim3(kBinThreads), shmem, st, p);
@@ -4314,7 +4268,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     hipLaunchKernelGGL(k_tile_prefix, dim3((unsigned)((VT + 15) / 16)), dim3(1024), 0, st, p);
   }
   const bool scan_in_emit = VT <= (size_t)kEmitScanMax && p.g.T <= kTileWindow;
-  if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3((unsigned)((VT + 1023) / 1024)), dim3(1024), 0, st, p);
+  if (!fused_bin && !scan_in_emit) hipLaunchKernelGGL(k_tile_scan, dim3(tile_scan_blocks(VT)), dim3(1024), 0, st, p);
   GSR_STAGE_DONE(2);
   GSR_MARK();
   if (!fused_bin) {

@@ -146,5 +146,7 @@ def gaussians_from_ply(source, device=None, opacity_is_logit: bool = False, scal
     scales = np.exp(d["scale"]) if scale_is_log else d["scale"]
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None].to(device) if device is not None else \
         torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))[None]
-    return Gaussians(means=to(d["xyz"]), covariances=None, harmonics=to(harmonics), opacities=to(opac), scales=to(scales),
+    from .sh_rotation import mark_external_harmonics
+
+    return Gaussians(means=to(d["xyz"]), covariances=None, harmonics=mark_external_harmonics(to(harmonics)), opacities=to(opac), scales=to(scales),
                      rotations=to(d["rot"][:, [1, 2, 3, 0]]), frames=None)

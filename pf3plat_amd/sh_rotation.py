@@ -104,10 +104,35 @@ def e3nn_band_rotations(rotations: Tensor, degree: int) -> list:
     return out
 
 
-def rotate_sh(sh_coefficients: Tensor, rotations: Tensor, basis: str = "e3nn") -> Tensor:
+# Harmonics that did NOT come out of the reference's adapter: `ply_export.gaussians_from_ply` registers the storage of the tensor it
+# returns here (views of it - a scene, a slice, a permutation - share the storage), so that `rotate_sh` can say when the reference's
+# e3nn-convention default is about to be applied to coefficients that live in the rasterizer's basis.
+_EXTERNAL_STORAGES: set = set()
+_warned_external = False
+
+
+def mark_external_harmonics(harmonics: Tensor) -> Tensor:
+    _EXTERNAL_STORAGES.add(harmonics.untyped_storage().data_ptr())
+    return harmonics
+
+
+def rotate_sh(sh_coefficients: Tensor, rotations: Tensor, basis: str | None = None) -> Tensor:
     """sh_coefficients (*#batch, n), n = (degree + 1)^2 <= 25; rotations (*#batch, 3, 3) -> (*batch, n).
-    basis: "e3nn" = the matrices the reference applies (src/misc/sh_rotation.py:24-34), "rasterizer" = the rotation in the basis
-    the rasterizer evaluates (see the module docstring)."""
+    basis: "e3nn" (the default when None) = the matrices the reference applies (src/misc/sh_rotation.py:24-34), "rasterizer" = the
+    rotation in the basis the rasterizer evaluates (see the module docstring).  Called WITHOUT a basis on harmonics that came from
+    `gaussians_from_ply` (an external scene: its coefficients were never rotated by the reference's adapter) it warns once - the e3nn
+    convention does not keep such a scene's colours still under a rotation, `basis="rasterizer"` does."""
+    global _warned_external
+    if basis is None:
+        basis = "e3nn"
+        if (not _warned_external and _EXTERNAL_STORAGES and sh_coefficients.numel() > 0
+                and sh_coefficients.untyped_storage().data_ptr() in _EXTERNAL_STORAGES):
+            import warnings
+
+            _warned_external = True
+            warnings.warn("rotate_sh: these harmonics come from gaussians_from_ply (an external scene); the default basis='e3nn' "
+                          "reproduces the reference's adapter for ITS OWN weights and does not keep an external scene's colours "
+                          "under a rotation - pass basis='rasterizer' (or basis='e3nn' to silence this).", UserWarning, stacklevel=2)
     n = sh_coefficients.shape[-1]
     degree = isqrt(n) - 1
     if (degree + 1) ** 2 != n or degree > 4:

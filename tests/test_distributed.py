@@ -98,6 +98,61 @@ def test_two_rank_gloo_sharded_render_matches_single_process(tmp_path, n_views):
         np.testing.assert_allclose(got[f"g{i}"], x.grad.numpy(), rtol=2e-4, atol=1e-6)
 
 
+def _worker_config5(rank, world, port, out_dir):
+    """configs[4] at a small size: rank r owns scene seed 50 + r (its own Gaussians - nothing is shared), renders its ONE target view,
+    and a single fused gather puts rank r's view in slot r on every rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pf3plat_amd
+        from pf3plat_amd import synthetic
+        from tests.oracle_backend import OracleBackend
+        from tests.util import install_backend
+
+        torch.set_num_threads(1)
+        install_backend(OracleBackend())
+        sc = synthetic.make_scene(50 + rank, 300, (16, 16), num_views=1)
+        out = pf3plat_amd.DecoderSplattingCUDA().forward(sc.gaussians, sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 16))
+        local = out.color[0].detach()  # (1, 3, 16, 16): this rank's shard of the job list
+        jobs = [(s, 0) for s in range(world)]  # (scene, view) jobs, one scene per rank (reference src/main.py:109)
+        assert shard_jobs(jobs, rank, world) == [(rank, 0)]
+        allv = gather_views(local, num_total=world)  # the one exchange step
+        assert allv.shape == (world, 3, 16, 16)
+        assert torch.equal(allv[rank], local[0])  # my view sits in MY slot
+        ones = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(ones)
+        assert int(ones.item()) == world
+        np.save(os.path.join(out_dir, f"views_rank{rank}.npy"), allv.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_rank_gloo_config5_one_scene_per_rank_one_fused_gather(tmp_path):
+    """World size EIGHT (the node the driver's scaling run uses), BASELINE configs[4] at a small G: 8 scenes (seeds 50 + r), one
+    target view each, one fused gather; every rank must end with the same (8, 3, h, w) tensor whose slot r is scene 50 + r's view."""
+    world = 8
+    mp.spawn(_worker_config5, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    import pf3plat_amd
+    from pf3plat_amd import synthetic
+    from tests.oracle_backend import OracleBackend
+    from tests.util import install_backend
+
+    got = [np.load(tmp_path / f"views_rank{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(got[r], got[0])  # every rank holds the same gathered tensor
+    old = install_backend(OracleBackend())
+    try:
+        for r in range(world):
+            sc = synthetic.make_scene(50 + r, 300, (16, 16), num_views=1)
+            want = pf3plat_amd.DecoderSplattingCUDA().forward(sc.gaussians, sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 16)).color[0, 0]
+            np.testing.assert_allclose(got[0][r], want.numpy(), rtol=1e-6, atol=1e-7)
+    finally:
+        install_backend(old)
+    sums = [float(got[0][r].sum()) for r in range(world)]
+    assert len(set(round(x, 4) for x in sums)) == world  # eight different scenes: a permuted slot would show
+
+
 def test_gather_is_identity_without_process_group():
     x = torch.arange(6.0).reshape(2, 3)
     assert gather_views(x) is x
@@ -158,3 +213,32 @@ def test_bench_py_rccl_communicator_world_size_1():
     assert d["gather_check"]["ok"], d["gather_check"]
     assert d["config5"]["views_per_s"] > 0 and "one fused" in d["config5"]["workload"]
     assert d["value"] > 0 and abs(d["value"] - d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+
+
+@pytest.mark.gpu
+def test_bench_py_eight_ranks_on_one_gpu_config5_leg():
+    """bench.py launched exactly as the driver launches the 8-GPU scaling run (`--nproc-per-node 8 ... --gpus 8`), all eight ranks
+    on the one GPU of the box, the exchange on gloo (BENCH_DIST_BACKEND; RCCL needs one GPU per rank), small scenes: the rank -> slot
+    mapping at world size 8 (every rank's last view in ITS slot of the gathered tensor, eight different checksums), the collective
+    saw eight ranks, the whole-job value counts eight, and the config-5 leg (8 scenes, seeds 50 + rank, one fused gather) ran.
+    Mirrors reference src/main.py:109 (one scene per GPU) and assets/evaluation_index_dl3dv_10view.json."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2",
+           "--windows", "2", "--preheat-ms", "0", "--gaussians", "20000", "--config5-gaussians", "16384"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 8 and d["rccl_ranks"] == 8 and d["dist_backend"] == "gloo" and d["scaling"] == "weak"
+    assert d["gather_check"]["ok"], d["gather_check"]
+    sums = d["gather_check"]["last_view_checksum_per_rank"]
+    assert len(sums) == 8 and len(set(round(x, 2) for x in sums)) == 8  # eight different scenes, each in its own slot
+    assert abs(d["value"] - 8 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
+    assert d["config"]["windows"]["R"] == 2 and len(d["config"]["windows"]["ms_per_step_of_each_window"]) == 2
+    assert d["config5"]["views_per_s"] > 0 and "8 scenes" in d["config5"]["workload"] and "one fused" in d["config5"]["workload"]

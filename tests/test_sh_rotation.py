@@ -117,3 +117,34 @@ def test_e3nn_convention_band_matrices():
     np.testing.assert_allclose(ref[..., 1:4].numpy(), (c[..., 1:4] @ a.T).numpy(), atol=1e-10)  # band 1: plain R c
     # a matrix that is not a rotation: the reference substitutes the identity (sh_rotation.py:21-22)
     np.testing.assert_allclose(sh_rotation.rotate_sh(c, 2.0 * a).numpy(), c.numpy())
+
+
+def test_default_basis_warns_once_on_harmonics_read_from_a_ply(tmp_path):
+    """`rotate_sh` without a basis on harmonics that came from `gaussians_from_ply` (a view of them included) warns - once - that the
+    reference's e3nn convention is about to be applied to coefficients in the rasterizer's basis; an explicit basis is silent, and
+    harmonics from anywhere else never warn."""
+    import warnings
+
+    import numpy as np
+
+    from pf3plat_amd import ply_export, sh_rotation
+
+    g = 5
+    rng = np.random.default_rng(0)
+    d = dict(xyz=rng.normal(size=(g, 3)).astype(np.float32), f_dc=rng.normal(size=(g, 3)).astype(np.float32),
+             f_rest=rng.normal(size=(g, 3 * 24)).astype(np.float32), opacity=rng.uniform(size=g).astype(np.float32),
+             scale=rng.normal(size=(g, 3)).astype(np.float32), rot=np.tile(np.array([1, 0, 0, 0], np.float32), (g, 1)))
+    gs = ply_export.gaussians_from_ply(d)
+    rot = torch.tensor([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    sh_rotation._warned_external = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        sh_rotation.rotate_sh(torch.randn(4, 25), rot)  # not from a ply: silent
+        sh_rotation.rotate_sh(gs.harmonics[0], rot, basis="rasterizer")  # explicit: silent
+        sh_rotation.rotate_sh(gs.harmonics[0], rot, basis="e3nn")
+        assert not w
+        out = sh_rotation.rotate_sh(gs.harmonics[0], rot)  # a view of the registered tensor, default basis
+        assert len(w) == 1 and "basis='rasterizer'" in str(w[0].message)
+        sh_rotation.rotate_sh(gs.harmonics, rot)  # once per process
+        assert len(w) == 1
+    assert torch.equal(out, sh_rotation.rotate_sh(gs.harmonics[0], rot, basis="e3nn"))  # the default is still the reference's convention
