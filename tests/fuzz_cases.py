@@ -1,0 +1,84 @@
+"""The random cases of the parity fuzz (tools/fuzz_parity.py) as a replayable sequence: case k of seed s is a pure function of
+(s, k) - the draws of a case do not depend on any result - so the worst cases a survey finds can be named and re-run
+(`named_case(seed, index)`; the regression cases of tests/test_gpu_parity.py and the rows of tools/parity_vs_fp64.py).
+Test infrastructure only."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from pf3plat_amd import _lib, synthetic
+from pf3plat_amd.rasterizer import RasterConfig
+from tests import gpu_util
+
+
+def draw_case(rng, build: bool = True):
+    """One random case: -> (desc, inputs) with inputs = (cfg, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra, capacity),
+    all CPU tensors.  build=False makes exactly the same draws (the generator ends in the same state) without building anything:
+    -> (desc, None)."""
+    n = int(rng.choice([0, 1, 7, 63, 64, 65, 500, 1023, 1024, 1025, 3000, 9000, 20000]))
+    h, w = int(rng.integers(1, 161)), int(rng.integers(1, 161))
+    if rng.random() < 0.15:
+        h, w = int(rng.choice([8, 16, 64, 128])), int(rng.choice([8, 16, 64, 128]))
+    sets = int(rng.choice([1, 1, 2]))
+    vps = int(rng.choice([1, 1, 2, 3]))
+    views = sets * vps
+    d_sh = int(rng.choice([1, 4, 9, 16, 25]))
+    use_sh = bool(rng.random() < 0.8)
+    with_extra = bool(rng.random() < 0.5)
+    windowed = bool(rng.random() < 0.2)
+    seed = int(rng.integers(0, 1 << 30))
+    nears = [float(rng.choice([1.0, 0.5, 2.0])) for _ in range(sets)]
+    scale_inv = [bool(rng.random() < 0.7) for _ in range(sets)]
+    extra_np = rng.uniform(0.5, 2.0, (views, n)).astype(np.float32) if with_extra else None
+    deg = int(round(d_sh ** 0.5)) - 1
+    flags = _lib.FLAG_WINDOWED_BINNING if windowed else 0
+    # native layouts and built-in extra modes (depth / disparity / relative disparity / log from the camera-space depth)
+    planar = bool(use_sh and rng.random() < 0.4)
+    cov33 = bool(rng.random() < 0.4)
+    emode = int(rng.integers(1, 5)) if (with_extra and rng.random() < 0.4) else 0
+    follows = bool(rng.random() < 0.5)  # the forward saves d rgb / d direction and the backward uses it instead of the harmonics
+    det = bool(rng.random() < 0.2)  # 64-bit fixed-point accumulators in the backward blend
+    gc_np = rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32)
+    ge_np = rng.uniform(0, 1, (views, h, w)).astype(np.float32) if with_extra else None
+    cap = None if rng.random() < 0.7 else int(rng.integers(1, 5000))
+    desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap,
+                planar=planar, cov33=cov33, emode=emode, follows=follows, det=det)
+    if not build:
+        return desc, None
+    scs = [synthetic.make_scene(seed + s, n, (h, w), num_views=vps, d_sh=d_sh, near=nears[s]) for s in range(sets)]
+    parts = [gpu_util.scene_tensors(sc, use_sh) for sc in scs]
+    means, cov6, opac, colors = (torch.cat([p[k] for p in parts], 0) for k in range(4))
+    vb = torch.cat([gpu_util.scene_viewbuf(sc, scale_inv[s]) for s, sc in enumerate(scs)], 0)
+    extra = torch.tensor(extra_np) if with_extra else None
+    if planar:
+        flags |= _lib.FLAG_SH_PLANAR
+        colors = colors.permute(0, 1, 3, 2).contiguous()
+    if cov33:
+        flags |= _lib.FLAG_COV_3X3
+        c = cov6
+        cov6 = torch.stack((c[..., 0], c[..., 1], c[..., 2], c[..., 1], c[..., 3], c[..., 4], c[..., 2], c[..., 4], c[..., 5]), -1).reshape(*c.shape[:-1], 3, 3).contiguous()
+    if emode:
+        flags |= emode << 4
+        extra = None
+    if follows:
+        flags |= _lib.FLAG_BACKWARD_FOLLOWS
+    if det:
+        flags |= _lib.FLAG_DETERMINISTIC
+    cfg = RasterConfig(views, sets, vps, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, flags)
+    gc = torch.tensor(gc_np)
+    ge = torch.tensor(ge_np) if with_extra else None
+    return desc, (cfg, vb, means, cov6, opac, colors, extra, gc, ge, cap)
+
+
+def named_case(seed: int, index: int):
+    """Case `index` of the sequence `np.random.default_rng(seed)` generates (the numbering of the survey's reports)."""
+    rng = np.random.default_rng(seed)
+    for _ in range(index):
+        draw_case(rng, build=False)
+    return draw_case(rng, build=True)
+
+
+# The worst cases of the surveys so far, by (seed, index): every one is one or two pixels whose threshold decision (alpha < 1/255,
+# T < 1e-4) falls the other way at fp32 rounding.  profiles/r04_m_fuzz_histogram_final_tree.md (seeds 7, 8), r04_fuzz_histogram.md (seed 4).
+WORST_CASES = ((8, 275), (8, 886), (7, 151), (7, 332), (7, 885), (7, 844), (8, 75), (7, 695), (4, 363))

@@ -360,6 +360,30 @@ def test_image_bits_do_not_depend_on_the_size_of_the_pair_workspace(n, hw, extra
             np.testing.assert_array_equal(eimg, images[0][1])
 
 
+@pytest.mark.parametrize("seed,index", [(8, 275), (8, 886), (7, 151), (7, 332), (7, 885), (7, 844), (8, 75), (7, 695), (4, 363)])
+def test_worst_fuzz_cases_of_the_surveys_as_named_regression_cases(seed, index):
+    """The worst cases the 5 000- / 2 000-case surveys found (profiles/r04_fuzz_histogram.md, r04_m_fuzz_histogram_final_tree.md), by
+    name: case `index` of `np.random.default_rng(seed)`'s sequence (tests/fuzz_cases.py replays the draws).  Each is one or two pixels
+    whose threshold decision falls the other way at fp32 rounding; all the suite's checks apply, and - the point of
+    profiles/r05_parity_vs_fp64.md - against the fp64 oracle the HIP path is no further off than the fp32 oracle itself."""
+    from tests.fuzz_cases import named_case
+    from tests.oracle_backend import OracleBackend
+
+    desc, (cfg, vb, means, cov6, opac, colors, extra, gc, ge, cap) = named_case(seed, index)
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
+    _all_checks(cfg, res, max_tiles=16)
+    o64 = OracleBackend(dtype=np.float64, threads=8)
+    c64, _, _, saved = o64.forward(cfg, vb, means, cov6, opac, colors, extra)
+    g64 = o64.backward(cfg, saved, vb, means, cov6, opac, colors, extra, gc, ge, True)
+    e_hip, e_o32 = parity_checks.rel_l2(res["hip"]["color"], c64.numpy()), parity_checks.rel_l2(res["oracle"]["color"], c64.numpy())
+    assert e_hip <= max(2.0 * e_o32, 5e-4), (desc, e_hip, e_o32)  # (a flipped pixel may fall on either side)
+    for nm, t in zip(("means", "cov6", "opac", "colors", "extra", "means2d"), g64):
+        if t is None or res["hip"]["grads"].get(nm) is None or not np.any(t.numpy()):
+            continue
+        a, b = parity_checks.rel_l2(res["hip"]["grads"][nm], t.numpy()), parity_checks.rel_l2(res["oracle"]["grads"][nm], t.numpy())
+        assert a <= max(2.0 * b, 1e-3), (desc, nm, a, b)
+
+
 def test_lazy_status_policy_poisons_and_raises_on_late_overflow():
     """Default policy: status read synchronously only the first time a shape is seen, verified asynchronously afterwards.
     If the pair count then outgrows the 1.25x workspace, that call's image is NaN and the next check raises (never silent)."""

@@ -17,51 +17,10 @@ from tests import gpu_util, parity_checks  # noqa: E402
 
 
 def one_case(rng):
-    n = int(rng.choice([0, 1, 7, 63, 64, 65, 500, 1023, 1024, 1025, 3000, 9000, 20000]))
-    h, w = int(rng.integers(1, 161)), int(rng.integers(1, 161))
-    if rng.random() < 0.15:
-        h, w = int(rng.choice([8, 16, 64, 128])), int(rng.choice([8, 16, 64, 128]))
-    sets = int(rng.choice([1, 1, 2]))
-    vps = int(rng.choice([1, 1, 2, 3]))
-    views = sets * vps
-    d_sh = int(rng.choice([1, 4, 9, 16, 25]))
-    use_sh = bool(rng.random() < 0.8)
-    with_extra = bool(rng.random() < 0.5)
-    windowed = bool(rng.random() < 0.2)
-    seed = int(rng.integers(0, 1 << 30))
-    scs = [synthetic.make_scene(seed + s, n, (h, w), num_views=vps, d_sh=d_sh, near=float(rng.choice([1.0, 0.5, 2.0]))) for s in range(sets)]
-    parts = [gpu_util.scene_tensors(sc, use_sh) for sc in scs]
-    means, cov6, opac, colors = (torch.cat([p[k] for p in parts], 0) for k in range(4))
-    vb = torch.cat([gpu_util.scene_viewbuf(sc, bool(rng.random() < 0.7)) for sc in scs], 0)
-    extra = torch.tensor(rng.uniform(0.5, 2.0, (views, n)).astype(np.float32)) if with_extra else None
-    deg = int(round(d_sh ** 0.5)) - 1
-    flags = _lib.FLAG_WINDOWED_BINNING if windowed else 0
-    # native layouts and built-in extra modes (depth / disparity / relative disparity / log from the camera-space depth)
-    planar = bool(use_sh and rng.random() < 0.4)
-    cov33 = bool(rng.random() < 0.4)
-    emode = int(rng.integers(1, 5)) if (with_extra and rng.random() < 0.4) else 0
-    if planar:
-        flags |= _lib.FLAG_SH_PLANAR
-        colors = colors.permute(0, 1, 3, 2).contiguous()
-    if cov33:
-        flags |= _lib.FLAG_COV_3X3
-        c = cov6
-        cov6 = torch.stack((c[..., 0], c[..., 1], c[..., 2], c[..., 1], c[..., 3], c[..., 4], c[..., 2], c[..., 4], c[..., 5]), -1).reshape(*c.shape[:-1], 3, 3).contiguous()
-    if emode:
-        flags |= emode << 4
-        extra = None
-    follows = bool(rng.random() < 0.5)  # the forward saves d rgb / d direction and the backward uses it instead of the harmonics
-    if follows:
-        flags |= _lib.FLAG_BACKWARD_FOLLOWS
-    det = bool(rng.random() < 0.2)  # 64-bit fixed-point accumulators in the backward blend
-    if det:
-        flags |= _lib.FLAG_DETERMINISTIC
-    cfg = RasterConfig(views, sets, vps, n, h, w, deg if use_sh else 0, d_sh if use_sh else 0, 4, with_extra, flags)
-    gc = torch.tensor(rng.uniform(0, 1, (views, 3, h, w)).astype(np.float32))
-    ge = torch.tensor(rng.uniform(0, 1, (views, h, w)).astype(np.float32)) if with_extra else None
-    cap = None if rng.random() < 0.7 else int(rng.integers(1, 5000))
-    desc = dict(n=n, hw=(h, w), sets=sets, vps=vps, d_sh=d_sh, use_sh=use_sh, extra=with_extra, windowed=windowed, seed=seed, cap=cap,
-                planar=planar, cov33=cov33, emode=emode, follows=follows, det=det)
+    from tests.fuzz_cases import draw_case
+
+    desc, (cfg, vb, means, cov6, opac, colors, extra, gc, ge, cap) = draw_case(rng)
+    n, views, h, w = cfg.num_gaussians, cfg.num_views, cfg.height, cfg.width
     one_case.last = desc
     one_case.inputs = (cfg, vb, means, cov6, opac, colors, extra, gc, ge)
     res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
