@@ -390,7 +390,10 @@ def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on
             nan_grad = any(torch.isnan(x.grad).any().item() for x in leaves)  # the reference's guard
             if k == 6:
                 assert any("returns NaN gradients" in str(c.message) for c in caught)
-                assert torch.isnan(img).all() and all(torch.isnan(x.grad).all() for x in leaves) and nan_grad
+                # (every gradient the operator hands out is NaN; the covariance leaf's lower triangle receives none at all - the
+                # reference's triu gather - and stays 0)
+                assert torch.isnan(img).all() and nan_grad and all(torch.isnan(x.grad).any() for x in leaves)
+                assert all(torch.isnan(leaves[k].grad).all() for k in (0, 2, 3))
             else:
                 assert not caught and torch.isfinite(img).all() and not nan_grad, k
             if k == 7:  # against the oracle-driven same code on the same parameter values
