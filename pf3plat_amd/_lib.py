@@ -101,6 +101,87 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str =
     return out
 
 
+TORCH_EXT_SRC = os.path.join(_HERE, "csrc", "gsr_torch.cpp")
+TORCH_EXT_PATH = os.path.join(_HERE, "_gsr_torch.so")
+
+
+def _torch_ext_stamp() -> str:
+    import hashlib
+
+    import torch
+
+    h = hashlib.sha256()
+    for path in (TORCH_EXT_SRC, HEADER):
+        with open(path, "rb") as f:
+            h.update(f.read())
+    h.update(torch.__version__.encode())
+    return h.hexdigest()
+
+
+def torch_ext_is_stale() -> bool:
+    try:
+        with open(TORCH_EXT_PATH + ".stamp") as f:
+            return not os.path.exists(TORCH_EXT_PATH) or f.read().strip() != _torch_ext_stamp()
+    except OSError:
+        return True
+
+
+def build_torch_ext(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/gsr_torch.cpp - the compiled autograd binding around the C ABI - against torch's headers into
+    pf3plat_amd/_gsr_torch.so (in-tree; host code only: g++, ~1 minute, no GPU needed).  It reaches libgsr_hip.so through dlopen at
+    run time, so the two are built independently."""
+    if not force and not torch_ext_is_stale():
+        return TORCH_EXT_PATH
+    import sysconfig
+
+    import torch
+    from torch.utils import cpp_extension as ce
+
+    cxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+    if cxx is None:
+        raise RuntimeError("no C++ compiler found for the torch binding (g++)")
+    inc = [f"-I{p}" for p in ce.include_paths()] + [f"-I{sysconfig.get_paths()['include']}", "-I/opt/rocm/include"]
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wno-deprecated-declarations", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch.compiled_with_cxx11_abi())}", "-DTORCH_EXTENSION_NAME=_gsr_torch", "-DTORCH_API_INCLUDE_EXTENSION_H",
+           *inc, TORCH_EXT_SRC, "-o", TORCH_EXT_PATH + ".tmp", f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
+           "-lamdhip64", "-ldl", f"-Wl,-rpath,{tlib}"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building the torch binding failed:\n" + " ".join(cmd) + "\n" + res.stdout[-4000:] + res.stderr[-8000:])
+    os.replace(TORCH_EXT_PATH + ".tmp", TORCH_EXT_PATH)
+    with open(TORCH_EXT_PATH + ".stamp", "w") as f:
+        f.write(_torch_ext_stamp() + "\n")
+    if verbose:
+        print("built", TORCH_EXT_PATH)
+    return TORCH_EXT_PATH
+
+
+_ext = None
+
+
+def load_torch_ext():
+    """Import the compiled binding (pf3plat_amd/_gsr_torch.so) and point it at the raster library.  Fails loudly if either is missing."""
+    global _ext
+    if _ext is not None:
+        return _ext
+    import importlib.util
+
+    import torch  # noqa: F401
+
+    if not os.path.exists(TORCH_EXT_PATH):
+        raise RuntimeError(f"{TORCH_EXT_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` first "
+                           "(the torch-facing path of the MI355X rasterizer is a compiled autograd function; there is no fallback)")
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: the MI355X rasterizer has no fallback path. Run `python -c 'import __graft_entry__ as g; g.build()'` first.")
+    spec = importlib.util.spec_from_file_location("pf3plat_amd._gsr_torch", TORCH_EXT_PATH)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.init(LIB_PATH)
+    _ext = mod
+    return mod
+
+
 _lib = None
 
 

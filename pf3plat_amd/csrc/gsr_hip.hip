@@ -2254,7 +2254,13 @@ __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* r
                                             const float pyf) {
   auto& sXY = lds.sXY; auto& sAB = lds.sAB; auto& sCO = lds.sCO; auto& sRG = lds.sRG; auto& sBE = lds.sBE;
   auto& sP = lds.sP;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#ifndef GSR_BLEND_SWAVE
+#define GSR_BLEND_SWAVE 1
+#endif
+  // (the wave's number in a SCALAR register: as `threadIdx.x >> 6` it lives in a vector register, and the choice of this wave's starting
+  // transmittance among Tb, t1, t2, t3 - wave-uniform - compiled into exec-mask branches and vector compares in every iteration)
+  const int wave = GSR_BLEND_SWAVE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   float Tb = s.Tb, Tmin = s.Tmin;
   f2 al[kFS / 2];                               // alphas of this wave's segment of the batch about to be accumulated
   uint32_t last = s.last, consumed = s.consumed;
@@ -2293,25 +2299,36 @@ __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* r
     float T = alive_in ? Tf : 0.f;
     float Tn[kFS];
     f2 w[kFS / 2];
+    float Tp = T;
 #pragma unroll
     for (int u = 0; u < kFS; u += 2) {
-      Tn[u] = T * om[u >> 1].x;
+      Tn[u] = Tp * om[u >> 1].x;
       Tn[u + 1] = Tn[u] * om[u >> 1].y;
-      w[u >> 1] = al[u >> 1] * f2{T, Tn[u]};
-      T = Tn[u + 1];
+      Tp = Tn[u + 1];
     }
-    const bool alive_out = !(T < 0.0001f);
+    const bool alive_out = !(Tp < 0.0001f);
+    // The weights alpha x (transmittance in front of the entry) are formed AFTER the decision, by the same packed multiply on either
+    // side: masked after the fact (a select per weight into fresh values) the two sides met with the weights in different registers
+    // and the USUAL side paid four 64-bit register copies per iteration for it.  alpha x 0 = +0 exactly: the same bits as the select.
     if (__any(alive_in && !alive_out)) {  // wave-uniform: some pixel's loop stops inside this segment
+      float Tq = T;
 #pragma unroll
       for (int u = 0; u < kFS; u += 2) {
         const bool alive0 = !(Tn[u] < 0.0001f), alive1 = !(Tn[u + 1] < 0.0001f);
-        w[u >> 1] = f2{alive0 ? w[u >> 1].x : 0.f, alive1 ? w[u >> 1].y : 0.f};
+        w[u >> 1] = al[u >> 1] * f2{alive0 ? Tq : 0.f, alive1 ? Tn[u] : 0.f};
+        Tq = Tn[u + 1];
         Tmin = alive0 ? Tn[u] : Tmin;
         Tmin = alive1 ? Tn[u + 1] : Tmin;
         last += (uint32_t)alive0 + (uint32_t)alive1;  // entries this pixel's loop went through (a prefix of the list)
       }
     } else {
-      Tmin = alive_out ? T : Tmin;
+      float Tq = T;
+#pragma unroll
+      for (int u = 0; u < kFS; u += 2) {
+        w[u >> 1] = al[u >> 1] * f2{Tq, Tn[u]};
+        Tq = Tn[u + 1];
+      }
+      Tmin = alive_out ? Tp : Tmin;
       last += alive_out ? (uint32_t)kFS : 0u;
     }
 #pragma unroll

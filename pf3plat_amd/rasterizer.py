@@ -138,30 +138,39 @@ class HipBackend:
     name = "hip"
 
     def __init__(self):
-        self.lib = _lib.load()
-        self.capacity_hint = {}  # (V, N, H, W) -> largest pair_capacity any call of that shape has needed (headroom included)
-        self.seen = {}  # (V, N, H, W) -> forwards of that shape whose status block has been read
-        self.sync_policy = "sync"  # or "lazy" (opt-in, inference / benchmarks): see forward()
-        # "sync" policy, calls that will be differentiated: once `defer_after` status blocks of a shape have been read, such a
-        # call is sized from the running maximum and its status is verified at the end of its own backward instead of in the
-        # forward (0: never - every forward blocks until its status has been read)
-        self.defer_after = 4
-        # what a DEFERRED forward of the default policy does when its workspace turns out too small (its image is NaN by then,
-        # so is the loss): "nan" (default) - its backward hands out NaN gradients with a one-line warning and raises nothing:
-        # the reference's training loop skips such a step by itself (model_wrapper.py:224-238 looks for NaN gradients) and every
-        # rank of a DDP job still enters the gradient all-reduce; "raise" - RuntimeError from that backward (round 4's behaviour).
-        # The opt-in "lazy" policy always raises at verification: its callers (inference loops, benchmarks) asked for that contract.
-        self.on_overflow = "nan"
-        self.defer_status = False  # True: lazy from the very first call (caller knows a safe capacity)
-        self.pending = []  # (pinned status copy, shape key, cfg, token, raises) of lazy / deferred forwards not yet verified
-        self.poisoned = set()  # tokens of deferred forwards found overflowed whose backward has not run yet
-        self._token = 0  # forwards handed a token so far (a workspace address is not an identity: freed memory is handed out again)
-        self.spin_us = 300.0  # longest busy-wait on a status copy before falling back to a blocking, error-reporting synchronize
-        self._pinned = []  # 16-byte pinned status buffers not in use
-        self._sizes = {}  # (cfg, capacity) -> (GsrDims, geom bytes, bin bytes, img bytes, backward scratch bytes)
-        self._lock = threading.Lock()  # pending / pools / caches: the process-wide backend may be called from several threads
-        self.workspace_cache = {}  # (cfg, capacity, device, stream) -> (geom, bin, img) of forwards that nothing differentiates
-        self.last_status = None
+        self.lib = _lib.load()  # the C ABI through ctypes: the plan API below (bench.py, tools/, the stage-level tests) and the small ops
+        # The torch-facing path - autograd function, workspaces, the pair-count policy and its state - is the compiled binding
+        # (csrc/gsr_torch.cpp, built by __graft_entry__.build()): `forward` / `backward` / `check_pending` below only hand over to it.
+        self._ext = _lib.load_torch_ext()
+        self._c = self._ext.Backend()
+        self._pinned = []  # 16-byte pinned status buffers of the plan API (read_status) not in use
+        self._sizes = {}  # (cfg, capacity) -> (GsrDims, geom bytes, bin bytes, img bytes, backward scratch bytes): plan API
+        self._lock = threading.Lock()  # pools / caches of the plan API
+        self._plan_ws = {}  # make_plan(reuse_workspaces=True): (cfg, capacity, device, stream) -> (geom, bin, img)
+
+    # ---- the pair-count policy and its state live in the compiled backend (one statement of each: csrc/gsr_torch.cpp::Backend)
+    # sync_policy: "sync" (default) | "lazy" (opt-in, inference / benchmarks): see forward()
+    # defer_after: "sync" policy, calls that will be differentiated - once that many status blocks of a shape have been read, such a
+    #   call is sized from the running maximum and its status is verified at the end of its own backward instead of in the forward
+    #   (0: never - every forward blocks until its status has been read)
+    # on_overflow: what a DEFERRED forward of the default policy does when its workspace turns out too small (its image is NaN by
+    #   then, so is the loss): "nan" (default) - its backward hands out NaN gradients with a one-line warning and raises nothing: the
+    #   reference's training loop skips such a step by itself (model_wrapper.py:224-238 looks for NaN gradients) and every rank of a
+    #   DDP job still enters the gradient all-reduce; "raise" - RuntimeError from that backward (round 4's behaviour).  The opt-in
+    #   "lazy" policy always raises at verification: its callers (inference loops, benchmarks) asked for that contract.
+    # defer_status: True = lazy from the very first call (caller knows a safe capacity)
+    # spin_us: longest busy-wait on a status copy before falling back to a blocking, error-reporting synchronize
+    sync_policy = property(lambda self: self._c.sync_policy, lambda self, v: setattr(self._c, "sync_policy", v))
+    defer_after = property(lambda self: self._c.defer_after, lambda self, v: setattr(self._c, "defer_after", int(v)))
+    on_overflow = property(lambda self: self._c.on_overflow, lambda self, v: setattr(self._c, "on_overflow", v))
+    defer_status = property(lambda self: self._c.defer_status, lambda self, v: setattr(self._c, "defer_status", bool(v)))
+    spin_us = property(lambda self: self._c.spin_us, lambda self, v: setattr(self._c, "spin_us", float(v)))
+    capacity_hint = property(lambda self: self._c.capacity_hint)  # (V, N, H, W) -> largest pair_capacity any call of that shape has needed (headroom included)
+    seen = property(lambda self: self._c.seen)  # (V, N, H, W) -> forwards of that shape whose status block has been read
+    pending = property(lambda self: self._c.pending)  # tokens of lazy / deferred forwards not yet verified
+    poisoned = property(lambda self: self._c.poisoned)  # tokens of deferred forwards found overflowed whose backward has not run yet
+    last_status = property(lambda self: self._c.last_status)
+    workspace_cache = property(lambda self: [None] * (self._c.workspace_cache_size + len(self._plan_ws)))  # (how many cached workspace sets are alive)
 
     def _rc(self, rc: int, what: str, stages=None):
         if rc == 0:
@@ -213,35 +222,10 @@ class HipBackend:
         camera centre (read through its stride: the reference passes `extrinsics[i, :3, 3]`, stride 4) and the background stay
         where they are on the device; the tan-fovs travel as launch arguments (floats, as the reference passes them) or as
         device pointers (tensors, as its orthographic wrapper passes them)."""
-        f32 = torch.float32
-
-        def dev_f32(t, shape=None):
-            t = t.to(device=device, dtype=f32)
-            return t if t.is_contiguous() else t.contiguous()
-
-        vm, pm, bg = dev_f32(rs.viewmatrix), dev_f32(rs.projmatrix), dev_f32(rs.bg)
-        cp = rs.campos.to(device=device, dtype=f32)
-        if cp.dim() != 1 or cp.shape[0] != 3:
-            cp = cp.reshape(3)
-        self._check_device(vm, pm, bg, cp)
-        tx = ty = 0.0
-        txd = tyd = None
-        if torch.is_tensor(rs.tanfovx):
-            txd = rs.tanfovx.reshape(-1)[:1].to(device=device, dtype=f32)
-        else:
-            tx = float(rs.tanfovx)
-        if torch.is_tensor(rs.tanfovy):
-            tyd = rs.tanfovy.reshape(-1)[:1].to(device=device, dtype=f32)
-        else:
-            ty = float(rs.tanfovy)
-        out = torch.empty((1, VIEW_FLOATS), dtype=f32, device=device)
-        stream = _stream_ptr(device)
-        with _on_device(device):
-            rc = self.lib.gsr_pack_view(_ptr(vm), _ptr(pm), _ptr(cp), int(cp.stride(0)), _ptr(bg), tx, ty, _ptr(txd), _ptr(tyd),
-                                        float(rs.scale_modifier), _ptr(out), stream)
-        if rc != 0:
-            raise RuntimeError(f"gsr_pack_view failed with code {rc}")
-        return out
+        tx, ty = rs.tanfovx, rs.tanfovy
+        tx_t, ty_t = torch.is_tensor(tx), torch.is_tensor(ty)
+        return self._ext.pack_view(rs.viewmatrix, rs.projmatrix, rs.campos, rs.bg, 0.0 if tx_t else float(tx), 0.0 if ty_t else float(ty),
+                                   tx if tx_t else None, ty if ty_t else None, float(rs.scale_modifier), torch.device(device))
 
     def workspace_layout(self, dims: _lib.GsrDims):
         offs = (ctypes.c_int64 * 8)()
@@ -274,13 +258,6 @@ class HipBackend:
             raise RuntimeError(f"gsr_capacity_for failed with code {need}")
         return int(need)
 
-    def _default_capacity(self, cfg: RasterConfig) -> int:
-        key = (cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width)
-        hint = self.capacity_hint.get(key)
-        if hint is not None:
-            return int(hint)
-        return cfg.num_views * max(8 * cfg.num_gaussians, 1 << 18)
-
     def _sized(self, cfg: RasterConfig, capacity: int):
         """(GsrDims, geom, bin, img, backward-scratch bytes) of a call shape: host-only library arithmetic, asked once per shape."""
         key = (cfg, int(capacity))
@@ -296,13 +273,11 @@ class HipBackend:
 
     def release_workspaces(self):
         """Drop the cached workspaces of the no-autograd path (up to 8 sets of geom / bin / img stay alive otherwise), the size
-        cache, and - after verifying them - the status copies still pending."""
-        if self.pending:
-            self.check_pending(wait=True)
+        caches, and - after verifying them - the status copies still pending."""
+        self._c.release_workspaces()
         with self._lock:
-            self.workspace_cache.clear()
+            self._plan_ws.clear()
             self._sizes.clear()
-            self.poisoned.clear()
 
     # ---- plans: outputs + workspaces allocated once, launch chains enqueued many times (bench / HIP-graph capture)
     def make_plan(self, cfg: RasterConfig, device, capacity: int, backward: bool = False, colors_shape=None,
@@ -316,7 +291,7 @@ class HipBackend:
         ws = None
         if reuse_workspaces:
             key = (cfg, int(capacity), str(device), _stream_ptr(device))
-            ws = self.workspace_cache.get(key)
+            ws = self._plan_ws.get(key)
         if ws is None:  # one allocation, three slices on 2 MiB boundaries (as separate large allocations would sit; the library
             # lays geom's own sub-arrays out on such boundaries too)
             al = (2 << 20) - 1
@@ -326,9 +301,9 @@ class HipBackend:
             ws = (whole[o_g:o_g + gb], whole[:bb], whole[o_i:o_i + ib])
             if reuse_workspaces:
                 with self._lock:
-                    if len(self.workspace_cache) >= 8:
-                        self.workspace_cache.clear()
-                    self.workspace_cache[key] = ws
+                    if len(self._plan_ws) >= 8:
+                        self._plan_ws.clear()
+                    self._plan_ws[key] = ws
         plan = dict(
             cfg=cfg, dims=_lib.GsrDims.from_buffer_copy(dims), device=device,  # (a copy: tools flip flag bits in a plan's dims)
             color=torch.empty((v, 3, h, w), dtype=f32, device=device),
@@ -477,10 +452,11 @@ class HipBackend:
         return self._take_status(host)
 
     # ---- autograd-facing calls: fresh outputs per call; fresh workspaces too (kept alive for the backward) unless the caller says
-    # that nothing will be differentiated
+    # that nothing will be differentiated.  Implemented by the compiled backend; these are its Python entry points (the tests and the
+    # tools call them directly; `rasterize_views` goes through the compiled autograd function, which calls the same C++).
     def forward(self, cfg: RasterConfig, viewbuf, means, cov6, opac, colors, extra, capacity: Optional[int] = None,
                 frames=None, reuse_workspaces: bool = False):
-        """-> (color, extra_img, radii, saved).  `saved` = (dims, geom, bin, img) for `backward`, or None with reuse_workspaces.
+        """-> (color, extra_img, radii, saved).  `saved` = (dims, geom, bin, img, token) for `backward`, or None with reuse_workspaces.
 
         reuse_workspaces: the caller will not differentiate this call (rasterize_views' no-autograd branch): geom / bin / img
         come from a per-(shape, device, stream) cache that the next call of the same shape overwrites, and nothing is handed
@@ -502,110 +478,18 @@ class HipBackend:
                   and verify it at the next call, at `check_pending()`, and - for a call that is differentiated - at the
                   end of its backward.  A workspace that turns out too small poisons that call's image with NaN
                   (k_tile_fwd) and raises at verification - it cannot pass silently."""
-        self._check_device(viewbuf, means, cov6, opac, colors, extra)
-        if self.pending:
-            self.check_pending()
-        dev = viewbuf.device
-        if torch.cuda.is_current_stream_capturing():  # nothing can be read back while a graph is being captured: the caller sizes
-            if capacity is None and (cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width) not in self.capacity_hint:
-                raise RuntimeError("gsr_forward under stream capture: pass `capacity` (or run the shape once outside the capture)")
-            plan = self.make_plan(cfg, dev, self._default_capacity(cfg) if capacity is None else int(capacity))
-            self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
-            return plan["color"], plan["extra_img"], plan["radii"], (plan["dims"], plan["geom"], plan["bin"], plan["img"], 0)
-        v, h, w, n = cfg.num_views, cfg.height, cfg.width, cfg.num_gaussians
-        key = (v, n, h, w)
-        known = capacity is None and key in self.capacity_hint
-        lazy = (self.sync_policy == "lazy" and known) or self.defer_status
-        if (not lazy and known and not reuse_workspaces and (cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS) and self.defer_after > 0
-                and self.seen.get(key, 0) >= self.defer_after):
-            lazy = True
-        cap = self._default_capacity(cfg) if capacity is None else int(capacity)
-        for attempt in range(3):
-            plan = self.make_plan(cfg, dev, cap, reuse_workspaces=reuse_workspaces and not lazy)
-            self.run_forward(plan, viewbuf, means, cov6, opac, colors, extra, frames=frames)
-            with self._lock:
-                self._token += 1
-                token = self._token
-            saved = None if reuse_workspaces else (plan["dims"], plan["geom"], plan["bin"], plan["img"], token)
-            out = (plan["color"], plan["extra_img"], plan["radii"], saved)
-            if n == 0 or v == 0:
-                return out
-            if lazy:
-                # (the 16 bytes are copied behind the forward on its stream; the caching allocator hands freed memory to later
-                # work of that stream only, so nothing here needs to keep the workspace alive)
-                raises = self.sync_policy == "lazy" or self.defer_status or self.on_overflow == "raise"
-                item = (self._status_copy(plan["bin"]), key, cfg, token, raises)
-                with self._lock:
-                    self.pending.append(item)
-                return out
-            self.last_status = st = self.read_status(plan)
-            with self._lock:
-                self.seen[key] = self.seen.get(key, 0) + 1
-            self._raise_hint(key, self.capacity_for(cfg, st))
-            if not st["overflow"]:
-                return out
-            cap = self.capacity_for(cfg, st, headroom=1.05)
-        raise RuntimeError("gsr_forward: pair workspace overflowed repeatedly")
-
-    def _raise_hint(self, key, need: int):
-        with self._lock:
-            self.capacity_hint[key] = max(int(need), int(self.capacity_hint.get(key, 0)))  # a running maximum: it never shrinks
+        color, extra_img, radii, saved = self._c.forward(_cfg_vec(cfg), viewbuf, means, cov6, opac, colors, extra, frames,
+                                                         -1 if capacity is None else int(capacity), bool(reuse_workspaces))
+        if saved is not None:
+            saved = (_lib.GsrDims(*saved[0]),) + tuple(saved[1:])
+        return color, extra_img, radii, saved
 
     def check_pending(self, wait: bool = False, only_token: Optional[int] = None):
         """Verify the status blocks of earlier lazy / deferred forwards (those whose async copy has landed; all if `wait`;
         `only_token`: just that forward, waiting for it).  An overflowed forward of the lazy policy (or with
         `on_overflow = "raise"`) raises here; an overflowed DEFERRED forward of the default policy is remembered in
         `self.poisoned` - its backward returns NaN gradients - and a warning is issued."""
-        with self._lock:
-            items, self.pending = self.pending, []
-        keep, failed, warned = [], None, None
-        for item in items:
-            host, key, cfg, token, raises = item
-            mine = only_token is not None and token == only_token
-            if only_token is not None and not mine:
-                keep.append(item)
-                continue
-            if wait or mine:
-                self._wait_status(host)
-            elif not self._arrived(host):
-                keep.append(item)
-                continue
-            self.last_status = st = self._take_status(host)
-            with self._lock:
-                self.seen[key] = self.seen.get(key, 0) + 1
-            self._raise_hint(key, self.capacity_for(cfg, st))
-            if st["overflow"]:
-                if raises:
-                    failed = st["num_pairs"] if failed is None else failed
-                else:
-                    warned = st["num_pairs"]
-                    with self._lock:
-                        self.poisoned.add(token)
-        if keep:
-            with self._lock:
-                self.pending = keep + self.pending
-        if warned is not None:
-            warnings.warn(f"pf3plat_amd rasterizer: a training forward needed {warned} (tile, Gaussian) pairs, more than 1.25x the "
-                          "largest count seen for its shape: its image is NaN and its backward returns NaN gradients (the step is "
-                          "skipped by a NaN-gradient guard such as the reference's); the workspace has been enlarged for the next step.",
-                          RuntimeWarning, stacklevel=3)
-        if failed is not None:
-            raise RuntimeError(
-                f"an earlier gsr_forward needed {failed} pairs but its workspace was smaller; that call's image was "
-                "poisoned with NaN. The capacity hint has been raised - re-run the step (or use sync_policy='sync' with "
-                "defer_after = 0).")
-
-    def _verify_own_forward(self, token: int) -> bool:
-        """Backward of a lazily sized forward: its status must be known before its gradients are handed out (an overflowed
-        forward binned nothing; the backward kernels over it are harmless - no pixel has a contributor - but their result means
-        nothing).  -> True when that forward overflowed and the policy is to answer with NaN gradients instead of raising."""
-        if self.pending:
-            self.check_pending(only_token=token)
-        if self.poisoned and token in self.poisoned:
-            with self._lock:
-                self.poisoned.discard(token)
-            return True
-        return False
+        self._c.check_pending(bool(wait), -1 if only_token is None else int(only_token))
 
     def backward(self, cfg: RasterConfig, saved, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img,
                  want_means2d: bool, rows_in_workspace: bool = False, frames=None, want_views=False):
@@ -616,51 +500,14 @@ class HipBackend:
         if saved is None:
             raise RuntimeError("this forward ran with reuse_workspaces=True (nothing was to be differentiated): it has no backward")
         dims, geom, binb, img, token = saved
-        dev = viewbuf.device
-        v, n, s = cfg.num_views, cfg.num_gaussians, cfg.num_sets
-        f32 = torch.float32
-        own_rows = rows_in_workspace and bool(cfg.flags & _lib.FLAG_BACKWARD_FOLLOWS)
-        plan = dict(cfg=cfg, dims=dims, device=dev, geom=geom, bin=binb, img=img,
-                    scratch=None if own_rows else torch.empty(max(16, self._sized(cfg, int(dims.pair_capacity))[4]), dtype=torch.uint8, device=dev),
-                    d_means=torch.empty((s, n, 3), dtype=f32, device=dev),
-                    d_cov6=torch.empty((s, n, 7) if cfg.scale_rot else (s, n, 3, 3) if cfg.flags & _lib.FLAG_COV_3X3 else (s, n, 6),
-                                       dtype=f32, device=dev),
-                    d_opac=torch.empty((s, n), dtype=f32, device=dev), d_colors=torch.empty_like(colors),
-                    d_extra=torch.empty((v, n), dtype=f32, device=dev) if (cfg.has_extra and not (cfg.flags >> 4) & 7) else None,
-                    d_means2d=torch.empty((v, n, 3), dtype=f32, device=dev) if want_means2d else None)
-        if n > 0 and v > 0:
-            g_color = _f32c(g_color)
-            if cfg.has_extra:
-                g_extra_img = (torch.zeros((v, cfg.height, cfg.width), dtype=f32, device=dev) if g_extra_img is None
-                               else _f32c(g_extra_img))
-            d_views = torch.empty((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
-            self.run_backward(plan, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra_img, want_means2d, frames=frames,
-                              d_views=d_views, depth_term_only=(want_views == "depth"))
-        else:
-            d_views = torch.zeros((v, VIEW_FLOATS), dtype=f32, device=dev) if want_views else None
-        # (after the launches: the device works on the backward while the host waits for the forward's status, if it has to)
-        out = plan["d_means"], plan["d_cov6"], plan["d_opac"], plan["d_colors"], plan["d_extra"], plan["d_means2d"]
-        out = out + (d_views,) if want_views else out
-        if self._verify_own_forward(token):  # the forward had overflowed (deferred status, default policy): NaN, not numbers
-            for t in out:
-                if t is not None:
-                    t.fill_(float("nan"))
-        return out
+        dimsv = [getattr(dims, n) for n, _ in dims._fields_]
+        return self._c.backward(_cfg_vec(cfg), dimsv, geom, binb, img, int(token), viewbuf, means, cov6, opac, colors, extra, g_color,
+                                g_extra_img if cfg.has_extra else None, bool(want_means2d), bool(rows_in_workspace), frames,
+                                2 if want_views == "depth" else (1 if want_views else 0))
 
     def setup_views(self, extrinsics, intrinsics, near, far, background, scale_invariant: bool = True) -> Tensor:
         """(V,4,4) c2w, (V,3,3), (V,), (V,), (3,) or (V,3) -> (V,48) camera records, one kernel launch (gsr_setup_views)."""
-        self._check_device(extrinsics, intrinsics, near, far, background)
-        v = extrinsics.shape[0]
-        f32 = torch.float32
-        ext, intr, nr, fr, bg = _f32c(extrinsics), _f32c(intrinsics), _f32c(near), _f32c(far), _f32c(background)
-        out = torch.empty((v, VIEW_FLOATS), dtype=f32, device=ext.device)
-        stream = _stream_ptr(ext.device)
-        with _on_device(ext.device):
-            rc = self.lib.gsr_setup_views(v, _ptr(ext), _ptr(intr), _ptr(nr), _ptr(fr), _ptr(bg), 3 if bg.dim() == 2 else 0,
-                                          int(bool(scale_invariant)), _ptr(out), stream)
-        if rc != 0:
-            raise RuntimeError(f"gsr_setup_views failed with code {rc}")
-        return out
+        return self._ext.setup_views(extrinsics, intrinsics, near, far, background, bool(scale_invariant))
 
     def setup_views_backward(self, viewbuf: Tensor, d_views: Tensor) -> Tensor:
         """(V, 48) camera records + their gradient -> dL/d extrinsics (V, 4, 4), one launch (gsr_setup_views_backward)."""
@@ -710,6 +557,12 @@ class HipBackend:
         return present.bool()
 
 
+def _cfg_vec(cfg: RasterConfig):
+    """RasterConfig as the twelve integers the compiled backend takes."""
+    return [cfg.num_views, cfg.num_sets, cfg.views_per_set, cfg.num_gaussians, cfg.height, cfg.width, cfg.sh_degree, cfg.sh_coeffs,
+            cfg.max_sh_eval, int(cfg.has_extra), int(cfg.flags), int(cfg.scale_rot)]
+
+
 def cfg_repr(dims) -> str:
     return ", ".join(f"{n}={getattr(dims, n)}" for n, _ in dims._fields_)
 
@@ -729,6 +582,9 @@ def get_backend():
 # autograd
 # --------------------------------------------------------------------------------------------------
 class _RasterizeViews(torch.autograd.Function):
+    """The operator's autograd node for backend objects OTHER than the HIP one (tests/oracle_backend.py under the host wrappers on
+    CPU).  The product path does not come here: `rasterize_views` hands HipBackend calls to the compiled function."""
+
     @staticmethod
     def forward(ctx, means, cov6, opac, colors, extra, means2d, viewbuf, cfg: RasterConfig, frames=None, camera_gradient="full"):
         backend = get_backend()
@@ -830,12 +686,18 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags,
                        bool(scale_rot))
     viewbuf = _f32c(viewbuf)
-    if not (flags & _lib.FLAG_BACKWARD_FOLLOWS):  # nothing here can be differentiated: no autograd node, no saved workspaces
-        color, extra_img, radii, _ = get_backend().forward(cfg, viewbuf, means, cov6, opacities, colors, extra, frames=frames,
-                                                           reuse_workspaces=True)
-        return color, (extra_img if has_extra else None), radii
     if camera_gradient not in ("full", "depth"):
         raise ValueError("camera_gradient must be 'full' or 'depth'")
+    backend = get_backend()
+    if isinstance(backend, HipBackend):
+        # the product path: the compiled autograd function (csrc/gsr_torch.cpp::RasterizeFn; a plain call when nothing can be differentiated)
+        return backend._ext.rasterize(backend._c, means, cov6, opacities, colors, extra, means2d, viewbuf, _cfg_vec(cfg), frames,
+                                      2 if camera_gradient == "depth" else 1)
+    # (any other backend object - tests slide the CPU oracle under the host wrappers - goes through the Python autograd function below)
+    if not (flags & _lib.FLAG_BACKWARD_FOLLOWS):  # nothing here can be differentiated: no autograd node, no saved workspaces
+        color, extra_img, radii, _ = backend.forward(cfg, viewbuf, means, cov6, opacities, colors, extra, frames=frames,
+                                                     reuse_workspaces=True)
+        return color, (extra_img if has_extra else None), radii
     color, extra_img, radii = _RasterizeViews.apply(means, cov6, opacities, colors, extra, means2d, viewbuf, cfg, frames, camera_gradient)
     return color, (extra_img if has_extra else None), radii
 
@@ -866,10 +728,13 @@ def views_from_cameras(extrinsics: Tensor, intrinsics: Tensor, near: Tensor, far
     """(V,4,4) camera-to-world, (V,3,3) normalised intrinsics, (V,), (V,), (3,) | (V,3) -> (V,48) camera records in one launch
     (the arithmetic of cuda_splatting.py:64-71, :80-87).  pose_gradients: keep a gradient path from the render back to
     `extrinsics` (the reference has none through its rasterizer: opt-in)."""
+    backend = get_backend()
+    if isinstance(backend, HipBackend):  # (compiled: gsr_setup_views, and gsr_setup_views_backward as the node's backward)
+        return backend._ext.views_from_cameras(extrinsics, intrinsics, near, far, background, bool(scale_invariant), bool(pose_gradients))
     if pose_gradients and torch.is_grad_enabled() and extrinsics.requires_grad:
         return _SetupViews.apply(extrinsics, intrinsics, near, far, background, bool(scale_invariant))
     with torch.no_grad():
-        return get_backend().setup_views(extrinsics, intrinsics, near, far, background, scale_invariant)
+        return backend.setup_views(extrinsics, intrinsics, near, far, background, scale_invariant)
 
 
 class _CovFromScaleRot(torch.autograd.Function):
