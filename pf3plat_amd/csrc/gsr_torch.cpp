@@ -233,7 +233,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
   // ---- the autograd-facing forward: fresh outputs per call; fresh workspaces too (kept for the backward) unless the caller says that
   // nothing will be differentiated (reuse_workspaces)
   ForwardOut forward(const Cfg& cfg, const Tensor& viewbuf, const Tensor& means, const Tensor& cov, const Tensor& opac, const Tensor& colors,
-                     const Tensor& extra, const Tensor& frames, int64_t capacity /* <= 0: policy */, bool reuse_workspaces) {
+                     const Tensor& extra, const Tensor& frames, int64_t capacity /* <= 0: policy */, bool reuse_workspaces, bool one_view = false) {
     check_device({&viewbuf, &means, &cov, &opac, &colors, &extra, &frames});
     if (!pending_.empty()) check_pending(false, -1);
     const at::Device dev = viewbuf.device();
@@ -263,7 +263,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
     }
     int64_t cap = capacity > 0 ? capacity : default_capacity(cfg);
     for (int attempt = 0; attempt < 3; ++attempt) {
-      Plan plan = make_plan(cfg, dev, cap, reuse_workspaces && !lazy);
+      Plan plan = make_plan(cfg, dev, cap, reuse_workspaces && !lazy, one_view);
       run_forward(plan, cfg, viewbuf, means, cov, opac, colors, extra, frames, stream);
       int64_t token;
       {
@@ -444,7 +444,8 @@ class Backend : public std::enable_shared_from_this<Backend> {
 
   // outputs + ONE allocation for the three workspaces, sliced on 2 MiB boundaries (as separate large allocations would sit; the
   // library lays geom's own sub-arrays out on such boundaries too).  reuse: the workspaces come from a per-(shape, stream) cache.
-  Plan make_plan(const Cfg& cfg, const at::Device& dev, int64_t capacity, bool reuse) {
+  // one_view (V = 1): the image as (3, H, W) and the radii as (N) - what the per-view operator returns - instead of views of them
+  Plan make_plan(const Cfg& cfg, const at::Device& dev, int64_t capacity, bool reuse, bool one_view = false) {
     const Sizes sz = sized(cfg, capacity);
     Plan p;
     p.dims = cfg.dims(capacity);
@@ -470,6 +471,11 @@ class Backend : public std::enable_shared_from_this<Backend> {
     p.bin = whole.narrow(0, 0, (int64_t)sz.bin);
     p.geom = whole.narrow(0, o_g, (int64_t)sz.geom);
     p.img = whole.narrow(0, o_i, (int64_t)sz.img);
+    if (one_view && cfg.num_views == 1 && !cfg.has_extra) {
+      p.color = at::empty({3, cfg.height, cfg.width}, f32);
+      p.radii = at::empty({cfg.num_gaussians}, u8.dtype(at::kInt));
+      return p;
+    }
     p.color = at::empty({cfg.num_views, 3, cfg.height, cfg.width}, f32);
     if (cfg.has_extra) p.extra_img = at::empty({cfg.num_views, cfg.height, cfg.width}, f32);
     p.radii = at::empty({cfg.num_views, cfg.num_gaussians}, u8.dtype(at::kInt));
@@ -721,6 +727,41 @@ pybind11::tuple rasterize(PyBackend& pb, const Tensor& means, const Tensor& cov,
   return pybind11::make_tuple(color, e, radii);
 }
 
+// The per-view operator with upstream's call shape (reference cuda_splatting.py:99-124: one settings object, one call per view) in ONE
+// crossing from Python: the camera record (gsr_pack_view), the V = 1 views of the inputs, the call shape, the operator, the [0]s.
+// tanfov*: floats, or tensors (the orthographic wrapper passes tensors); cov3d: (n, 6) or anything that reshapes to it.
+pybind11::tuple rasterize_one_view(PyBackend& pb, int64_t height, int64_t width, double tanfovx, double tanfovy, const c10::optional<Tensor>& tanfovx_t,
+                                   const c10::optional<Tensor>& tanfovy_t, const Tensor& bg, double scale_modifier, const Tensor& viewmatrix,
+                                   const Tensor& projmatrix, int64_t sh_degree, const Tensor& campos, bool prefiltered, bool debug, const Tensor& means3d,
+                                   const c10::optional<Tensor>& means2d, const Tensor& opacities, const c10::optional<Tensor>& shs,
+                                   const c10::optional<Tensor>& colors_precomp, const Tensor& cov3d) {
+  const int64_t n = means3d.size(0);
+  const bool use_sh = shs.has_value();
+  const Tensor viewbuf = pack_view(viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, tanfovx_t.has_value() ? *tanfovx_t : Tensor(),
+                                   tanfovy_t.has_value() ? *tanfovy_t : Tensor(), scale_modifier, means3d.device());
+  const Tensor& col_in = use_sh ? *shs : *colors_precomp;
+  if (use_sh && col_in.dim() != 3) throw pybind11::value_error("shs must be (N, M, 3)");
+  TORCH_CHECK(cov3d.numel() == 6 * n && opacities.numel() == n, "cov3D_precomp must hold (N, 6) values and opacities N");
+  int64_t flags = (debug ? GSR_FLAG_DEBUG : 0) | (prefiltered ? GSR_FLAG_PREFILTERED : 0) | (at::globalContext().deterministicAlgorithms() ? GSR_FLAG_DETERMINISTIC : 0);
+  const bool grad = at::GradMode::is_enabled() && (means3d.requires_grad() || cov3d.requires_grad() || opacities.requires_grad() || col_in.requires_grad() ||
+                                                   (means2d.has_value() && means2d->defined() && means2d->requires_grad()));
+  if (!grad) {
+    // nothing can be differentiated (the reference's inference loop): the arrays go to the library as they are - the call shape says
+    // V = 1, S = 1 - and the image / radii are allocated in the shapes the operator returns: no view op on either side of the call
+    const std::vector<int64_t> cfgv{1, 1, 1, n, height, width, sh_degree, use_sh ? col_in.size(1) : 0, 4, 0, flags, 0};
+    ForwardOut o = pb.be().forward(cfg_from(cfgv), viewbuf, f32c(means3d), f32c(cov3d), f32c(opacities), f32c(col_in), Tensor(), Tensor(), -1, true, true);
+    return pybind11::make_tuple(o.color, o.radii);
+  }
+  flags |= GSR_FLAG_BACKWARD_FOLLOWS;  // the forward zero-fills the backward's accumulator rows on its way
+  const Tensor means = f32c(means3d.unsqueeze(0)), cov = f32c(cov3d.reshape({n, 6}).unsqueeze(0)), opac = f32c(opacities.reshape({n}).unsqueeze(0));
+  const Tensor colors = f32c(col_in.unsqueeze(0));
+  c10::optional<Tensor> m2;
+  if (means2d.has_value() && means2d->defined()) m2 = means2d->unsqueeze(0);
+  const std::vector<int64_t> cfgv{1, 1, 1, n, height, width, sh_degree, use_sh ? colors.size(2) : 0, 4, 0, flags, 0};
+  pybind11::tuple r = rasterize(pb, means, cov, opac, colors, c10::nullopt, m2, viewbuf, cfgv, c10::nullopt, 1);
+  return pybind11::make_tuple(r[0].cast<Tensor>().select(0, 0), r[2].cast<Tensor>().select(0, 0));
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -774,6 +815,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            });
   m.def("rasterize", &rasterize, pybind11::arg("backend"), pybind11::arg("means"), pybind11::arg("cov"), pybind11::arg("opac"), pybind11::arg("colors"),
         pybind11::arg("extra"), pybind11::arg("means2d"), pybind11::arg("viewbuf"), pybind11::arg("cfg"), pybind11::arg("frames"), pybind11::arg("camera_gradient"));
+  m.def("rasterize_one_view", &rasterize_one_view);
   m.def("views_from_cameras", &views_from_cameras);
   m.def("setup_views", &setup_views_raw);
   m.def("pack_view", [](const Tensor& vm, const Tensor& pm, const Tensor& cp, const Tensor& bg, double tx, double ty, const c10::optional<Tensor>& txt,

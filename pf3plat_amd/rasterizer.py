@@ -763,8 +763,20 @@ class GaussianRasterizer(nn.Module):
     """Per-view operator with the upstream call signature (reference cuda_splatting.py:113-124)."""
 
     def __init__(self, raster_settings: GaussianRasterizationSettings):
-        super().__init__()
-        self.raster_settings = raster_settings
+        # The reference builds one of these PER VIEW (cuda_splatting.py:113) and only ever calls it.  nn.Module.__init__ (a dozen
+        # ordered dicts, ~7 us) is therefore put off until something asks for module state (`.to()`, `.parameters()`, hooks, repr ...).
+        object.__setattr__(self, "raster_settings", raster_settings)
+
+    def __getattr__(self, name):
+        if "_parameters" not in self.__dict__:  # module state asked for the first time: become a regular nn.Module now
+            kept = dict(self.__dict__)  # (whatever has been set meanwhile - raster_settings, a `training` flag - survives)
+            nn.Module.__init__(self)
+            self.__dict__.update(kept)
+            return getattr(self, name)
+        return super().__getattr__(name)
+
+    def __call__(self, *args, **kwargs):  # (nn.Module's hook machinery costs ~3 us per call; the reference makes one call per view)
+        return self.forward(*args, **kwargs)
 
     def _viewbuf(self, device) -> Tensor:
         return get_backend().pack_view(self.raster_settings, device)
@@ -788,6 +800,14 @@ class GaussianRasterizer(nn.Module):
         n = means3D.shape[0]
         if cov3D_precomp is None:
             cov3D_precomp = _cov3d_from_scale_rotation(scales.float(), rotations.float(), float(rs.scale_modifier))
+        backend = get_backend()
+        if isinstance(backend, HipBackend):  # the product path: one crossing into the compiled binding per view
+            tx, ty = rs.tanfovx, rs.tanfovy
+            tx_t, ty_t = torch.is_tensor(tx), torch.is_tensor(ty)
+            return backend._ext.rasterize_one_view(
+                backend._c, int(rs.image_height), int(rs.image_width), 0.0 if tx_t else float(tx), 0.0 if ty_t else float(ty),
+                tx if tx_t else None, ty if ty_t else None, rs.bg, float(rs.scale_modifier), rs.viewmatrix, rs.projmatrix, int(rs.sh_degree),
+                rs.campos, bool(rs.prefiltered), bool(rs.debug), means3D, means2D, opacities, shs, colors_precomp, cov3D_precomp)
         use_sh = shs is not None
         colors = shs if use_sh else colors_precomp
         color, _, radii = rasterize_views(
