@@ -817,15 +817,25 @@ def main():
                 import pf3plat_amd
                 from pf3plat_amd.types import Gaussians
 
-                def time_calls(fn, reps, warm):
-                    for _ in range(warm):
+                def time_calls(fn, reps, warm, windows=3):
+                    """s per call: at least `warm` untimed calls AND (unless --preheat-ms 0) 120 ms of them - every leg here follows
+                    host-side work during which the device idled and fell back to its low-power clocks (a leg timed after five warm-up
+                    calls read 10-15 % slow: round 4's 8-view and 48-view figures did) - then the median of `windows` windows of `reps` calls."""
+                    t_w, k = time.perf_counter(), 0
+                    while k < warm or (args.preheat_ms > 0 and time.perf_counter() - t_w < 0.12):
                         fn()
+                        k += 1
+                        if k % 16 == 0:
+                            torch.cuda.synchronize()
                     torch.cuda.synchronize()
-                    t0_ = time.perf_counter()
-                    for _ in range(reps):
-                        fn()
-                    torch.cuda.synchronize()
-                    return (time.perf_counter() - t0_) / reps
+                    ws_ = []
+                    for _ in range(windows):
+                        t0_ = time.perf_counter()
+                        for _ in range(reps):
+                            fn()
+                        torch.cuda.synchronize()
+                        ws_.append((time.perf_counter() - t0_) / reps)
+                    return sorted(ws_)[len(ws_) // 2]
 
                 c8 = views8_call()
                 t8 = time_calls(lambda: be.run_forward(c8["plan"], c8["vb"], *c8["ins"]), 40, 5)
@@ -898,14 +908,7 @@ def main():
                 be.run_forward(plan48, vb48, *in48)
                 st48 = be.read_status(plan48)
                 plan48 = be.make_plan(cfg48, dev, capacity=be.capacity_for(cfg48, st48, headroom=1.1))
-                for _ in range(3):
-                    be.run_forward(plan48, vb48, *in48)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(10):
-                    be.run_forward(plan48, vb48, *in48)
-                torch.cuda.synchronize()
-                t48 = (time.perf_counter() - t0) / 10
+                t48 = time_calls(lambda: be.run_forward(plan48, vb48, *in48), 10, 3)
                 assert not be.read_status(plan48)["overflow"]
                 # SURVEY 8d bytes of the call: the Gaussians are read once for the set (means, cov, opacity, SH of those some view sees),
                 # everything per-view (projected records, keys, gather, image) once per view
@@ -956,14 +959,7 @@ def main():
                 bgc = torch.zeros(3, device=dev)
 
                 def bench_call(fn, reps=20, warm=3):
-                    for _ in range(warm):
-                        fn()
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    for _ in range(reps):
-                        fn()
-                    torch.cuda.synchronize()
-                    return (time.perf_counter() - t0) / reps
+                    return time_calls(fn, reps, warm)
 
                 def dropin_fwd():
                     with torch.no_grad():

@@ -27,7 +27,9 @@ FLAG_BACKWARD_FOLLOWS = 0x10000  # forward zero-fills the backward's accumulator
 FLAG_FULL_LISTS = 0x20000  # test aid: every per-tile list depth-ordered to its end (default: the nearest ~512 entries + what the blend walks)
 FLAG_WINDOWED_BINNING = 0x4000  # test aid: the windowed binning path on an image small enough for the fused one
 
-HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared"]
+# (-falign-functions=4096: every kernel starts on a page of its own.  Without it the layout of one kernel's hot loop in the instruction
+# cache moved with the size of the kernels in front of it: adding an unrelated instance cost the single-view forward 0.4-0.5 us)
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-falign-functions=4096", "-fPIC", "-shared"]
 
 
 class GsrDims(ctypes.Structure):

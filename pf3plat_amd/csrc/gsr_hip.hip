@@ -2593,9 +2593,6 @@ __device__ __forceinline__ void bitonic_whole_list(unsigned long long* sk, uint3
 #ifndef GSR_PF_COMPACT_MIN_TILES
 #define GSR_PF_COMPACT_MIN_TILES (5 * kCUs)  // calls with more tiles than this take the compact instance
 #endif
-#ifndef GSR_PF_COMPACT_EXTRA
-#define GSR_PF_COMPACT_EXTRA 0
-#endif
 // kCompact (calls with more tiles than the chip holds at once: many views): 1024 depth buckets instead of 2048, their counters /
 // cursors packed two to a 32-bit word (a cursor is at most 2048: sixteen bits; the LDS atomic adds 1 or 1 << 16) - 25.7 KB of LDS
 // instead of 31.9, and the instance is built for six waves per SIMD (80 VGPRs): SIX workgroups per CU instead of five.  The single
@@ -4313,13 +4310,12 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     // ranked whole anyway - many small tiles, e.g. one 1024 x 1024 view of the 300 k scene: 78 entries per tile - and those are
     // better off with k_tile_fwd's smaller LDS footprint (five workgroups per CU instead of four: 192 vs 217 us for that view)
     else if (p.stride <= 2048u && p.stride > (uint32_t)(kPrefix + kPrefix / 4) && p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {
-      // (more tiles than five workgroups per CU hold at once: the compact instance, six per CU; with the extra channel it would spill)
-#if GSR_PF_COMPACT_EXTRA  // (measured: at 80 registers the instance with the extra channel spills the record in flight, 20 B - 48 views 27.7 vs 24.7 us per view)
-      if (d.has_extra && VT > (size_t)(5 * kCUs)) hipLaunchKernelGGL((k_tile_fwd_prefix<true, true>), tgrid, dim3(kFwdThreads), 0, st, p);
-      else
-#endif
-      if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true, false>), tgrid, dim3(kFwdThreads), 0, st, p);
-      else if (VT > (size_t)GSR_PF_COMPACT_MIN_TILES && GSR_PF_COMPACT) hipLaunchKernelGGL((k_tile_fwd_prefix<false, true>), tgrid, dim3(kFwdThreads), 0, st, p);
+      // (more tiles than five workgroups per CU hold at once: the compact instance, six per CU.  Round 5: with the extra channel too - until
+      // stage A formed its weights after the death decision (blend_range) that instance spilled the record in flight at 80 registers)
+      const bool compact = VT > (size_t)GSR_PF_COMPACT_MIN_TILES && GSR_PF_COMPACT;
+      if (d.has_extra && compact) hipLaunchKernelGGL((k_tile_fwd_prefix<true, true>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true, false>), tgrid, dim3(kFwdThreads), 0, st, p);
+      else if (compact) hipLaunchKernelGGL((k_tile_fwd_prefix<false, true>), tgrid, dim3(kFwdThreads), 0, st, p);
       else hipLaunchKernelGGL((k_tile_fwd_prefix<false, false>), tgrid, dim3(kFwdThreads), 0, st, p);
     } else if (p.stride <= 2048u) GSR_TILES(true, 2048);
     else GSR_TILES(true, 4096);

@@ -23,6 +23,7 @@ def one_case(rng):
     n, views, h, w = cfg.num_gaussians, cfg.num_views, cfg.height, cfg.width
     one_case.last = desc
     one_case.inputs = (cfg, vb, means, cov6, opac, colors, extra, gc, ge)
+    one_case.cap = cap
     res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, extra, gc, ge, capacity=cap)
     if n:
         for v in range(views):
@@ -51,8 +52,15 @@ def survey(cases, seeds, out):
         rng = np.random.default_rng(seed)
         for k in range(cases):
             desc = one_case(rng)
-            rows.append(dict(one_case.metrics, seed=seed, case=k, hw=desc["hw"], views=desc["sets"] * desc["vps"], det=desc["det"],
-                             windowed=desc["windowed"]))
+            row = dict(one_case.metrics, seed=seed, case=k, hw=desc["hw"], views=desc["sets"] * desc["vps"], det=desc["det"],
+                       windowed=desc["windowed"])
+            if row["grad_kept"] > 5e-5 or row["img"] > 1e-4 or row["grad"] > 1e-4:
+                # a case in the tail: which side is off?  HIP and the fp32 oracle against the fp64 oracle (tools/parity_vs_fp64.py)
+                from tools.parity_vs_fp64 import three_way
+
+                rows3, px = three_way(one_case.inputs + (one_case.cap,))
+                row["vs_fp64"] = dict(px, tensors=[dict(tensor=nm, hip_vs_f64=a, o32_vs_f64=b, hip_vs_o32=c) for nm, a, b, c in rows3])
+            rows.append(row)
         print(f"seed {seed}: {cases} cases ok ({time.time() - t0:.0f} s so far)", flush=True)
     os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
     json.dump(dict(cases_per_seed=cases, seeds=list(seeds), seconds=time.time() - t0, rows=rows), open(out, "w"))
