@@ -895,6 +895,26 @@ def main():
                                     "child run: profiles/r05_*_kernel_stats_config4_{fwd,train}.md"}
 
                 result["roofline_config4"] = {"fwd": config4_roofline(False), "train": config4_roofline(True)}
+                # ---- two calls in flight (NOT the headline): the headline step alternating between two HIP streams, each with its own
+                # workspaces and output - the tail of one call's tile launch may run under the head of the next call's binning launch.
+                # What cross-call overlap buys with the kernels as they are (a binning workgroup owns its CU: DESIGN 8)
+                try:
+                    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+                    plan_2 = be.make_plan(cfg, dev, capacity=int(plan["dims"].pair_capacity))
+                    pair = ((s_a, plan), (s_b, plan_2))
+                    torch.cuda.synchronize()
+
+                    def two_in_flight():
+                        for st_, pl_ in pair:
+                            with torch.cuda.stream(st_):
+                                be.run_forward(pl_, viewbuf, means, cov6, opac, shs)
+
+                    t2 = time_calls(two_in_flight, 100, 20) / 2
+                    t1 = time_calls(step, 200, 20)
+                    result["two_calls_in_flight"] = {"us_per_view_two_streams": 1e6 * t2, "us_per_view_one_stream_same_leg": 1e6 * t1,
+                                                     "note": "the headline workload alternating between two streams with two workspaces; an extra, not the headline"}
+                except Exception as e:
+                    result["two_calls_in_flight"] = f"{type(e).__name__}: {e}"
                 # ---- many views of ONE scene in one call: PF3plat's video rendering makes 46-51 views of a scene per decoder call
                 # (reference src/model/model_wrapper.py:699-778, decoder call at :731; assets/evaluation_index_re10k_video.json).
                 # G = 131 072 (2 context views x 256 x 256), V = 48 cameras on the path between the two context cameras, one launch chain.

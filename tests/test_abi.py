@@ -197,3 +197,32 @@ def test_geom_sub_arrays_never_overlap_and_fit_the_reported_size():
         else:
             assert gl["rows"] == -1
         assert g >= end, (cfg, g, end, gl)
+
+
+def test_compiled_torch_binding_loads_and_carries_the_policy_defaults():
+    """The torch-facing path is ONE compiled translation unit (pf3plat_amd/csrc/gsr_torch.cpp -> pf3plat_amd/_gsr_torch.so, built by
+    __graft_entry__.build()): it loads in-tree, resolves the C ABI out of libgsr_hip.so, exposes the autograd entry points the package
+    calls, and a fresh backend object carries the default pair-count policy (host logic only - no compute without a GPU)."""
+    import os
+
+    ext = _lib.load_torch_ext()
+    assert os.path.dirname(ext.__file__) == os.path.dirname(_lib.LIB_PATH)  # in-tree: it travels with the snapshot
+    for name in ("Backend", "rasterize", "rasterize_one_view", "views_from_cameras", "setup_views", "pack_view", "init"):
+        assert hasattr(ext, name), name
+    be = rasterizer.HipBackend()
+    assert (be.sync_policy, be.defer_after, be.on_overflow, be.defer_status) == ("sync", 4, "nan", False)
+    assert be.pending == [] and be.seen == {} and be.capacity_hint == {} and be.last_status is None and not be.poisoned
+    be.sync_policy, be.defer_after, be.on_overflow = "lazy", 0, "raise"
+    assert (be._c.sync_policy, be._c.defer_after, be._c.on_overflow) == ("lazy", 0, "raise")
+    with pytest.raises(ValueError):
+        be.sync_policy = "sometimes"
+    with pytest.raises(ValueError):
+        be.on_overflow = "ignore"
+    # the capacity arithmetic of the two sides of the binding agrees (C++ policy code vs the ctypes plan API)
+    cfg = rasterizer.RasterConfig(3, 1, 3, 131072, 256, 256, 4, 25, 4, True, 1 << 4)
+    st = {"num_pairs": 1645303, "overflow": 0, "max_list": 766}
+    assert be._c.capacity_for(rasterizer._cfg_vec(cfg), st["num_pairs"], st["max_list"], 1.25) == be.capacity_for(cfg, st)
+    # CPU tensors are refused by the compiled path itself
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        be.forward(cfg, torch.zeros(3, 48), torch.zeros(1, 131072, 3), torch.zeros(1, 131072, 6), torch.zeros(1, 131072),
+                   torch.zeros(1, 131072, 25, 3), None)

@@ -9,8 +9,10 @@ O=gpurun_out/$L
 R=$GRAFT_REPO_ROOT
 mkdir -p $O
 export TMPDIR=/tmp
+if [ -z "$PERF_ONLY" ]; then
 timeout 900 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1
 tail -1 $O/pytest.log
+fi
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -2 $O/bench.err
@@ -35,8 +37,12 @@ cp $O/sq8/table.md $O/sq_counters_8_views_raw.md 2>/dev/null
 bash tools/sq_counters.sh $O/sq48 bench.py --traffic-child views48 > /dev/null 2>&1
 cp $O/sq48/table.md $O/sq_counters_48_views_raw.md 2>/dev/null
 timeout 120 python tools/clock_probe.py > $O/clock_probe.txt 2>&1
+if [ -z "$PERF_ONLY" ]; then
 timeout 600 python tools/parity_vs_fp64.py $O/parity_vs_fp64.md > $O/parity_vs_fp64.log 2>&1
 tail -3 $O/parity_vs_fp64.log
+fi
+timeout 120 ./tools/micro/blend_mix_bench > $O/blend_mix_bench.txt 2>&1
+cat $O/blend_mix_bench.txt
 if [ "$FUZZ" != "0" ]; then
   timeout 1500 python tools/fuzz_parity.py --cases $FUZZ --seeds 11,12,13,14,15 --out $O/fuzz.json > $O/fuzz.log 2>&1
   tail -2 $O/fuzz.log
