@@ -728,6 +728,49 @@ def test_forward_chain_replays_from_a_hip_graph():
     assert torch.equal(plan["color"], eager)
 
 
+def test_compiled_backend_status_wait_falls_back_to_a_synchronize_and_forward_under_capture_is_sized_by_the_caller():
+    """Two host paths of the compiled backend that the other tests do not take: (i) with `spin_us = 0` every wait for a status block
+    goes through the bounded poll's fallback - a device synchronize that would report a device error instead of spinning on it - and
+    gives the same results; (ii) under stream capture nothing can be read back: the forward takes the caller's `capacity`, returns
+    without a status read, and the captured chain replays to the eager image."""
+    from pf3plat_amd import _lib, rasterizer
+    from pf3plat_amd.synthetic import scene_operator_inputs, scene_viewbuf
+
+    dev = torch.device("cuda:0")
+    sc = synthetic.make_scene(19, 5000, (64, 64))
+    means, cov6, opac, colors = (t.to(dev) for t in scene_operator_inputs(sc))
+    vb = scene_viewbuf(sc).to(dev)
+    cfg = RasterConfig(1, 1, 1, 5000, 64, 64, 4, 25, 4, False)
+    be = rasterizer.HipBackend()
+    c0, _, _, _ = be.forward(cfg, vb, means, cov6, opac, colors, None)
+    be2 = rasterizer.HipBackend()
+    be2.spin_us = 0.0
+    c1, _, _, saved = be2.forward(cfg, vb, means, cov6, opac, colors, None)
+    assert torch.equal(c0, c1) and be2.last_status == be.last_status and be2.seen[(1, 5000, 64, 64)] == 1
+    cfg_b = RasterConfig(1, 1, 1, 5000, 64, 64, 4, 25, 4, False, _lib.FLAG_BACKWARD_FOLLOWS)
+    for _ in range(5):  # (the fifth is deferred: its status is awaited - through the fallback - at the end of its backward)
+        _, _, _, saved = be2.forward(cfg_b, vb, means, cov6, opac, colors, None)
+        g = be2.backward(cfg_b, saved, vb, means, cov6, opac, colors, None, torch.ones((1, 3, 64, 64), device=dev), None, True, rows_in_workspace=True)
+    assert not be2.pending and be2.seen[(1, 5000, 64, 64)] == 6 and all(torch.isfinite(t).all() for t in g if t is not None)
+    # (ii) capture: sized by the caller, no read-back
+    cap = be.capacity_hint[(1, 5000, 64, 64)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        be.forward(cfg, vb, means, cov6, opac, colors, None, capacity=cap)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    seen_before = be.seen[(1, 5000, 64, 64)]
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        cg, _, _, _ = be.forward(cfg, vb, means, cov6, opac, colors, None, capacity=cap)
+    assert be.seen[(1, 5000, 64, 64)] == seen_before and not be.pending  # nothing was read back during the capture
+    cg.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(cg, c0)
+
+
 # ------------------------------------------------------------------ launch-path coverage: every binning variant the host code can pick
 def test_image_with_more_tiles_than_the_fused_binning_takes_uses_windowed_count_and_separate_scan():
     """1456 x 1000 => 182 x 126 = 22 932 8x8 tiles > the 20 480 the fused binning launch histograms in LDS: k_preprocess + k_count
