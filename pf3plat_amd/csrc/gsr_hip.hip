@@ -4307,9 +4307,12 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
       else GSR_TILES(false, 4096);
     }
     // the usual case (cursor gather + prefix rank): long lists.  A slot of at most kPrefix (+ 25 %) entries means lists that are
-    // ranked whole anyway - many small tiles, e.g. one 1024 x 1024 view of the 300 k scene: 78 entries per tile - and those are
-    // better off with k_tile_fwd's smaller LDS footprint (five workgroups per CU instead of four: 192 vs 217 us for that view)
-    else if (p.stride <= 2048u && p.stride > (uint32_t)(kPrefix + kPrefix / 4) && p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {
+    // ranked whole anyway - many small tiles, e.g. one 1024 x 1024 view of the 300 k scene: 78 entries per tile.  With the 32 KB
+    // instance those were better off with k_tile_fwd's smaller LDS footprint (192 vs 217 us for that view, round 4); the COMPACT
+    // instance (25.8 KB, 80 registers: six workgroups per CU, like k_tile_fwd's) keeps its cheaper gather - no scan over the rows,
+    // four barriers fewer - and takes them when the call has more tiles than the chip holds at once: that view 174.3 -> 167.3 us.
+    else if (p.stride <= 2048u && (p.stride > (uint32_t)(kPrefix + kPrefix / 4) || (GSR_PF_COMPACT && VT > (size_t)GSR_PF_COMPACT_MIN_TILES)) &&
+             p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {
       // (more tiles than five workgroups per CU hold at once: the compact instance, six per CU.  Round 5: with the extra channel too - until
       // stage A formed its weights after the death decision (blend_range) that instance spilled the record in flight at 80 registers)
       const bool compact = VT > (size_t)GSR_PF_COMPACT_MIN_TILES && GSR_PF_COMPACT;
