@@ -24,6 +24,7 @@
 #include <map>
 #include <mutex>
 #include <set>
+#include <sstream>
 #include <tuple>
 #include <vector>
 
@@ -727,6 +728,45 @@ pybind11::tuple rasterize(PyBackend& pb, const Tensor& means, const Tensor& cov,
   return pybind11::make_tuple(color, e, radii);
 }
 
+// `pf3plat_amd.rasterizer.rasterize_views` in one crossing: argument checks (the Python function's, message for message), dtype /
+// contiguity normalisation, the call shape and its flags (GSR_FLAG_BACKWARD_FOLLOWS when something can be differentiated), the operator.
+pybind11::tuple rasterize_views(PyBackend& pb, const Tensor& means_in, const Tensor& cov_in, const Tensor& opac_in, const Tensor& colors_in, const Tensor& viewbuf_in,
+                                int64_t h, int64_t w, int64_t sh_degree, bool use_sh, int64_t views_per_set, const c10::optional<Tensor>& extra_in,
+                                const c10::optional<Tensor>& means2d, int64_t max_sh_eval, bool sh_planar, bool cov_3x3, int64_t extra_mode, bool debug,
+                                bool prefiltered, int64_t deterministic, bool scale_rot, const c10::optional<Tensor>& frames_in, int64_t camera_gradient) {
+  const int64_t s = means_in.size(0), n = means_in.size(1), v = viewbuf_in.size(0);
+  if (v != s * views_per_set) throw pybind11::value_error(std::to_string(v) + " views != " + std::to_string(s) + " sets x " + std::to_string(views_per_set) + " views per set");
+  const Tensor means = f32c(means_in), cov = f32c(cov_in), opac = f32c(opac_in), colors = f32c(colors_in);
+  c10::optional<Tensor> extra, frames;
+  if (extra_in.has_value() && extra_in->defined()) extra = f32c(*extra_in);
+  if (use_sh && colors.dim() != 4) throw pybind11::value_error("shs must be (sets, N, M, 3) or (sets, N, 3, M)");
+  const auto shape_str = [](const Tensor& t) { std::ostringstream o; o << t.sizes(); return o.str(); };
+  if (scale_rot) {
+    if (cov_3x3 || cov.dim() != 3 || cov.size(2) != 7) throw pybind11::value_error("scale/rotation records have shape " + shape_str(cov) + "; expected (sets, N, 7)");
+    if (frames_in.has_value() && frames_in->defined()) frames = f32c(frames_in->detach());
+  } else if (frames_in.has_value() && frames_in->defined()) {
+    throw pybind11::value_error("`frames` goes with scale_rot=True");
+  } else if (cov_3x3 ? (cov.dim() != 4 || cov.size(2) != 3 || cov.size(3) != 3) : (cov.dim() != 3 || cov.size(2) != 6)) {
+    throw pybind11::value_error("covariances have shape " + shape_str(cov) + "; expected (sets, N, " + (cov_3x3 ? "3, 3" : "6") + ")");
+  }
+  const int64_t m = use_sh ? (sh_planar ? colors.size(3) : colors.size(2)) : 0;
+  int64_t flags = ((sh_planar && use_sh) ? GSR_FLAG_SH_PLANAR : 0) | (cov_3x3 ? GSR_FLAG_COV_3X3 : 0);
+  const bool det = deterministic < 0 ? at::globalContext().deterministicAlgorithms() : deterministic != 0;
+  flags |= (debug ? GSR_FLAG_DEBUG : 0) | (prefiltered ? GSR_FLAG_PREFILTERED : 0) | (det ? GSR_FLAG_DETERMINISTIC : 0);
+  const auto rg = [](const c10::optional<Tensor>& t) { return t.has_value() && t->defined() && t->requires_grad(); };
+  if (at::GradMode::is_enabled() && (means.requires_grad() || cov.requires_grad() || opac.requires_grad() || colors.requires_grad() || rg(extra) || rg(means2d) ||
+                                     viewbuf_in.requires_grad()))
+    flags |= GSR_FLAG_BACKWARD_FOLLOWS;  // the forward zero-fills the backward's accumulator rows on its way
+  if (extra_mode) {
+    if (extra.has_value()) throw pybind11::value_error("give either `extra` or `extra_mode`");
+    flags |= GSR_FLAG_EXTRA_MODE(extra_mode);
+  }
+  const bool has_extra = extra.has_value() || extra_mode != 0;
+  if (camera_gradient != 1 && camera_gradient != 2) throw pybind11::value_error("camera_gradient must be 'full' or 'depth'");
+  const std::vector<int64_t> cfgv{v, s, views_per_set, n, h, w, sh_degree, m, max_sh_eval, has_extra ? 1 : 0, flags, scale_rot ? 1 : 0};
+  return rasterize(pb, means, cov, opac, colors, extra, means2d, f32c(viewbuf_in), cfgv, frames, camera_gradient);
+}
+
 // The per-view operator with upstream's call shape (reference cuda_splatting.py:99-124: one settings object, one call per view) in ONE
 // crossing from Python: the camera record (gsr_pack_view), the V = 1 views of the inputs, the call shape, the operator, the [0]s.
 // tanfov*: floats, or tensors (the orthographic wrapper passes tensors); cov3d: (n, 6) or anything that reshapes to it.
@@ -815,6 +855,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            });
   m.def("rasterize", &rasterize, pybind11::arg("backend"), pybind11::arg("means"), pybind11::arg("cov"), pybind11::arg("opac"), pybind11::arg("colors"),
         pybind11::arg("extra"), pybind11::arg("means2d"), pybind11::arg("viewbuf"), pybind11::arg("cfg"), pybind11::arg("frames"), pybind11::arg("camera_gradient"));
+  m.def("rasterize_views", &rasterize_views);
   m.def("rasterize_one_view", &rasterize_one_view);
   m.def("views_from_cameras", &views_from_cameras);
   m.def("setup_views", &setup_views_raw);

@@ -653,6 +653,18 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     stage that failed.  deterministic: the backward accumulates per-Gaussian gradients in 64-bit fixed point (bit-identical
     from run to run); None = follow `torch.are_deterministic_algorithms_enabled()`.
     """
+    backend = get_backend()
+    if isinstance(backend, HipBackend):
+        # the product path, one crossing: checks, normalisation, call shape, flags and the compiled autograd function
+        # (csrc/gsr_torch.cpp::rasterize_views / RasterizeFn; a plain call when nothing can be differentiated)
+        if camera_gradient not in ("full", "depth"):
+            raise ValueError("camera_gradient must be 'full' or 'depth'")
+        return backend._ext.rasterize_views(
+            backend._c, means, cov6, opacities, colors, viewbuf, int(image_shape[0]), int(image_shape[1]), int(sh_degree), bool(use_sh),
+            int(views_per_set), extra, means2d, int(max_sh_eval), bool(sh_planar), bool(cov_3x3), EXTRA_MODES[extra_mode] if extra_mode is not None else 0,
+            bool(debug), bool(prefiltered), -1 if deterministic is None else int(bool(deterministic)), bool(scale_rot), frames,
+            2 if camera_gradient == "depth" else 1)
+    # (any other backend object - tests slide the CPU oracle under the host wrappers - takes the Python statement of the same steps)
     s, n = means.shape[0], means.shape[1]
     v = viewbuf.shape[0]
     if v != s * views_per_set:
@@ -688,12 +700,6 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
     viewbuf = _f32c(viewbuf)
     if camera_gradient not in ("full", "depth"):
         raise ValueError("camera_gradient must be 'full' or 'depth'")
-    backend = get_backend()
-    if isinstance(backend, HipBackend):
-        # the product path: the compiled autograd function (csrc/gsr_torch.cpp::RasterizeFn; a plain call when nothing can be differentiated)
-        return backend._ext.rasterize(backend._c, means, cov6, opacities, colors, extra, means2d, viewbuf, _cfg_vec(cfg), frames,
-                                      2 if camera_gradient == "depth" else 1)
-    # (any other backend object - tests slide the CPU oracle under the host wrappers - goes through the Python autograd function below)
     if not (flags & _lib.FLAG_BACKWARD_FOLLOWS):  # nothing here can be differentiated: no autograd node, no saved workspaces
         color, extra_img, radii, _ = backend.forward(cfg, viewbuf, means, cov6, opacities, colors, extra, frames=frames,
                                                      reuse_workspaces=True)

@@ -12,6 +12,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_sessionstart(session):
+    """The native pieces are built artefacts kept out of git: a fresh checkout has none.  Build what is missing or stale before the
+    first test asks for it (no-ops when current: content stamps; the same calls as __graft_entry__.build())."""
+    from pf3plat_amd import _lib
+
+    try:
+        _lib.build()
+        _lib.build_torch_ext()
+    except Exception as e:  # (no compiler on this machine: the tests that need the libraries will say so themselves)
+        print(f"[conftest] native build skipped: {type(e).__name__}: {str(e)[:300]}", file=sys.stderr)
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     from oracle import load_oracle
