@@ -911,8 +911,14 @@ def main():
 
                     t2 = time_calls(two_in_flight, 100, 20) / 2
                     t1 = time_calls(step, 200, 20)
-                    result["two_calls_in_flight"] = {"us_per_view_two_streams": 1e6 * t2, "us_per_view_one_stream_same_leg": 1e6 * t1,
-                                                     "note": "the headline workload alternating between two streams with two workspaces; an extra, not the headline"}
+                    result["two_calls_in_flight"] = {
+                        "us_per_view_two_streams": 1e6 * t2, "us_per_view_one_stream_same_leg": 1e6 * t1, "views_per_s_two_streams": 1.0 / t2,
+                        "roofline_chain_two_streams": {"bound": "hbm", "achieved": ab["total"] / t2 / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                       "frac": ab["total"] / t2 / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": ab["total"]},
+                        "note": "the headline workload as INDEPENDENT calls alternating between two HIP streams, each with its own workspaces and image "
+                                "(tools/multi_stream.py: S = 1 .. 4, other shapes): the tail of one call's tile launch runs under the next call's binning "
+                                "launch.  A throughput figure for callers that hold several independent requests; an extra, NOT the headline - `value` is "
+                                "one call after the other on one stream"}
                 except Exception as e:
                     result["two_calls_in_flight"] = f"{type(e).__name__}: {e}"
                 # ---- many views of ONE scene in one call: PF3plat's video rendering makes 46-51 views of a scene per decoder call
