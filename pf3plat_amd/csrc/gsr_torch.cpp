@@ -212,6 +212,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
   std::vector<int64_t> pending_tokens() { std::lock_guard<std::mutex> g(mu_); std::vector<int64_t> t; for (auto& p : pending_) t.push_back(p.token); return t; }
   std::vector<int64_t> poisoned_tokens() { std::lock_guard<std::mutex> g(mu_); return std::vector<int64_t>(poisoned_.begin(), poisoned_.end()); }
   bool has_status() const { return has_status_; }
+  bool any_pending() { std::lock_guard<std::mutex> g(mu_); return !pending_.empty(); }
   Status last_status() const { return last_; }
   void set_capacity_hint(const ShapeKey& k, int64_t v) { std::lock_guard<std::mutex> g(mu_); hint_[k] = v; }
 
@@ -223,7 +224,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
   }
 
   void release_workspaces() {
-    if (!pending_.empty()) check_pending(true, -1);
+    if (any_pending()) check_pending(true, -1);
     std::lock_guard<std::mutex> g(mu_);
     ws_cache_.clear();
     sizes_.clear();
@@ -236,7 +237,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
   ForwardOut forward(const Cfg& cfg, const Tensor& viewbuf, const Tensor& means, const Tensor& cov, const Tensor& opac, const Tensor& colors,
                      const Tensor& extra, const Tensor& frames, int64_t capacity /* <= 0: policy */, bool reuse_workspaces, bool one_view = false) {
     check_device({&viewbuf, &means, &cov, &opac, &colors, &extra, &frames});
-    if (!pending_.empty()) check_pending(false, -1);
+    if (any_pending()) check_pending(false, -1);
     const at::Device dev = viewbuf.device();
     const ShapeKey key{cfg.num_views, cfg.num_gaussians, cfg.height, cfg.width};
     c10::hip::HIPGuard guard(dev.index());
@@ -338,7 +339,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
 
   // -> true when that forward overflowed and the policy is to answer with NaN gradients instead of raising
   bool verify_own_forward(int64_t token) {
-    if (!pending_.empty()) check_pending(false, token);
+    if (any_pending()) check_pending(false, token);
     std::lock_guard<std::mutex> g(mu_);
     auto it = poisoned_.find(token);
     if (it == poisoned_.end()) return false;
@@ -710,22 +711,40 @@ pybind11::dict status_dict(const Status& st) {
   return d;
 }
 
-// (color, extra_img | None, radii): the differentiable operator (an autograd node only when the call announces a backward)
+// (color, extra_img (undefined without the extra channel), radii): the differentiable operator - an autograd node only when the call
+// announces a backward.  Runs WITHOUT the GIL (the callers below release it around their work and take it back to build the result):
+// a blocking forward polls its status block for as long as its kernels run, and other Python threads - a data loader's pin-memory
+// thread - must not stand still meanwhile.
+struct RasterOut { Tensor color, extra_img, radii; };
+RasterOut rasterize_impl(PyBackend& pb, const Tensor& means, const Tensor& cov, const Tensor& opac, const Tensor& colors, const c10::optional<Tensor>& extra,
+                         const c10::optional<Tensor>& means2d, const Tensor& viewbuf, const std::vector<int64_t>& cfgv, const c10::optional<Tensor>& frames,
+                         int64_t camera_gradient) {
+  const Cfg cfg = cfg_from(cfgv);
+  const Tensor ex = extra.has_value() ? *extra : Tensor(), fr = frames.has_value() ? *frames : Tensor();
+  RasterOut r;
+  if (!(cfg.flags & GSR_FLAG_BACKWARD_FOLLOWS)) {  // nothing here can be differentiated: no autograd node, no saved workspaces
+    ForwardOut o = pb.be().forward(cfg, viewbuf, means, cov, opac, colors, ex, fr, -1, true);
+    r.color = o.color; r.extra_img = o.extra_img; r.radii = o.radii;
+  } else {
+    auto out = RasterizeFn::apply(means, cov, opac, colors, extra, means2d, viewbuf, frames, pb.holder, cfgv, camera_gradient);
+    r.color = out[0]; r.radii = out[2];
+    if (cfg.has_extra) r.extra_img = out[1];
+  }
+  return r;
+}
+pybind11::tuple raster_tuple(const RasterOut& r) {
+  pybind11::object e = r.extra_img.defined() ? pybind11::cast(r.extra_img) : pybind11::none();
+  return pybind11::make_tuple(r.color, e, r.radii);
+}
 pybind11::tuple rasterize(PyBackend& pb, const Tensor& means, const Tensor& cov, const Tensor& opac, const Tensor& colors, const c10::optional<Tensor>& extra,
                           const c10::optional<Tensor>& means2d, const Tensor& viewbuf, const std::vector<int64_t>& cfgv, const c10::optional<Tensor>& frames,
                           int64_t camera_gradient) {
-  const Cfg cfg = cfg_from(cfgv);
-  const Tensor ex = extra.has_value() ? *extra : Tensor(), fr = frames.has_value() ? *frames : Tensor();
-  Tensor color, extra_img, radii;
-  if (!(cfg.flags & GSR_FLAG_BACKWARD_FOLLOWS)) {  // nothing here can be differentiated: no autograd node, no saved workspaces
-    ForwardOut o = pb.be().forward(cfg, viewbuf, means, cov, opac, colors, ex, fr, -1, true);
-    color = o.color; extra_img = o.extra_img; radii = o.radii;
-  } else {
-    auto out = RasterizeFn::apply(means, cov, opac, colors, extra, means2d, viewbuf, frames, pb.holder, cfgv, camera_gradient);
-    color = out[0]; extra_img = out[1]; radii = out[2];
+  RasterOut r;
+  {
+    pybind11::gil_scoped_release nogil;
+    r = rasterize_impl(pb, means, cov, opac, colors, extra, means2d, viewbuf, cfgv, frames, camera_gradient);
   }
-  pybind11::object e = cfg.has_extra ? pybind11::cast(extra_img) : pybind11::none();
-  return pybind11::make_tuple(color, e, radii);
+  return raster_tuple(r);
 }
 
 // `pf3plat_amd.rasterizer.rasterize_views` in one crossing: argument checks (the Python function's, message for message), dtype /
@@ -734,6 +753,9 @@ pybind11::tuple rasterize_views(PyBackend& pb, const Tensor& means_in, const Ten
                                 int64_t h, int64_t w, int64_t sh_degree, bool use_sh, int64_t views_per_set, const c10::optional<Tensor>& extra_in,
                                 const c10::optional<Tensor>& means2d, int64_t max_sh_eval, bool sh_planar, bool cov_3x3, int64_t extra_mode, bool debug,
                                 bool prefiltered, int64_t deterministic, bool scale_rot, const c10::optional<Tensor>& frames_in, int64_t camera_gradient) {
+  RasterOut result;
+  {
+  pybind11::gil_scoped_release nogil;
   const int64_t s = means_in.size(0), n = means_in.size(1), v = viewbuf_in.size(0);
   if (v != s * views_per_set) throw pybind11::value_error(std::to_string(v) + " views != " + std::to_string(s) + " sets x " + std::to_string(views_per_set) + " views per set");
   const Tensor means = f32c(means_in), cov = f32c(cov_in), opac = f32c(opac_in), colors = f32c(colors_in);
@@ -764,7 +786,9 @@ pybind11::tuple rasterize_views(PyBackend& pb, const Tensor& means_in, const Ten
   const bool has_extra = extra.has_value() || extra_mode != 0;
   if (camera_gradient != 1 && camera_gradient != 2) throw pybind11::value_error("camera_gradient must be 'full' or 'depth'");
   const std::vector<int64_t> cfgv{v, s, views_per_set, n, h, w, sh_degree, m, max_sh_eval, has_extra ? 1 : 0, flags, scale_rot ? 1 : 0};
-  return rasterize(pb, means, cov, opac, colors, extra, means2d, f32c(viewbuf_in), cfgv, frames, camera_gradient);
+  result = rasterize_impl(pb, means, cov, opac, colors, extra, means2d, f32c(viewbuf_in), cfgv, frames, camera_gradient);
+  }
+  return raster_tuple(result);
 }
 
 // The per-view operator with upstream's call shape (reference cuda_splatting.py:99-124: one settings object, one call per view) in ONE
@@ -775,6 +799,9 @@ pybind11::tuple rasterize_one_view(PyBackend& pb, int64_t height, int64_t width,
                                    const Tensor& projmatrix, int64_t sh_degree, const Tensor& campos, bool prefiltered, bool debug, const Tensor& means3d,
                                    const c10::optional<Tensor>& means2d, const Tensor& opacities, const c10::optional<Tensor>& shs,
                                    const c10::optional<Tensor>& colors_precomp, const Tensor& cov3d) {
+  Tensor out_color, out_radii;
+  {
+  pybind11::gil_scoped_release nogil;
   const int64_t n = means3d.size(0);
   const bool use_sh = shs.has_value();
   const Tensor viewbuf = pack_view(viewmatrix, projmatrix, campos, bg, tanfovx, tanfovy, tanfovx_t.has_value() ? *tanfovx_t : Tensor(),
@@ -790,16 +817,19 @@ pybind11::tuple rasterize_one_view(PyBackend& pb, int64_t height, int64_t width,
     // V = 1, S = 1 - and the image / radii are allocated in the shapes the operator returns: no view op on either side of the call
     const std::vector<int64_t> cfgv{1, 1, 1, n, height, width, sh_degree, use_sh ? col_in.size(1) : 0, 4, 0, flags, 0};
     ForwardOut o = pb.be().forward(cfg_from(cfgv), viewbuf, f32c(means3d), f32c(cov3d), f32c(opacities), f32c(col_in), Tensor(), Tensor(), -1, true, true);
-    return pybind11::make_tuple(o.color, o.radii);
-  }
+    out_color = o.color; out_radii = o.radii;
+  } else {
   flags |= GSR_FLAG_BACKWARD_FOLLOWS;  // the forward zero-fills the backward's accumulator rows on its way
   const Tensor means = f32c(means3d.unsqueeze(0)), cov = f32c(cov3d.reshape({n, 6}).unsqueeze(0)), opac = f32c(opacities.reshape({n}).unsqueeze(0));
   const Tensor colors = f32c(col_in.unsqueeze(0));
   c10::optional<Tensor> m2;
   if (means2d.has_value() && means2d->defined()) m2 = means2d->unsqueeze(0);
   const std::vector<int64_t> cfgv{1, 1, 1, n, height, width, sh_degree, use_sh ? colors.size(2) : 0, 4, 0, flags, 0};
-  pybind11::tuple r = rasterize(pb, means, cov, opac, colors, c10::nullopt, m2, viewbuf, cfgv, c10::nullopt, 1);
-  return pybind11::make_tuple(r[0].cast<Tensor>().select(0, 0), r[2].cast<Tensor>().select(0, 0));
+  RasterOut r = rasterize_impl(pb, means, cov, opac, colors, c10::nullopt, m2, viewbuf, cfgv, c10::nullopt, 1);
+  out_color = r.color.select(0, 0); out_radii = r.radii.select(0, 0);
+  }
+  }
+  return pybind11::make_tuple(out_color, out_radii);
 }
 
 }  // namespace
@@ -827,13 +857,18 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
              Status st; st.num_pairs = num_pairs; st.max_list = max_list;
              return b.be().capacity_for(cfg_from(cfgv), st, headroom);
            }, pybind11::arg("cfg"), pybind11::arg("num_pairs"), pybind11::arg("max_list"), pybind11::arg("headroom") = 1.25)
-      .def("check_pending", [](PyBackend& b, bool wait, int64_t only_token) { b.be().check_pending(wait, only_token); }, pybind11::arg("wait") = false,
+      .def("check_pending", [](PyBackend& b, bool wait, int64_t only_token) { pybind11::gil_scoped_release nogil; b.be().check_pending(wait, only_token); },
+           pybind11::arg("wait") = false,
            pybind11::arg("only_token") = -1)
-      .def("release_workspaces", [](PyBackend& b) { b.be().release_workspaces(); })
+      .def("release_workspaces", [](PyBackend& b) { pybind11::gil_scoped_release nogil; b.be().release_workspaces(); })
       .def("forward", [](PyBackend& b, const std::vector<int64_t>& cfgv, const Tensor& viewbuf, const Tensor& means, const Tensor& cov, const Tensor& opac,
                          const Tensor& colors, const c10::optional<Tensor>& extra, const c10::optional<Tensor>& frames, int64_t capacity, bool reuse_workspaces) {
-             ForwardOut o = b.be().forward(cfg_from(cfgv), viewbuf, means, cov, opac, colors, extra.has_value() ? *extra : Tensor(), frames.has_value() ? *frames : Tensor(),
-                                           capacity, reuse_workspaces);
+             ForwardOut o;
+             {
+               pybind11::gil_scoped_release nogil;
+               o = b.be().forward(cfg_from(cfgv), viewbuf, means, cov, opac, colors, extra.has_value() ? *extra : Tensor(), frames.has_value() ? *frames : Tensor(),
+                                  capacity, reuse_workspaces);
+             }
              pybind11::object saved = pybind11::none();
              if (o.saved.valid) saved = pybind11::make_tuple(dims_vec(o.saved.dims), o.saved.geom, o.saved.bin, o.saved.img, o.saved.token);
              pybind11::object e = o.extra_img.defined() ? pybind11::cast(o.extra_img) : pybind11::none();
@@ -846,9 +881,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                           const c10::optional<Tensor>& frames, int want_views) {
              Saved ws;
              ws.valid = true; ws.dims = dims_from(dimsv); ws.geom = geom; ws.bin = bin; ws.img = img; ws.token = token;
-             std::vector<Tensor> g = b.be().backward(cfg_from(cfgv), ws, viewbuf, means, cov, opac, colors, extra.has_value() ? *extra : Tensor(), g_color,
-                                                     g_extra.has_value() ? *g_extra : Tensor(), want_means2d, rows_in_workspace,
-                                                     frames.has_value() ? *frames : Tensor(), want_views);
+             std::vector<Tensor> g;
+             {
+               pybind11::gil_scoped_release nogil;
+               g = b.be().backward(cfg_from(cfgv), ws, viewbuf, means, cov, opac, colors, extra.has_value() ? *extra : Tensor(), g_color,
+                                   g_extra.has_value() ? *g_extra : Tensor(), want_means2d, rows_in_workspace, frames.has_value() ? *frames : Tensor(), want_views);
+             }
              pybind11::list out;
              for (size_t k = 0; k < (want_views ? 7u : 6u); ++k) out.append(g[k].defined() ? pybind11::cast(g[k]) : pybind11::none());
              return pybind11::tuple(out);

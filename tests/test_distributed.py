@@ -132,7 +132,9 @@ def test_eight_rank_gloo_config5_one_scene_per_rank_one_fused_gather(tmp_path):
     """World size EIGHT (the node the driver's scaling run uses), BASELINE configs[4] at a small G: 8 scenes (seeds 50 + r), one
     target view each, one fused gather; every rank must end with the same (8, 3, h, w) tensor whose slot r is scene 50 + r's view."""
     world = 8
-    mp.spawn(_worker_config5, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    # (forked, not spawned: eight fresh interpreters importing torch at once cost minutes on a cold page cache; the children inherit
+    # this process's modules and never touch a GPU)
+    mp.start_processes(_worker_config5, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="fork")
     import pf3plat_amd
     from pf3plat_amd import synthetic
     from tests.oracle_backend import OracleBackend
