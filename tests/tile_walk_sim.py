@@ -78,8 +78,8 @@ def tile_lists(seed: int = 2, n: int = 300000):
     return dict(x=x, y=y, A=A, B=B, C=C, op=op, pg=pg, starts=np.searchsorted(pt, np.arange(T + 1)), n_visible=len(idx), r16=res.r16)
 
 
-def walk(L):
-    """Per tile: list length, entries walked (batches of 32, as the kernel stops), and order-free per-tile / per-pixel sums."""
+def walk(L, batch=32):
+    """Per tile: list length, entries walked (batches of `batch` = 32, as the kernel stops), and order-free per-tile / per-pixel sums."""
     n = np.diff(L["starts"])
     walked = np.zeros(T, np.int64)
     pix_tau = np.zeros((T, 64))
@@ -96,7 +96,7 @@ def walk(L):
         stopped = np.cumprod(1 - alpha, axis=0) < 1e-4
         first = np.where(stopped.any(0), stopped.argmax(0), len(gg)).max()  # the slowest pixel's stop
         exact = len(gg) if first >= len(gg) else first + 1
-        walked[t] = min(((exact + 31) // 32) * 32, len(gg))
+        walked[t] = min(((exact + batch - 1) // batch) * batch, len(gg))
         pix_tau[t] = (-np.log1p(-alpha)).sum(0)  # optical depth per pixel, whole list (no order needed)
     return n, walked, pix_tau
 

@@ -23,7 +23,7 @@ def xcd_remap(b, n):
     return (xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q) + k
 
 
-def simulate(batches, split=None, hand=2.0, dt=0.01):
+def simulate(batches, split=None, hand=2.0, dt=0.01, alone=ALONE, shared=SHARED):
     """-> (launch end, idle-weighted mean CU end).  batches[tile]; split = S batches before a still-open tile hands its tail over (None: never)."""
     cus = [[] for _ in range(256)]  # per CU: [start time, remaining batches, progress within the current batch]
     for b in range(T):
@@ -44,7 +44,7 @@ def simulate(batches, split=None, hand=2.0, dt=0.01):
                 active = True
             if not run:
                 continue
-            rate = dt / (ALONE if len(run) == 1 else SHARED * len(run))
+            rate = dt / (alone if len(run) == 1 else max(alone, shared * len(run)))
             for x in run:
                 x[2] += rate
                 if x[2] >= 1.0:
@@ -69,6 +69,16 @@ def main():
     base, mean = simulate(batches)
     print(f"seed {seed}: batches per tile min {batches.min()} mean {batches.mean():.2f} max {batches.max()}; per CU sum mean {batches.reshape(-1).sum() / 256:.1f}")
     print(f"no hand-over: blend phase ends at {base:.2f} us (mean CU {mean:.2f})   [measured tile launch: 28.7 us incl. ~1.7 us of epilogue / launch tail]")
+    # six waves per tile workgroup: batches of 48 entries; per-CU arithmetic unchanged, issued by six waves per SIMD instead of four -
+    # tools/micro/blend_mix_bench (profiles/r05_h_blend_mix_bench.txt): 0.260 us per wave-iteration at W = 6 against 0.282 at W = 4, and a
+    # tile alone on its CU (1.5 waves per SIMD) between W = 1 (0.517) and W = 2 (0.345 per workgroup): ~0.43 us per 32 entries
+    _, walked48, _ = walk(L, 48)
+    b48 = (walked48 + 47) // 48
+    shared6 = SHARED * 1.5 * (0.260 / 0.282)
+    alone6 = 0.43 * 1.5
+    e6, m6 = simulate(b48, alone=alone6, shared=shared6)
+    print(f"six waves per tile (batches of 48: mean {b48.mean():.2f} per tile, {b48.sum() / 256:.1f} per CU; {shared6:.3f} us x tiles per batch, {alone6:.3f} alone): "
+          f"blend phase ends at {e6:.2f} us ({e6 - base:+.2f}), mean CU {m6:.2f} ({m6 - mean:+.2f}) - if the sort phase and the first gather cost what they cost now")
     print("| split after batch S | hand-over 1 us | 2 us | 3 us |")
     print("|---|---|---|---|")
     for S in (6, 8, 9, 10, 11, 12):
