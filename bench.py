@@ -255,8 +255,8 @@ def main():
     st = be.read_status(plan)
     plan = be.make_plan(cfg, dev, capacity=be.capacity_for(cfg, st, headroom=1.1), backward=True)
 
-    def step():
-        be.run_forward(plan, viewbuf, means, cov6, opac, shs)
+    step = be.bind_forward(plan, viewbuf, means, cov6, opac, shs)  # (= be.run_forward(plan, ...) with its argument list built once: the
+    #                                                                   same C call, gsr_forward, on torch's current stream)
 
     from pf3plat_amd import _lib as _gl0
 

@@ -769,6 +769,13 @@ def test_compiled_backend_status_wait_falls_back_to_a_synchronize_and_forward_un
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(cg, c0)
+    # the plan API's pre-bound call (bench.py's timed loop): the same launch chain, arguments built once
+    plan = be.make_plan(cfg, dev, capacity=cap)
+    step = be.bind_forward(plan, vb, means, cov6, opac, colors)
+    for _ in range(3):
+        plan["color"].zero_()
+        step()
+    assert torch.equal(plan["color"], c0) and not be.read_status(plan)["overflow"]
 
 
 # ------------------------------------------------------------------ launch-path coverage: every binning variant the host code can pick
