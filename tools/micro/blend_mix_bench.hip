@@ -9,7 +9,11 @@
 #include <cstdio>
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__global__ __launch_bounds__(256) void k_mix(float* out, int iters) {
+// DUTY 0: the bare loop.  1: the wave with (iteration & 3) == wave also does the staging wave's share of the real loop - ~35 VALU and ten
+// LDS stores (the records of a later batch moved to the exp2 domain and parked) - and everybody meets it at the barrier, as in
+// blend_range.  2: the same 35 instructions done by a FIFTH wave that blends nothing (a staging wave; the workgroup then has five).
+template <int DUTY>
+__global__ __launch_bounds__(DUTY == 2 ? 320 : 256) void k_mix(float* out, int iters) {
   __shared__ float4 sXY[4][16], sAB[4][16], sCO[4][16], sRG[4][16], sBE[4][16];
   __shared__ float sP[2][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -32,8 +36,25 @@ __global__ __launch_bounds__(256) void k_mix(float* out, int iters) {
   f2 CR = {0, 0}, CG = {0, 0}, CB = {0, 0};
   float Tb = 1.f, Tmin = 1.f;
   unsigned last = 0;
-  const int e0 = wave * 8;
+  const int e0 = (wave & 3) * 8;
+  float d0 = pxf * 0.01f, d1 = pyf * 0.02f, d2 = 0.3f, d3 = 0.4f, d4 = 0.5f;
   for (int i = 0; i < iters; ++i) {
+    if (DUTY && (DUTY == 2 ? wave == 4 : wave == (i & 3))) {  // the staging share: ~35 dependent-ish VALU + 10 LDS stores
+#pragma unroll
+      for (int r = 0; r < 7; ++r) {
+        d0 = __builtin_fmaf(d0, 0.999f, d1); d1 = d1 * 0.998f + d2; d2 = __builtin_fmaf(d2, d0, 0.001f); d3 = d3 * d0; d4 = __builtin_fmaf(d4, 0.5f, d3);
+      }
+      if (lane < 32) {
+        float* raw = reinterpret_cast<float*>(&sRG[(i + 2) & 3][0]);
+        const int o = (lane >> 1) * 4 + (lane & 1);
+        raw[o] = 0.5f + 1e-9f * d0; raw[o + 2] = 0.4f + 1e-9f * d1;
+        float* raw2 = reinterpret_cast<float*>(&sBE[(i + 2) & 3][0]);
+        raw2[o] = 0.2f + 1e-9f * d2; raw2[o + 2] = 1e-9f * d3;
+        float* raw3 = reinterpret_cast<float*>(&sCO[(i + 2) & 3][0]);
+        raw3[o + 2] = 0.3f + 1e-9f * d4;
+      }
+    }
+    if (DUTY == 2 && wave == 4) { __syncthreads(); continue; }
     // stage A: the four segment products, the chain, the weights, the colour sums
     const float P0 = sP[i & 1][0][lane], P1 = sP[i & 1][1][lane], P2 = sP[i & 1][2][lane], P3 = sP[i & 1][3][lane];
     const float t1 = Tb * P0, t2 = t1 * P1, t3 = t2 * P2, t4 = t3 * P3;
@@ -81,36 +102,37 @@ __global__ __launch_bounds__(256) void k_mix(float* out, int iters) {
     Tb = fmaxf(t4, 0.5f);
     __syncthreads();
   }
-  out[blockIdx.x * 256 + tid] = CR.x + CR.y + CG.x + CG.y + CB.x + CB.y + Tmin + (float)last + Tb;
+  out[blockIdx.x * 320 + tid] = CR.x + CR.y + CG.x + CG.y + CB.x + CB.y + Tmin + (float)last + Tb + d0 + d4;
 }
 
 int main() {
   float* out;
-  hipMalloc(&out, 256 * 8 * 256 * 4);
+  hipMalloc(&out, 256 * 8 * 320 * 4);
   const int iters = 20000;
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
   printf("blend-loop instruction mix, 256 CUs, W four-wave workgroups resident per CU (= W waves per SIMD), %d iterations each\n", iters);
-  double base = 0;
-  for (int W = 1; W <= 8; ++W) {
-    hipLaunchKernelGGL(k_mix, dim3(256 * W), dim3(256), 0, 0, out, 2000);
-    hipDeviceSynchronize();
-    float best = 1e9f;
-    for (int r = 0; r < 3; ++r) {
-      hipEventRecord(a);
-      hipLaunchKernelGGL(k_mix, dim3(256 * W), dim3(256), 0, 0, out, iters);
-      hipEventRecord(b);
-      hipEventSynchronize(b);
-      float ms;
-      hipEventElapsedTime(&ms, a, b);
-      best = ms < best ? ms : best;
+  auto sweep = [&](auto kernel, int threads, const char* what) {
+    printf("-- %s\n", what);
+    for (int W = 1; W <= 6; ++W) {
+      hipLaunchKernelGGL(kernel, dim3(256 * W), dim3(threads), 0, 0, out, 2000);
+      hipDeviceSynchronize();
+      float best = 1e9f;
+      for (int r = 0; r < 3; ++r) {
+        hipEventRecord(a);
+        hipLaunchKernelGGL(kernel, dim3(256 * W), dim3(threads), 0, 0, out, iters);
+        hipEventRecord(b);
+        hipEventSynchronize(b);
+        float ms;
+        hipEventElapsedTime(&ms, a, b);
+        best = ms < best ? ms : best;
+      }
+      const double us_per_iter = best * 1e3 / iters;  // one workgroup's iteration with W on the CU
+      printf("W = %d: %.3f us per workgroup-iteration, %.2f workgroup-iterations per us and CU (%.3f us / W)\n", W, us_per_iter, W / us_per_iter, us_per_iter / W);
     }
-    const double us_per_iter = best * 1e3 / iters;      // one workgroup's iteration with W on the CU
-    const double rate = W / us_per_iter;                 // workgroup-iterations per us and CU
-    if (W == 4) base = rate;
-    printf("W = %d: %.3f us per workgroup-iteration, %.2f workgroup-iterations per us and CU (%.3f us per iteration of the CU's work / W)\n", W, us_per_iter, rate,
-           us_per_iter / W);
-  }
-  printf("(rate at W = 4: %.2f; what six or eight waves per SIMD add to it is what a six- or eight-wave tile workgroup could add to the blend phase)\n", base);
+  };
+  sweep(k_mix<0>, 256, "bare loop (four waves)");
+  sweep(k_mix<1>, 256, "+ the staging share on the wave whose turn it is (four waves, as blend_range)");
+  sweep(k_mix<2>, 320, "+ the staging share on a fifth wave that blends nothing");
   return 0;
 }
