@@ -303,11 +303,20 @@ class Backend : public std::enable_shared_from_this<Backend> {
     }
     std::vector<PendingItem> keep;
     int64_t failed = -1, warned = -1;
-    for (PendingItem& it : items) {
+    for (size_t k = 0; k < items.size(); ++k) {
+      PendingItem& it = items[k];
       const bool mine = only_token >= 0 && it.token == only_token;
       if (only_token >= 0 && !mine) { keep.push_back(it); continue; }
-      if (wait || mine) wait_status(it.host, it.device);
-      else if (!it.host.arrived()) { keep.push_back(it); continue; }
+      if (wait || mine) {
+        try {
+          wait_status(it.host, it.device);
+        } catch (...) {  // (a device error while waiting: nothing is dropped - this item and the ones behind it stay pending)
+          keep.insert(keep.end(), items.begin() + k, items.end());
+          std::lock_guard<std::mutex> g(mu_);
+          pending_.insert(pending_.begin(), keep.begin(), keep.end());
+          throw;
+        }
+      } else if (!it.host.arrived()) { keep.push_back(it); continue; }
       const Status st = take_status(it.host);
       note_status(it.key, it.cfg, st);
       if (st.overflow) {
