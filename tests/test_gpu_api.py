@@ -428,3 +428,49 @@ def test_pack_view_matches_the_torch_assembly_of_the_record():
         f = lambda x: x.reshape(-1)[:1].float() if torch.is_tensor(x) else torch.tensor([x], device=DEV)
         want = pack_views(vm[None], pm[None], campos[None], f(tx), f(ty), bg[None], None, 1.5)
         assert rec.shape == (1, 48) and torch.equal(rec, want)
+
+
+def test_two_host_threads_share_the_process_wide_backend():
+    """The compiled backend releases the GIL around its work and keeps its bookkeeping (capacity hints, pending status copies, caches)
+    under a lock: two host threads rendering different shapes through the process-wide backend, each on a stream of its own, get the
+    images a single thread gets - under the default policy (blocking status reads) and under `lazy` (pending copies verified by
+    whichever thread calls next)."""
+    import threading
+
+    be = rasterizer.HipBackend()
+    old = install_backend(be)
+    try:
+        scenes = [synthetic.make_scene(71, 20000, (96, 96), num_views=2).to(DEV), synthetic.make_scene(72, 9000, (64, 128), num_views=1).to(DEV)]
+        dec = pf3plat_amd.DecoderSplattingCUDA().to(DEV)
+
+        def render(sc):
+            with torch.no_grad():
+                return dec.forward(sc.gaussians, sc.extrinsics, sc.intrinsics, sc.near, sc.far, tuple(sc.image_shape)).color
+
+        want = [render(sc).clone() for sc in scenes]
+        for policy in ("sync", "lazy"):
+            be.sync_policy = policy
+            got, errors = [[], []], []
+
+            def worker(k):
+                try:
+                    stream = torch.cuda.Stream()
+                    with torch.cuda.stream(stream):
+                        for _ in range(25):
+                            got[k].append(render(scenes[k]))
+                    stream.synchronize()
+                except Exception as e:  # pragma: no cover - reported below
+                    errors.append(e)
+
+            threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            be.check_pending(wait=True)
+            assert not errors, errors
+            for k in range(2):
+                assert len(got[k]) == 25 and all(torch.equal(g, want[k]) for g in got[k]), (policy, k)
+        assert not be.pending
+    finally:
+        install_backend(old)
