@@ -407,6 +407,9 @@ def main():
             clocks = device_clocks()
             preheat_steps += 1500
         torch.cuda.synchronize()
+        if dist_on:  # rank 0 has just spent ~0.2 s more than the others: every rank starts its pre-heat together, so that nobody
+            dist.barrier()  # sits idle (and falls back to the low-power clock) in the first window's barrier waiting for rank 0
+            torch.cuda.synchronize()
         t_pre = time.perf_counter()
         for _ in range(100):
             step()

@@ -39,15 +39,13 @@
 #define GSR_ABL(flags, bit) false
 #endif
 
-#ifndef GSR_COLOR_FENCE_NOJ
-#define GSR_COLOR_FENCE_NOJ 0  // scheduling fences between the bands of the compile-time colour evaluation without Jacobian
-#endif
-
 namespace gsr {
 
 constexpr int kChunkMax = 2048;   // most Gaussians per binning workgroup (= one row of the per-view count matrix)
 constexpr int kChunkMin = 1024;
 constexpr int kCUs = 256;
+// de-phasing of a tile launch's first resident round (sort_tile, k_tile_fwd_prefix): group = the workgroup's residency slot on its CU
+constexpr int kDephaseShift = 8, kDephaseGroups = 4;
 constexpr int kBinThreads = 1024; // threads of a binning workgroup (count / emit)
 constexpr int kTileWindow = 8192; // tiles histogrammed in LDS at a time by a binning workgroup of the WINDOWED chain (32 KiB, static)
 #ifndef GSR_FUSED_MAX_TILES
@@ -741,14 +739,9 @@ __device__ __forceinline__ GaussIn load_gauss(const Params& p, int v, int i) {
 template <class F, class B>
 __device__ __forceinline__ PreRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big) {
   const int N = p.d.num_gaussians;
-#ifndef GSR_VIEW_CONST
-#define GSR_VIEW_CONST 0  // (measured: the ~30 scalar registers it takes spill in the binning kernels, forward +0.6 us)
-#endif
-#if GSR_VIEW_CONST
-  const GsrView cam = view_const(p.views, v);  // scalar registers, loaded once: not ~35 per-lane loads in every iteration of the caller
-#else
+  // (per-lane loads of the uniform record: held in scalar registers - view_const, as k_preprocess_bwd does - the ~30 registers spill in
+  // the binning kernels, forward +0.6 us)
   const GsrView& cam = p.views[v];
-#endif
   const Grid& g = p.g;
   const size_t oi = (size_t)v * N + i;
 
@@ -978,9 +971,6 @@ __device__ __forceinline__ void color_eval_lane(const Params& p, int set, int i,
       } else {
         sh_visit(deg, dx, dy, dz, [&](int k, float bk, float, float, float) {
           if (kFull || k < M) {
-#if GSR_COLOR_FENCE_NOJ
-            if (kFull && (k == 4 || k == 9 || k == 16)) __builtin_amdgcn_sched_barrier(0);
-#endif
             cr += bk * sh[k * ks + 0 * cs]; cg += bk * sh[k * ks + 1 * cs]; cb += bk * sh[k * ks + 2 * cs];
           }
         });
@@ -1064,10 +1054,8 @@ __device__ __forceinline__ void color_unit(const Params& p, uint32_t cu, bool va
   if (!in_range || !valid) return;
   const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING) && set == 0 && tid == 0;
   if (dbg) dbg_stamps(p, 16384 + unit)[0] = t_start;
-#ifndef GSR_KCOLOR_FULL
-#define GSR_KCOLOR_FULL 0  // (the stand-alone colour launch lives on bandwidth at eight workgroups per CU: the compile-time instance buys it nothing)
-#endif
-  color_eval<kJ, GSR_KCOLOR_FULL != 0>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, Vs, rmx, rmy, rmz,
+  // (the stand-alone colour launch lives on bandwidth at eight workgroups per CU: the compile-time instance buys it nothing)
+  color_eval<kJ, false>(p, set, i, lds + lane * ldstride, wave, kColorThreads / 64, Vs, rmx, rmy, rmz,
                         cam_lite(p.views, __builtin_amdgcn_readfirstlane(set * Vs + min(wave, Vs - 1))));
   if (dbg) dbg_stamps(p, 16384 + unit)[1] = __builtin_amdgcn_s_memrealtime();
 }
@@ -1118,19 +1106,9 @@ __device__ __forceinline__ void color_unit_wave(const Params& p, int set, int un
   __builtin_amdgcn_s_waitcnt(0);  // the DMA writes count as vector memory operations (vmcnt); the plain LDS stores as lgkmcnt
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (dbg) stamp[2] = __builtin_amdgcn_s_memrealtime();
-#ifndef GSR_EXP_NO_COLOR_EVAL
-#ifndef GSR_COLOR_EVAL_PRIO
-#define GSR_COLOR_EVAL_PRIO 2
-#endif
-  if (GSR_COLOR_EVAL_PRIO) __builtin_amdgcn_s_setprio(GSR_COLOR_EVAL_PRIO);
-#ifndef GSR_COLOR_FULL_J
-#define GSR_COLOR_FULL_J 1
-#endif
-  if (in_range) color_eval<kJ, !kJ || GSR_COLOR_FULL_J>(p, set, i, lds + lane * ldstride, vbegin, 1, vend, rmx, rmy, rmz, cam0);
-  if (GSR_COLOR_EVAL_PRIO) __builtin_amdgcn_s_setprio(0);
-#else
-  if (in_range) p.rgbc[(size_t)(set * p.d.views_per_set + vbegin) * N + i] = make_float4(lds[lane * ldstride], rmx, rmy, rmz);  // experiment: stream without the arithmetic
-#endif
+  __builtin_amdgcn_s_setprio(2);
+  if (in_range) color_eval<kJ, true>(p, set, i, lds + lane * ldstride, vbegin, 1, vend, rmx, rmy, rmz, cam0);
+  __builtin_amdgcn_s_setprio(0);
   if (dbg) stamp[3] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -1927,14 +1905,7 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
     // a CU - HW_ID stamps, tools/tile_timeline.py): the four tiles of a CU are then out of phase with EACH OTHER, one blends
     // while the next still sorts (grouping neighbouring CUs instead: +0.8 us).  Later rounds start whenever a slot frees up.
     if (bid < 1024u) {
-#ifndef GSR_DEPHASE_GROUPS
-#define GSR_DEPHASE_GROUPS 4
-#define GSR_DEPHASE_SLEEP 64
-#endif
-#ifndef GSR_DEPHASE_SHIFT
-#define GSR_DEPHASE_SHIFT 8
-#endif
-      for (int q = 0; q < (int)((bid >> GSR_DEPHASE_SHIFT) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_DEPHASE_SLEEP);
+      for (int q = 0; q < (int)((bid >> kDephaseShift) % kDephaseGroups); ++q) __builtin_amdgcn_s_sleep(64);
     }
     const uint2* col = p.pair_mat + (size_t)v * R * (T + 8) + t;
     const size_t cstride = (size_t)T + 8;
@@ -1967,14 +1938,11 @@ __device__ __forceinline__ uint2 sort_tile(const Params& p, const uint32_t bid, 
     const bool plain = !any_missing && (uint32_t)n <= p.stride && n <= kLds;
     // (the longest list so far, statistics.  Two ways of taking this read off wave 1's path were tried - asked for at the kernel's start:
     // it reads 0 in every tile and a thousand same-address atomics follow, +2 us; asked for here and compared after the run copy: +11 us)
-#ifndef GSR_MAXLIST_LATE
-#define GSR_MAXLIST_LATE 1
-#endif
     // Round 4: for the usual tile (`plain`) the statistic is updated by k_tile_fwd AFTER the tile's image is written - here it sat
     // in front of a barrier, and a barrier waits for the wave's outstanding memory operations: the load of a word every tile of
     // the launch goes for and, for the first tiles to arrive, a device-scope atomic queued behind hundreds of others (see
     // k_tile_fwd_prefix).  A tile that may fail to place its list keeps the early update: the caller sizes its retry from it.
-    if ((!GSR_MAXLIST_LATE || !plain) && tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);
+    if (!plain && tid == 64 && (uint32_t)n > p.status->max_list) atomicMax(&p.status->max_list, (uint32_t)n);
     if (plain) {
       if (tid == 0) p.ranges[tg] = make_uint2((uint32_t)tg * p.stride, (uint32_t)tg * p.stride + (uint32_t)n);
     } else if (tid == 0) {
@@ -2201,9 +2169,6 @@ constexpr int kFwdWaves = 4;
 #ifndef GSR_KFS
 #define GSR_KFS 8
 #endif
-#ifndef GSR_BLEND_ORDER
-#define GSR_BLEND_ORDER 1
-#endif
 constexpr int kFS = GSR_KFS;                  // entries per wave per batch (even)
 constexpr int kFB = kFS * kFwdWaves;          // 32 list entries per batch
 constexpr int kFwdThreads = 64 * kFwdWaves;   // 256
@@ -2254,12 +2219,9 @@ __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* r
                                             const float pyf) {
   auto& sXY = lds.sXY; auto& sAB = lds.sAB; auto& sCO = lds.sCO; auto& sRG = lds.sRG; auto& sBE = lds.sBE;
   auto& sP = lds.sP;
-#ifndef GSR_BLEND_SWAVE
-#define GSR_BLEND_SWAVE 1
-#endif
   // (the wave's number in a SCALAR register: as `threadIdx.x >> 6` it lives in a vector register, and the choice of this wave's starting
   // transmittance among Tb, t1, t2, t3 - wave-uniform - compiled into exec-mask branches and vector compares in every iteration)
-  const int wave = GSR_BLEND_SWAVE ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : (int)(threadIdx.x >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   float Tb = s.Tb, Tmin = s.Tmin;
   f2 al[kFS / 2];                               // alphas of this wave's segment of the batch about to be accumulated
@@ -2339,13 +2301,11 @@ __device__ __forceinline__ bool blend_range(const GeomRec* geom, const float4* r
       CB = __builtin_elementwise_fma(f2{be.x, be.y}, w[u >> 1], CB);
       if (kExtra) CE = __builtin_elementwise_fma(f2{be.z, be.w}, w[u >> 1], CE);
     }
-#if GSR_BLEND_ORDER
     // keep stage A where it is written: its sums are not needed before the next iteration, and left alone the compiler sinks this
     // arithmetic below stage E - the old and the new alphas of the segment are then alive together and the loop pays sixteen
     // register copies per iteration for it
     asm volatile("" : "+v"(CR), "+v"(CG), "+v"(CB), "+v"(Tmin), "+v"(last));
     if (kExtra) asm volatile("" : "+v"(CE));
-#endif
   };
   auto put_records = [&](int sb, float4 q, float2 q2, const float4& c) {  // lane = entry of the batch
     q.z = (-0.5f * kLog2e) * q.z; q.w = (-kLog2e) * q.w; q2.x = (-0.5f * kLog2e) * q2.x;  // to_exp2_domain
@@ -2534,18 +2494,15 @@ __global__ __launch_bounds__(kFwdThreads, (kLds == 2048 && kGather && !kExtra) ?
   // The sort phase is a chain of short instruction bursts between trips to memory and LDS; the blend phase of the other tiles of
   // the CU (de-phased: they are up to 5 us ahead) keeps the SIMDs issuing every cycle.  A wave in its sort phase goes first
   // when both are ready: its next request leaves at once and the blend waves lose nothing they would not lose later (-0.7 us).
-#ifndef GSR_SORT_PRIO
-#define GSR_SORT_PRIO 2
-#endif
-  if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(GSR_SORT_PRIO);
+  __builtin_amdgcn_s_setprio(2);
   const uint2 rg = sort_tile<kGather, kLds>(p, bid, smem, red, sInfo);
-  if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(0);
   if (bid == 0 && threadIdx.x == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;  // the binning launch's (take_pages)
   __syncthreads();  // the list is this workgroup's own: its stores are visible to its waves from here on; the keys are dead
   const int tg = kGather ? xcd_remap((int)bid, (int)p.sort_blocks) : (int)bid;
   const int v = tg / p.g.T;
   blend_tile<kExtra>(p, v, tg - v * p.g.T, rg, *reinterpret_cast<BlendLds*>(smem));
-  if (kGather && GSR_MAXLIST_LATE && threadIdx.x == 64 && rg.y - rg.x > p.status->max_list) atomicMax(&p.status->max_list, rg.y - rg.x);
+  if (kGather && threadIdx.x == 64 && rg.y - rg.x > p.status->max_list) atomicMax(&p.status->max_list, rg.y - rg.x);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2569,9 +2526,6 @@ __global__ __launch_bounds__(kFwdThreads, (kLds == 2048 && kGather && !kExtra) ?
 #ifndef GSR_PREFIX
 #define GSR_PREFIX 512
 #endif
-#ifndef GSR_NO_PREFIX_KERNEL
-#define GSR_NO_PREFIX_KERNEL 0  // 1: measurement builds that time the round-3 tile launch (k_tile_fwd<true, 2048, .>) on the same tree
-#endif
 constexpr int kPrefix = GSR_PREFIX;  // list positions ranked before the blend starts (a multiple of kFB)
 static_assert(kPrefix % kFB == 0 && kPrefix >= 2 * kFB, "the prefix is whole batches");
 
@@ -2587,9 +2541,6 @@ __device__ __forceinline__ void bitonic_whole_list(unsigned long long* sk, uint3
   for (int k = threadIdx.x; k < n; k += kSortThreads) out[k] = (uint32_t)sk[k];
 }
 
-#ifndef GSR_PF_COMPACT
-#define GSR_PF_COMPACT 1  // 0: measurement builds without the compact instance
-#endif
 #ifndef GSR_PF_COMPACT_MIN_TILES
 #define GSR_PF_COMPACT_MIN_TILES (5 * kCUs)  // calls with more tiles than this take the compact instance
 #endif
@@ -2614,15 +2565,12 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
   __shared__ uint32_t sCount;
-#ifndef GSR_PF_EARLY_STATUS
-#define GSR_PF_EARLY_STATUS 1  // status->overflow asked for at the kernel's start instead of between the sort and the blend
-#endif
   const uint32_t bid = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (overflow is raised by tiles of THIS launch only - a tile that cannot place its list - and such a tile poisons its own pixels
   // whatever it read here; for everybody else the flag is a courtesy whose outcome depends on timing either way)
   uint32_t overflow_early = 0;
-  if (GSR_PF_EARLY_STATUS && tid == 0) overflow_early = p.status->overflow;
+  if (tid == 0) overflow_early = p.status->overflow;  // (asked for at the kernel's start, not between the sort and the blend)
   unsigned long long* sk = smem;
   uint32_t* hist = reinterpret_cast<uint32_t*>(smem + kLds);
   uint32_t* cur = hist;
@@ -2638,18 +2586,15 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   unsigned long long* stamp2 = dbg_stamps(p, 8192 + p.sort_blocks + bid);
 #define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define GSR_STAMP2(k) do { if (dbg && tid == 0) stamp2[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(GSR_SORT_PRIO);
+  __builtin_amdgcn_s_setprio(2);
   GSR_STAMP(0);
   const int T = p.g.T, R = p.rows;
   const int tg = xcd_remap((int)bid, (int)p.sort_blocks);
   const int v = tg / T, t = tg - v * T;
   // (de-phasing of the first resident round: see sort_tile.  With this kernel's shorter gather 1 us between the four groups is
   // enough: sleeps of 16 / 24 / 32 / 40 / 64 gave 53.0 / 52.9 / 53.0 / 53.0 / 53.9 us for the forward)
-#ifndef GSR_PF_DEPHASE_SLEEP
-#define GSR_PF_DEPHASE_SLEEP 32
-#endif
   if (bid < 1024u)
-    for (int q = 0; q < (int)((bid >> GSR_DEPHASE_SHIFT) % GSR_DEPHASE_GROUPS); ++q) __builtin_amdgcn_s_sleep(GSR_PF_DEPHASE_SLEEP);
+    for (int q = 0; q < (int)((bid >> kDephaseShift) % kDephaseGroups); ++q) __builtin_amdgcn_s_sleep(32);
   // ---- gather: column (v, :, t) of the pair matrix, one row per thread
   uint2 e0 = make_uint2(0u, 0u);
   uint32_t bb0 = 0;
@@ -2796,7 +2741,7 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   if (bucketed) rank_positions(0u, ranked);
   GSR_STAMP(5);
   GSR_STAMP(6);
-  if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(0);
+  __builtin_amdgcn_s_setprio(0);
   if (bid == 0 && tid == 0) *p.page_counter = (unsigned long long)p.call_tag << 32;  // the binning launch's (take_pages)
   __syncthreads();  // the list is this workgroup's own: its stores are visible to its waves from here on
   // ---- blend: the ranked prefix (whole batches of it), then - only if some pixel is still open - the rest
@@ -2823,7 +2768,7 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
     }
   };
   // (usual path: the flag as thread 0 read it at the kernel's start, handed round through LDS - the same value in every wave)
-  if ((GSR_PF_EARLY_STATUS && fast_path) ? (sInfo[3] != 0u && blend_poisoned<kExtra>(p, v, pxi, pyi, inside, true))
+  if (fast_path ? (sInfo[3] != 0u && blend_poisoned<kExtra>(p, v, pxi, pyi, inside, true))
                                           : blend_poisoned<kExtra>(p, v, pxi, pyi, inside)) {
     report_length();
     return;
@@ -2847,9 +2792,9 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
     bool done = blend_range<kExtra, kCompact>(geom, rgbc, plist, whole ? n : b1 * kFB, b0, b1, blds, acc, (float)pxi, (float)pyi);
     done = done || whole || __all(acc.Tb < 0.0001f);  // (Tb: the same bits in all four waves)
     if (done) break;
-    if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(GSR_SORT_PRIO);
+    __builtin_amdgcn_s_setprio(2);
     rank_positions(ranked, n);
-    if (GSR_SORT_PRIO) __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_s_setprio(0);
     ranked = n;
     b0 = b1;
     __syncthreads();
@@ -2943,12 +2888,6 @@ __device__ __forceinline__ float from_fixed(long long x) { return (float)x * kFi
 // tiles out across the whole chip by load was measured - the gathers then miss, prologue 3.0 -> 4.1 us, no gain), but inside
 // the XCD they are dealt to its 32 CUs heaviest first, every other round mirrored.  Work of a tile = list entries the forward
 // walked (Params::tile_total); every workgroup finds its own tile: a selection by bisection over the <= 256 keys of its XCD, one wave, ballots only.
-#ifndef GSR_BWD_BALANCE
-#define GSR_BWD_BALANCE 1
-#endif
-#ifndef GSR_BWD_WAITALL
-#define GSR_BWD_WAITALL 1
-#endif
 constexpr int kBalanceMax = 256;  // tiles per XCD up to which the deal is computed (more: image order; later rounds balance themselves)
 
 template <bool kExtra, bool kDet>
@@ -2964,7 +2903,6 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int v = blockIdx.y;
   int t = xcd_remap(blockIdx.x, g.T);
-#if GSR_BWD_BALANCE
   {
     __shared__ int sPick;
     const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3, q8 = g.T >> 3, r8 = g.T & 7;
@@ -2999,7 +2937,6 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
       t = base + sPick;
     }
   }
-#endif
   const int tx = t % g.sgx, ty = t / g.sgx;
 #ifdef GSR_BWD_LONE  // measurement aid: one workgroup per CU (how fast is a tile that has its SIMDs to itself?)
   if (blockIdx.x >= 256 * GSR_BWD_LONE) return;
@@ -3295,12 +3232,10 @@ __global__ __launch_bounds__(kBwdThreads, 4) void k_blend_bwd(const Params p) {
     // the sums are FINISHED here, in the reduction's own basic block: left to itself the compiler sinks the last step of the
     // DPP all-reduce below the branch that follows, where a cross-lane move can no longer be folded into its add (+18 VALU)
     asm volatile("" : "+v"(rs.val), "+v"(rs.tail), "+v"(rs.id));
-#if GSR_BWD_WAITALL
     // every wave: nothing of its own is in flight past this point except the atomics that follow (an explicit wait the compiler
     // sees: without it, it has to assume at the top of the loop that a request of an earlier iteration may still be pending on
     // the registers the next one writes, and waits there for the previous iteration's ATOMICS)
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
-#endif
     if (wave == (int)((it + 2) & 3) && it + 2 < nbat) park((int)((it + 2) & 3), sg, sg2, sc, id_next);
     asm volatile("" ::: "memory");
     scatter(rs);
@@ -3405,14 +3340,7 @@ __global__ __launch_bounds__(64) void k_preprocess_bwd(const Params p) {
   bool seen = false;
   for (int vv = 0; vv < Vs; ++vv) {
     const int v = set * Vs + vv;
-#ifndef GSR_BWD_VIEW_CONST
-#define GSR_BWD_VIEW_CONST 1  // the view record in scalar registers: -2 us (the per-lane loads of the uniform record held ~35 VGPRs)
-#endif
-#if GSR_BWD_VIEW_CONST
-    const GsrView cam = view_const(p.views, v);
-#else
-    const GsrView& cam = p.views[v];
-#endif
+    const GsrView cam = view_const(p.views, v);  // the view record in scalar registers: -2 us (the per-lane loads of the uniform record held ~35 VGPRs)
     const size_t oi = (size_t)v * N + (in_range ? i : 0);
     float sg[12];
 #pragma unroll
@@ -4311,11 +4239,11 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     // instance those were better off with k_tile_fwd's smaller LDS footprint (192 vs 217 us for that view, round 4); the COMPACT
     // instance (25.8 KB, 80 registers: six workgroups per CU, like k_tile_fwd's) keeps its cheaper gather - no scan over the rows,
     // four barriers fewer - and takes them when the call has more tiles than the chip holds at once: that view 174.3 -> 167.3 us.
-    else if (p.stride <= 2048u && (p.stride > (uint32_t)(kPrefix + kPrefix / 4) || (GSR_PF_COMPACT && VT > (size_t)GSR_PF_COMPACT_MIN_TILES)) &&
-             p.rows <= kSortThreads && !GSR_NO_PREFIX_KERNEL) {
+    else if (p.stride <= 2048u && (p.stride > (uint32_t)(kPrefix + kPrefix / 4) || VT > (size_t)GSR_PF_COMPACT_MIN_TILES) &&
+             p.rows <= kSortThreads) {
       // (more tiles than five workgroups per CU hold at once: the compact instance, six per CU.  Round 5: with the extra channel too - until
       // stage A formed its weights after the death decision (blend_range) that instance spilled the record in flight at 80 registers)
-      const bool compact = VT > (size_t)GSR_PF_COMPACT_MIN_TILES && GSR_PF_COMPACT;
+      const bool compact = VT > (size_t)GSR_PF_COMPACT_MIN_TILES;
       if (d.has_extra && compact) hipLaunchKernelGGL((k_tile_fwd_prefix<true, true>), tgrid, dim3(kFwdThreads), 0, st, p);
       else if (d.has_extra) hipLaunchKernelGGL((k_tile_fwd_prefix<true, false>), tgrid, dim3(kFwdThreads), 0, st, p);
       else if (compact) hipLaunchKernelGGL((k_tile_fwd_prefix<false, true>), tgrid, dim3(kFwdThreads), 0, st, p);
