@@ -44,7 +44,7 @@ fi
 timeout 120 ./tools/micro/blend_mix_bench > $O/blend_mix_bench.txt 2>&1
 cat $O/blend_mix_bench.txt
 if [ "$FUZZ" != "0" ]; then
-  timeout 1500 python tools/fuzz_parity.py --cases $FUZZ --seeds 11,12,13,14,15 --out $O/fuzz.json > $O/fuzz.log 2>&1
+  timeout 1500 python tools/fuzz_parity.py --cases $FUZZ --seeds ${FUZZ_SEEDS:-11,12,13,14,15} --out $O/fuzz.json > $O/fuzz.log 2>&1
   tail -2 $O/fuzz.log
   python tools/fuzz_report.py $O/fuzz.json $O/fuzz_histogram.md > /dev/null 2>&1
 fi
