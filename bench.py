@@ -207,7 +207,7 @@ def main():
                          "ranks); ms_per_step / value report the MEDIAN window, every window is listed in config.windows")
     ap.add_argument("--config5-gaussians", type=int, default=131072, help=argparse.SUPPRESS)  # (tests: the config-5 leg at a small size)
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 PMC passes behind roofline.traffic")
-    ap.add_argument("--traffic-child", choices=("fwd", "train", "cfg4_fwd", "cfg4_train", "views8", "views48"), default=None,
+    ap.add_argument("--traffic-child", choices=("fwd", "train", "cfg4_fwd", "cfg4_train", "views8", "views48", "shard131k", "cfg4s_fwd", "cfg4s_train"), default=None,
                     help=argparse.SUPPRESS)  # the runs the PMC passes / tools/profile_round.sh profile
     args = ap.parse_args()
 
@@ -260,10 +260,10 @@ def main():
 
     from pf3plat_amd import _lib as _gl0
 
-    def many_view_call(seed, n_g, n_views, offsets, extra_mode=0, train=False):
+    def many_view_call(seed, n_g, n_views, offsets, extra_mode=0, train=False, structure="random"):
         """V views of ONE scene in one launch chain through the plan API, workspace sized from a first call's status:
         -> dict(plan, ins, vb, cfg, status).  extra_mode 1: colour + depth (GSR_EXTRA_DEPTH built in), train: a backward follows."""
-        sc_m = synthetic.make_scene(seed, n_g, (H, W), d_sh=D_SH, num_views=n_views, view_offsets=offsets)
+        sc_m = synthetic.make_scene(seed, n_g, (H, W), d_sh=D_SH, num_views=n_views, view_offsets=offsets, structure=structure)
         ins_m = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc_m))
         vb_m = synthetic.scene_viewbuf(sc_m).to(dev)
         fl = (_gl0.FLAG_BACKWARD_FOLLOWS if train else 0) | (extra_mode << 4)
@@ -274,8 +274,11 @@ def main():
         plan_m = be.make_plan(cfg_m, dev, capacity=be.capacity_for(cfg_m, st_m, headroom=1.1), backward=train)
         return dict(plan=plan_m, ins=ins_m, vb=vb_m, cfg=cfg_m, status=st_m)
 
-    def config4_call(train):  # BASELINE configs[3]: B = 1, G = 131 072, V = 3 target views, colour + depth (decoder_splatting_cuda.py:35-67)
-        return many_view_call(50, 131072, 3, None, extra_mode=1, train=train)
+    def config4_call(train, structure="random"):  # BASELINE configs[3]: B = 1, G = 131 072, V = 3 target views, colour + depth (decoder_splatting_cuda.py:35-67)
+        return many_view_call(50, 131072, 3, None, extra_mode=1, train=train, structure=structure)
+
+    def shard131k_call():  # BASELINE configs[4], one GPU's share: one DL3DV-shaped scene of 131 072 Gaussians, ONE target view, colour only
+        return many_view_call(50, 131072, 1, None)
 
     def views8_call():
         offs8 = torch.randn(8, generator=torch.Generator().manual_seed(8)).mul(0.05).tolist()
@@ -284,14 +287,15 @@ def main():
     def views48_call():
         return many_view_call(50, 131072, 48, torch.linspace(-0.45, 0.45, 48).tolist())
 
-    if args.traffic_child in ("cfg4_fwd", "cfg4_train", "views8", "views48"):  # profiled by tools/profile_round.sh (rocprofv3)
+    if args.traffic_child in ("cfg4_fwd", "cfg4_train", "views8", "views48", "shard131k", "cfg4s_fwd", "cfg4s_train"):  # profiled by tools/profile_round*.sh (rocprofv3)
         c = {"cfg4_fwd": lambda: config4_call(False), "cfg4_train": lambda: config4_call(True), "views8": views8_call,
-             "views48": views48_call}[args.traffic_child]()
+             "views48": views48_call, "shard131k": shard131k_call, "cfg4s_fwd": lambda: config4_call(False, "pixel_aligned"),
+             "cfg4s_train": lambda: config4_call(True, "pixel_aligned")}[args.traffic_child]()
         gc_c = torch.rand((c["cfg"].num_views, 3, H, W), device=dev)
         ge_c = torch.rand((c["cfg"].num_views, H, W), device=dev)
         for _ in range(150 if c["cfg"].num_views < 48 else 40):
             be.run_forward(c["plan"], c["vb"], *c["ins"])
-            if args.traffic_child == "cfg4_train":
+            if args.traffic_child in ("cfg4_train", "cfg4s_train"):
                 be.run_backward(c["plan"], c["vb"], *c["ins"], None, gc_c, ge_c)
         torch.cuda.synchronize()
         return

@@ -10,6 +10,7 @@ import ctypes
 import os
 import shutil
 import subprocess
+import warnings
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 REPO_ROOT = os.path.dirname(_HERE)
@@ -79,6 +80,14 @@ def is_stale() -> bool:
     except OSError:
         t = os.path.getmtime(LIB_PATH)  # (a library from before the stamp file existed)
         return any(os.path.getmtime(s) > t for s in (SRC, HEADER))
+
+
+class RasterOverflowWarning(RuntimeWarning):
+    """A deferred training forward outgrew its pair workspace: its image is NaN and its backward returns NaN gradients
+    (`on_overflow = "nan"`).  Registered with the "always" filter: every such step is reported, not the first one per location."""
+
+
+warnings.simplefilter("always", RasterOverflowWarning)
 
 
 def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str = None) -> str:

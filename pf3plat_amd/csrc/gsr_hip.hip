@@ -42,7 +42,8 @@
 namespace gsr {
 
 constexpr int kChunkMax = 2048;   // most Gaussians per binning workgroup (= one row of the per-view count matrix)
-constexpr int kChunkMin = 1024;
+constexpr int kChunkMin = 1024;    // ... unless ONE round of smaller chunks (down to kChunkSmall) still fits the chip: see choose_chunk
+constexpr int kChunkSmall = 512;
 constexpr int kCUs = 256;
 // de-phasing of a tile launch's first resident round (sort_tile, k_tile_fwd_prefix): group = the workgroup's residency slot on its CU
 constexpr int kDephaseShift = 8, kDephaseGroups = 4;
@@ -136,8 +137,13 @@ static int choose_chunk(const GsrDims& d) {
   const long long slots = plain_two ? 2 * kCUs : kCUs;
   long long best_cost = -1;
   int best = kChunkPrefer;
-  for (int c = kChunkPrefer; c >= kChunkMin; c -= 64) {
+  for (int c = kChunkPrefer; c >= kChunkSmall; c -= 64) {
     const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + slots - 1) / slots) * c;
+    // chunks below kChunkMin only while a single round of workgroups holds them all: one 131 072-Gaussian view (configs[4]'s share of
+    // a GPU, PF3plat's native size) took 128 workgroups of 1024 - half the chip idle through the whole binning launch (19.5 us); 256
+    // workgroups of 512 are one projection pass per wave instead of two.  With several rounds the per-workgroup prologue, scan and
+    // copy-out are paid per round: there the larger chunks stay.
+    if (c < kChunkMin && blocks > slots) break;
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = c; }
   }
   return best;
@@ -889,11 +895,16 @@ __global__ __launch_bounds__(kPreThreads) void k_preprocess(const Params p) {
 // Only the rare workgroup that outgrows its fixed slot / the rare list longer than the LDS sort comes here.
 __device__ __forceinline__ uint32_t take_pages(unsigned long long* counter, uint32_t call_tag, uint32_t n) {
   const unsigned long long tag = (unsigned long long)call_tag << 32;
+  // Once the counter carries this call's tag it keeps it until the launch is over (the reset is the OTHER launch's): from then on a
+  // taker is ONE fetch-add.  Only the takers that still see a foreign tag compete with compare-and-swap - one of them installs the
+  // tag, the others see it in what their failed attempt returns.  (Round 5 looped on compare-and-swap throughout: on the pixel-aligned
+  // scene a third of the 246 binning workgroups of a configs[3] call outgrow their slot within the same microsecond, every failed
+  // attempt is a round trip to the memory side of the fabric, and the workgroups spent 28-38 us here - profiles/r06_a_stamps_*.)
   unsigned long long cur = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   while (true) {
-    const unsigned long long base = (cur >> 32) == (tag >> 32) ? cur : tag;
-    const unsigned long long seen = atomicCAS(counter, cur, base + n);
-    if (seen == cur) return (uint32_t)base;
+    if ((cur >> 32) == (tag >> 32)) return (uint32_t)atomicAdd(counter, (unsigned long long)n);
+    const unsigned long long seen = atomicCAS(counter, cur, tag + n);
+    if (seen == cur) return 0u;
     cur = seen;
   }
 }
@@ -2465,7 +2476,8 @@ __device__ __forceinline__ void blend_tile(const Params& p, const int v, const i
   (void)blend_range<kExtra>(p.geom + (size_t)v * p.d.num_gaussians, p.rgbc + (size_t)v * p.d.num_gaussians, p.point_list + rg.x, n, 0u,
                             (n + kFB - 1) / kFB, lds, acc, (float)pxi, (float)pyi);
   if (dbg && threadIdx.x == 0) {
-    unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
+    unsigned long long* o = dbg_stamps(p, 24576 + (size_t)v * g.T + t);  // (NOT over the binning workgroups' key slots: with more than one
+    //                                        resident round a later tile still gathers from them when an earlier one stamps)
     // where it ran: HW_ID (id 4: wave, simd, pipe, cu, sh, se ...) and XCC_ID (id 20), 16 bits each
     const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
                         ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
@@ -2526,6 +2538,9 @@ __global__ __launch_bounds__(kFwdThreads, (kLds == 2048 && kGather && !kExtra) ?
 #ifndef GSR_PREFIX
 #define GSR_PREFIX 512
 #endif
+#ifndef GSR_LONG_RUN
+#define GSR_LONG_RUN 24  // runs of more keys than this are copied by the whole workgroup (k_tile_fwd_prefix)
+#endif
 constexpr int kPrefix = GSR_PREFIX;  // list positions ranked before the blend starts (a multiple of kFB)
 static_assert(kPrefix % kFB == 0 && kPrefix >= 2 * kFB, "the prefix is whole batches");
 
@@ -2564,7 +2579,7 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   BlendLds& blds = *reinterpret_cast<BlendLds*>(kCompact ? smem + kLds + kCounterWords : blds_own);
   __shared__ uint32_t red[8];
   __shared__ uint32_t sInfo[4];
-  __shared__ uint32_t sCount;
+  __shared__ uint32_t sCount, sLongRuns, sLongKeys;
   const uint32_t bid = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // (overflow is raised by tiles of THIS launch only - a tile that cannot place its list - and such a tile poisons its own pixels
@@ -2603,7 +2618,7 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
     bb0 = p.blk_base[(size_t)v * R + tid];
   }
   for (int k = tid; k < (kCompact ? kBk / 2 : kBk); k += kSortThreads) hist[k] = 0;  // (while the column is on its way)
-  if (tid == 0) sCount = 0;
+  if (tid == 0) { sCount = 0; sLongRuns = 0; sLongKeys = 0; }
   __syncthreads();
   GSR_STAMP2(0);
   const bool has = e0.y != 0u, miss = has && bb0 == 0xffffffffu;
@@ -2618,16 +2633,41 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   const bool fits = start0 + e0.y <= (uint32_t)kLds;
   GSR_STAMP2(1);
   uint32_t lo = 0xffffffffu, hi = 0u;
-  if (has && !miss && fits) {
+  auto take = [&](unsigned long long* d, unsigned long long key) {
+    *d = key;
+    const uint32_t dep = (uint32_t)(key >> 32);
+    lo = dep < lo ? dep : lo;
+    hi = dep > hi ? dep : hi;
+  };
+  // LONG runs (round 6).  Gaussians that arrive in the raster order of the images they were predicted from - what PF3plat's encoder
+  // emits - put a binning workgroup's whole chunk into a narrow band of the target view: a tile then draws its list from a handful of
+  // rows, 50-200 keys each, and one thread copying such a run six keys per round trip was the longest phase of the tile (10.4 us
+  // "runs to LDS" against 1.4-2.0 on the independently drawn scene: profiles/r06_a_stamps_config4_structured.txt).  A run of more
+  // than kLongRun keys is therefore not copied by its thread: the thread leaves a descriptor (source, place, length, running total)
+  // in LDS - the blend's area, idle until the blend - and behind the barrier all 256 threads copy the long runs' keys side by side,
+  // every load of a thread requested before its first store.  Short runs (every run of the independently drawn scenes) go as before.
+  constexpr uint32_t kLongRun = GSR_LONG_RUN;
+  uint4* ldesc = reinterpret_cast<uint4*>(&blds);  // up to kLds / kLongRun descriptors of 16 bytes
+  static_assert(sizeof(BlendLds) >= (size_t)(kLds / GSR_LONG_RUN + 1) * 16, "descriptors of the long runs fit the blend's area");
+  const bool is_long = has && !miss && fits && e0.y > kLongRun;
+  if (__any((int)is_long)) {  // wave-uniform
+    const uint32_t lcnt = is_long ? e0.y : 0u;
+    const uint32_t lincl = wave_inclusive_scan_u32(lcnt);
+    const unsigned long long lmask = __ballot((int)is_long);
+    uint32_t kbase = 0, dbase = 0;
+    if (lane == 63) {
+      kbase = atomicAdd(&sLongKeys, lincl);
+      dbase = atomicAdd(&sLongRuns, (uint32_t)__popcll(lmask));
+    }
+    kbase = (uint32_t)__builtin_amdgcn_readlane((int)kbase, 63);
+    dbase = (uint32_t)__builtin_amdgcn_readlane((int)dbase, 63);
+    if (is_long)
+      ldesc[dbase + (uint32_t)__popcll(lmask & ((1ull << lane) - 1ull))] = make_uint4(bb0 + e0.x, start0, e0.y, kbase + lincl - lcnt);
+  }
+  if (has && !miss && fits && !is_long) {
     // six keys per step as three 16-byte loads issued together; the loads may run one key past the run (the buffer is padded)
     const unsigned long long* src = p.keys + bb0 + e0.x;
     unsigned long long* d0 = sk + start0;
-    auto take = [&](unsigned long long* d, unsigned long long key) {
-      *d = key;
-      const uint32_t dep = (uint32_t)(key >> 32);
-      lo = dep < lo ? dep : lo;
-      hi = dep > hi ? dep : hi;
-    };
     for (uint32_t j = 0; j < e0.y; j += 6) {
       const ull2 a = *reinterpret_cast<const ull2*>(src + j);
       ull2 b = {0ull, 0ull}, c = {0ull, 0ull};
@@ -2648,6 +2688,46 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   if (tid == 0) sInfo[3] = overflow_early;
   __shared__ uint32_t sAnyBad[kSortThreads / 64];
   const bool bad = block_any(miss || (has && !fits), sAnyBad);
+  if (sLongRuns != 0u) {  // workgroup-uniform (written before the barrier inside block_any)
+    const uint32_t nruns = sLongRuns, nkeys = sLongKeys;
+    // flat index f over the long runs' keys -> (run, position): the descriptors carry their running total; a thread's up to Q keys are
+    // independent loads, all requested before the first of them is stored
+    constexpr int QL = kLds / kSortThreads;
+    unsigned long long kv[QL];
+    uint32_t dst[QL];
+    uint32_t r = 0;
+    uint4 dsc = ldesc[0];
+#pragma unroll
+    for (int q = 0; q < QL; ++q) {
+      const uint32_t f = (uint32_t)tid + (uint32_t)q * kSortThreads;
+      dst[q] = 0xffffffffu;
+      kv[q] = 0ull;
+      if (f < nkeys) {
+        // (descriptor slots were handed out wave by wave, so their running totals are not sorted: search them all - there are few)
+        if (!(f >= dsc.w && f - dsc.w < dsc.z)) {
+          for (r = 0; r < nruns; ++r) {
+            dsc = ldesc[r];
+            if (f >= dsc.w && f - dsc.w < dsc.z) break;
+          }
+        }
+        kv[q] = p.keys[(size_t)dsc.x + (f - dsc.w)];
+        dst[q] = dsc.y + (f - dsc.w);
+      }
+    }
+    uint32_t lo2 = 0xffffffffu, hi2 = 0u;
+#pragma unroll
+    for (int q = 0; q < QL; ++q)
+      if (dst[q] != 0xffffffffu) {
+        sk[dst[q]] = kv[q];
+        const uint32_t dep = (uint32_t)(kv[q] >> 32);
+        lo2 = dep < lo2 ? dep : lo2;
+        hi2 = dep > hi2 ? dep : hi2;
+      }
+    hi2 = wave_max_u32(hi2);
+    lo2 = ~wave_max_u32(~lo2);
+    if (lane == 0) { red[wave] = min(red[wave], lo2); red[4 + wave] = max(red[4 + wave], hi2); }  // (this lane wrote them above)
+    __syncthreads();  // the long runs' keys are in place, the depth range covers them
+  }
   GSR_STAMP2(2);
   GSR_STAMP(1);
   uint32_t n = sCount, ranked = 0, obase = (uint32_t)tg * p.stride;
@@ -2800,7 +2880,8 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
     __syncthreads();
   }
   if (dbg && tid == 0) {
-    unsigned long long* o = p.keys + ((size_t)v * g.T + t) * 4;
+    unsigned long long* o = dbg_stamps(p, 24576 + (size_t)v * g.T + t);  // (NOT over the binning workgroups' key slots: with more than one
+    //                                        resident round a later tile still gathers from them when an earlier one stamps)
     const unsigned hw = (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xffffu) |
                         ((__builtin_amdgcn_s_getreg(20 | (0 << 6) | (15 << 11)) & 0xfu) << 16);
     o[0] = tm0; o[1] = ((unsigned long long)hw << 32); o[2] = __builtin_readcyclecounter();

@@ -21,6 +21,7 @@
 #include <dlfcn.h>
 
 #include <chrono>
+#include <cmath>
 #include <map>
 #include <mutex>
 #include <set>
@@ -197,9 +198,12 @@ class Backend : public std::enable_shared_from_this<Backend> {
   // policy (see pf3plat_amd/rasterizer.py::HipBackend for the full statement)
   std::string sync_policy = "sync";  // or "lazy"
   int defer_after = 4;
-  std::string on_overflow = "nan";   // or "raise"
+  std::string on_overflow = "raise";  // or "nan": opted into by callers whose loop skips NaN-gradient steps (DecoderSplattingCUDA does)
   bool defer_status = false;
   double spin_us = 300.0;
+  // head-room of a workspace sized from a shape's history: running maximum x clamp(1 + headroom_sigmas x sigma / mean, headroom_min, headroom_max)
+  // of the pair counts seen for the shape (a new scene every step: tools/skip_rate.py -> profiles/r06_skip_rate.md)
+  double headroom_min = 1.25, headroom_max = 3.0, headroom_sigmas = 4.0;
 
   ~Backend() {
     for (Pinned& p : pool_) (void)hipHostFree((void*)p.q);
@@ -211,10 +215,16 @@ class Backend : public std::enable_shared_from_this<Backend> {
   std::map<ShapeKey, int64_t> seen() { std::lock_guard<std::mutex> g(mu_); return seen_; }
   std::vector<int64_t> pending_tokens() { std::lock_guard<std::mutex> g(mu_); std::vector<int64_t> t; for (auto& p : pending_) t.push_back(p.token); return t; }
   std::vector<int64_t> poisoned_tokens() { std::lock_guard<std::mutex> g(mu_); return std::vector<int64_t>(poisoned_.begin(), poisoned_.end()); }
-  bool has_status() const { return has_status_; }
+  bool has_status() { std::lock_guard<std::mutex> g(mu_); return has_status_; }
   bool any_pending() { std::lock_guard<std::mutex> g(mu_); return !pending_.empty(); }
-  Status last_status() const { return last_; }
+  Status last_status() { std::lock_guard<std::mutex> g(mu_); return last_; }
   void set_capacity_hint(const ShapeKey& k, int64_t v) { std::lock_guard<std::mutex> g(mu_); hint_[k] = v; }
+  // the head-room factor the next deferred / lazy call of this shape is sized with (1.25 until two status blocks have been read)
+  double headroom_for(const ShapeKey& k) {
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = stats_.find(k);
+    return it == stats_.end() ? headroom_min : factor_of(it->second);
+  }
 
   int64_t capacity_for(const Cfg& cfg, const Status& st, double headroom = 1.25) const {
     const GsrDims d = cfg.dims(0);
@@ -228,7 +238,6 @@ class Backend : public std::enable_shared_from_this<Backend> {
     std::lock_guard<std::mutex> g(mu_);
     ws_cache_.clear();
     sizes_.clear();
-    poisoned_.clear();
   }
   size_t workspace_cache_size() { std::lock_guard<std::mutex> g(mu_); return ws_cache_.size(); }
 
@@ -251,7 +260,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
     }
     if (cap_status != hipStreamCaptureStatusNone) {  // nothing can be read back while a graph is being captured: the caller sizes
       TORCH_CHECK(capacity > 0 || known, "gsr_forward under stream capture: pass `capacity` (or run the shape once outside the capture)");
-      Plan plan = make_plan(cfg, dev, capacity > 0 ? capacity : default_capacity(cfg), false);
+      Plan plan = make_plan(cfg, dev, capacity > 0 ? capacity : default_capacity(cfg), false, one_view);
       run_forward(plan, cfg, viewbuf, means, cov, opac, colors, extra, frames, stream);
       ForwardOut o{plan.color, plan.extra_img, plan.radii, {}};
       o.saved = Saved{true, plan.dims, plan.geom, plan.bin, plan.img, 0};
@@ -325,6 +334,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
           warned = st.num_pairs;
           std::lock_guard<std::mutex> g(mu_);
           poisoned_.insert(it.token);
+          while (poisoned_.size() > 4096) poisoned_.erase(poisoned_.begin());
         }
       }
     }
@@ -334,11 +344,14 @@ class Backend : public std::enable_shared_from_this<Backend> {
     }
     if (warned >= 0) {
       const std::string msg = "pf3plat_amd rasterizer: a training forward needed " + std::to_string(warned) +
-                              " (tile, Gaussian) pairs, more than 1.25x the largest count seen for its shape: its image is NaN and its backward "
+                              " (tile, Gaussian) pairs, more than the head-room over the largest count seen for its shape: its image is NaN and its backward "
                               "returns NaN gradients (the step is skipped by a NaN-gradient guard such as the reference's); the workspace has "
                               "been enlarged for the next step.";
       pybind11::gil_scoped_acquire gil;  // (the backward runs on one of the engine's threads)
-      if (PyErr_WarnEx(PyExc_RuntimeWarning, msg.c_str(), 1) < 0) throw pybind11::error_already_set();
+      // pf3plat_amd._lib.RasterOverflowWarning: a RuntimeWarning registered with the "always" filter - EVERY skipped step is reported,
+      // not the first one per code location
+      pybind11::object cls = pybind11::module_::import("pf3plat_amd._lib").attr("RasterOverflowWarning");
+      if (PyErr_WarnEx(cls.ptr(), msg.c_str(), 1) < 0) throw pybind11::error_already_set();
     }
     if (failed >= 0)
       throw std::runtime_error("an earlier gsr_forward needed " + std::to_string(failed) +
@@ -346,14 +359,13 @@ class Backend : public std::enable_shared_from_this<Backend> {
                                "re-run the step (or use sync_policy='sync' with defer_after = 0).");
   }
 
-  // -> true when that forward overflowed and the policy is to answer with NaN gradients instead of raising
+  // -> true when that forward overflowed and the policy is to answer with NaN gradients instead of raising.  The token STAYS in the
+  // set: every backward over that forward (retain_graph, several autograd.grad calls) gets the same answer - numbers computed from an
+  // overflowed forward's workspace are meaningless.  (Tokens only grow; the set keeps the newest 4096.)
   bool verify_own_forward(int64_t token) {
     if (any_pending()) check_pending(false, token);
     std::lock_guard<std::mutex> g(mu_);
-    auto it = poisoned_.find(token);
-    if (it == poisoned_.end()) return false;
-    poisoned_.erase(it);
-    return true;
+    return poisoned_.count(token) != 0;
   }
 
   // -> d_means, d_cov, d_opac, d_colors, d_extra, d_means2d, d_views (undefined where not asked for)
@@ -557,8 +569,37 @@ class Backend : public std::enable_shared_from_this<Backend> {
     return st;
   }
 
+  // What a shape's pair counts have looked like so far (Welford), and the largest count / longest list among them
+  struct ShapeStats {
+    int64_t n = 0, max_pairs = 0;
+    int max_list = 0;
+    double mean = 0.0, m2 = 0.0;
+  };
+  double factor_of(const ShapeStats& s) const {
+    double f = headroom_min;
+    if (s.n >= 2 && s.mean > 0.0) f = std::max(f, 1.0 + headroom_sigmas * std::sqrt(s.m2 / (double)(s.n - 1)) / s.mean);
+    return std::min(f, std::max(headroom_max, headroom_min));
+  }
+
+  // The capacity hint of a shape = what its largest pair count (and longest list) seen so far needs, times the head-room factor.  A
+  // loop over one scene sees sigma = 0 and keeps 1.25x; a training run that meets a new scene every step widens the factor to
+  // 1 + 4 sigma / mean (capped at 3x) - head-room costs workspace bytes, not time, and a deferred forward that outgrows it costs a step.
   void note_status(const ShapeKey& key, const Cfg& cfg, const Status& st) {
-    const int64_t need = capacity_for(cfg, st);
+    Status top;
+    double f;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      ShapeStats& s = stats_[key];
+      s.n += 1;
+      const double d = (double)st.num_pairs - s.mean;
+      s.mean += d / (double)s.n;
+      s.m2 += d * ((double)st.num_pairs - s.mean);
+      s.max_pairs = std::max(s.max_pairs, st.num_pairs);
+      s.max_list = std::max(s.max_list, st.max_list);
+      top.num_pairs = s.max_pairs; top.max_list = s.max_list;
+      f = factor_of(s);
+    }
+    const int64_t need = capacity_for(cfg, top, f);
     std::lock_guard<std::mutex> g(mu_);
     last_ = st;
     has_status_ = true;
@@ -569,6 +610,7 @@ class Backend : public std::enable_shared_from_this<Backend> {
 
   std::mutex mu_;
   std::map<ShapeKey, int64_t> hint_, seen_;
+  std::map<ShapeKey, ShapeStats> stats_;
   std::vector<PendingItem> pending_;
   std::set<int64_t> poisoned_;
   int64_t token_ = 0;
@@ -756,25 +798,32 @@ pybind11::tuple rasterize(PyBackend& pb, const Tensor& means, const Tensor& cov,
   return raster_tuple(r);
 }
 
-// `pf3plat_amd.rasterizer.rasterize_views` in one crossing: argument checks (the Python function's, message for message), dtype /
-// contiguity normalisation, the call shape and its flags (GSR_FLAG_BACKWARD_FOLLOWS when something can be differentiated), the operator.
-pybind11::tuple rasterize_views(PyBackend& pb, const Tensor& means_in, const Tensor& cov_in, const Tensor& opac_in, const Tensor& colors_in, const Tensor& viewbuf_in,
-                                int64_t h, int64_t w, int64_t sh_degree, bool use_sh, int64_t views_per_set, const c10::optional<Tensor>& extra_in,
-                                const c10::optional<Tensor>& means2d, int64_t max_sh_eval, bool sh_planar, bool cov_3x3, int64_t extra_mode, bool debug,
-                                bool prefiltered, int64_t deterministic, bool scale_rot, const c10::optional<Tensor>& frames_in, int64_t camera_gradient) {
-  RasterOut result;
-  {
-  pybind11::gil_scoped_release nogil;
+// The call shape of `rasterize_views`, stated ONCE: argument checks (message for message what the Python surface documents), dtype /
+// contiguity normalisation, the twelve integers of the call shape and its flags (GSR_FLAG_BACKWARD_FOLLOWS when something can be
+// differentiated).  Touches no device: `rasterize_views` below runs it in front of the operator, and `pf3plat_amd.rasterizer` runs the
+// SAME function (bound as `prepare_call`) in front of any other backend object - the tests slide the CPU oracle under the host wrappers
+// that way - so the two paths cannot drift apart.
+struct Prepared {
+  Tensor means, cov, opac, colors, viewbuf;
+  c10::optional<Tensor> extra, frames;
+  std::vector<int64_t> cfgv;
+};
+Prepared prepare_call(const Tensor& means_in, const Tensor& cov_in, const Tensor& opac_in, const Tensor& colors_in, const Tensor& viewbuf_in, int64_t h, int64_t w,
+                      int64_t sh_degree, bool use_sh, int64_t views_per_set, const c10::optional<Tensor>& extra_in, const c10::optional<Tensor>& means2d,
+                      int64_t max_sh_eval, bool sh_planar, bool cov_3x3, int64_t extra_mode, bool debug, bool prefiltered, int64_t deterministic, bool scale_rot,
+                      const c10::optional<Tensor>& frames_in, int64_t camera_gradient) {
+  Prepared p;
   const int64_t s = means_in.size(0), n = means_in.size(1), v = viewbuf_in.size(0);
   if (v != s * views_per_set) throw pybind11::value_error(std::to_string(v) + " views != " + std::to_string(s) + " sets x " + std::to_string(views_per_set) + " views per set");
-  const Tensor means = f32c(means_in), cov = f32c(cov_in), opac = f32c(opac_in), colors = f32c(colors_in);
-  c10::optional<Tensor> extra, frames;
-  if (extra_in.has_value() && extra_in->defined()) extra = f32c(*extra_in);
+  p.means = f32c(means_in); p.cov = f32c(cov_in); p.opac = f32c(opac_in); p.colors = f32c(colors_in);
+  const Tensor& cov = p.cov;
+  const Tensor& colors = p.colors;
+  if (extra_in.has_value() && extra_in->defined()) p.extra = f32c(*extra_in);
   if (use_sh && colors.dim() != 4) throw pybind11::value_error("shs must be (sets, N, M, 3) or (sets, N, 3, M)");
   const auto shape_str = [](const Tensor& t) { std::ostringstream o; o << t.sizes(); return o.str(); };
   if (scale_rot) {
     if (cov_3x3 || cov.dim() != 3 || cov.size(2) != 7) throw pybind11::value_error("scale/rotation records have shape " + shape_str(cov) + "; expected (sets, N, 7)");
-    if (frames_in.has_value() && frames_in->defined()) frames = f32c(frames_in->detach());
+    if (frames_in.has_value() && frames_in->defined()) p.frames = f32c(frames_in->detach());
   } else if (frames_in.has_value() && frames_in->defined()) {
     throw pybind11::value_error("`frames` goes with scale_rot=True");
   } else if (cov_3x3 ? (cov.dim() != 4 || cov.size(2) != 3 || cov.size(3) != 3) : (cov.dim() != 3 || cov.size(2) != 6)) {
@@ -785,17 +834,31 @@ pybind11::tuple rasterize_views(PyBackend& pb, const Tensor& means_in, const Ten
   const bool det = deterministic < 0 ? at::globalContext().deterministicAlgorithms() : deterministic != 0;
   flags |= (debug ? GSR_FLAG_DEBUG : 0) | (prefiltered ? GSR_FLAG_PREFILTERED : 0) | (det ? GSR_FLAG_DETERMINISTIC : 0);
   const auto rg = [](const c10::optional<Tensor>& t) { return t.has_value() && t->defined() && t->requires_grad(); };
-  if (at::GradMode::is_enabled() && (means.requires_grad() || cov.requires_grad() || opac.requires_grad() || colors.requires_grad() || rg(extra) || rg(means2d) ||
+  if (at::GradMode::is_enabled() && (p.means.requires_grad() || cov.requires_grad() || p.opac.requires_grad() || colors.requires_grad() || rg(p.extra) || rg(means2d) ||
                                      viewbuf_in.requires_grad()))
     flags |= GSR_FLAG_BACKWARD_FOLLOWS;  // the forward zero-fills the backward's accumulator rows on its way
   if (extra_mode) {
-    if (extra.has_value()) throw pybind11::value_error("give either `extra` or `extra_mode`");
+    if (p.extra.has_value()) throw pybind11::value_error("give either `extra` or `extra_mode`");
     flags |= GSR_FLAG_EXTRA_MODE(extra_mode);
   }
-  const bool has_extra = extra.has_value() || extra_mode != 0;
+  const bool has_extra = p.extra.has_value() || extra_mode != 0;
   if (camera_gradient != 1 && camera_gradient != 2) throw pybind11::value_error("camera_gradient must be 'full' or 'depth'");
-  const std::vector<int64_t> cfgv{v, s, views_per_set, n, h, w, sh_degree, m, max_sh_eval, has_extra ? 1 : 0, flags, scale_rot ? 1 : 0};
-  result = rasterize_impl(pb, means, cov, opac, colors, extra, means2d, f32c(viewbuf_in), cfgv, frames, camera_gradient);
+  p.cfgv = {v, s, views_per_set, n, h, w, sh_degree, m, max_sh_eval, has_extra ? 1 : 0, flags, scale_rot ? 1 : 0};
+  p.viewbuf = f32c(viewbuf_in);
+  return p;
+}
+
+// `pf3plat_amd.rasterizer.rasterize_views` in one crossing: the call shape (prepare_call), then the operator.
+pybind11::tuple rasterize_views(PyBackend& pb, const Tensor& means_in, const Tensor& cov_in, const Tensor& opac_in, const Tensor& colors_in, const Tensor& viewbuf_in,
+                                int64_t h, int64_t w, int64_t sh_degree, bool use_sh, int64_t views_per_set, const c10::optional<Tensor>& extra_in,
+                                const c10::optional<Tensor>& means2d, int64_t max_sh_eval, bool sh_planar, bool cov_3x3, int64_t extra_mode, bool debug,
+                                bool prefiltered, int64_t deterministic, bool scale_rot, const c10::optional<Tensor>& frames_in, int64_t camera_gradient) {
+  RasterOut result;
+  {
+  pybind11::gil_scoped_release nogil;
+  const Prepared p = prepare_call(means_in, cov_in, opac_in, colors_in, viewbuf_in, h, w, sh_degree, use_sh, views_per_set, extra_in, means2d, max_sh_eval, sh_planar,
+                                  cov_3x3, extra_mode, debug, prefiltered, deterministic, scale_rot, frames_in, camera_gradient);
+  result = rasterize_impl(pb, p.means, p.cov, p.opac, p.colors, p.extra, means2d, p.viewbuf, p.cfgv, p.frames, camera_gradient);
   }
   return raster_tuple(result);
 }
@@ -855,6 +918,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
                     [](PyBackend& b, const std::string& v) { if (v != "nan" && v != "raise") throw pybind11::value_error("on_overflow must be 'nan' or 'raise'"); b.be().on_overflow = v; })
       .def_property("defer_status", [](PyBackend& b) { return b.be().defer_status; }, [](PyBackend& b, bool v) { b.be().defer_status = v; })
       .def_property("spin_us", [](PyBackend& b) { return b.be().spin_us; }, [](PyBackend& b, double v) { b.be().spin_us = v; })
+      .def_property("headroom_min", [](PyBackend& b) { return b.be().headroom_min; }, [](PyBackend& b, double v) { b.be().headroom_min = std::max(1.0, v); })
+      .def_property("headroom_max", [](PyBackend& b) { return b.be().headroom_max; }, [](PyBackend& b, double v) { b.be().headroom_max = std::max(1.0, v); })
+      .def_property("headroom_sigmas", [](PyBackend& b) { return b.be().headroom_sigmas; }, [](PyBackend& b, double v) { b.be().headroom_sigmas = std::max(0.0, v); })
+      .def("headroom_for", [](PyBackend& b, const ShapeKey& k) { return b.be().headroom_for(k); })
       .def_property_readonly("capacity_hint", [](PyBackend& b) { return b.be().capacity_hint(); })
       .def_property_readonly("seen", [](PyBackend& b) { return b.be().seen(); })
       .def_property_readonly("pending", [](PyBackend& b) { return b.be().pending_tokens(); })
@@ -903,6 +970,16 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("rasterize", &rasterize, pybind11::arg("backend"), pybind11::arg("means"), pybind11::arg("cov"), pybind11::arg("opac"), pybind11::arg("colors"),
         pybind11::arg("extra"), pybind11::arg("means2d"), pybind11::arg("viewbuf"), pybind11::arg("cfg"), pybind11::arg("frames"), pybind11::arg("camera_gradient"));
   m.def("rasterize_views", &rasterize_views);
+  m.def("prepare_call", [](const Tensor& means, const Tensor& cov, const Tensor& opac, const Tensor& colors, const Tensor& viewbuf, int64_t h, int64_t w, int64_t sh_degree,
+                           bool use_sh, int64_t views_per_set, const c10::optional<Tensor>& extra, const c10::optional<Tensor>& means2d, int64_t max_sh_eval,
+                           bool sh_planar, bool cov_3x3, int64_t extra_mode, bool debug, bool prefiltered, int64_t deterministic, bool scale_rot,
+                           const c10::optional<Tensor>& frames, int64_t camera_gradient) {
+    const Prepared p = prepare_call(means, cov, opac, colors, viewbuf, h, w, sh_degree, use_sh, views_per_set, extra, means2d, max_sh_eval, sh_planar, cov_3x3,
+                                    extra_mode, debug, prefiltered, deterministic, scale_rot, frames, camera_gradient);
+    pybind11::object e = p.extra.has_value() ? pybind11::cast(*p.extra) : pybind11::none();
+    pybind11::object f = p.frames.has_value() ? pybind11::cast(*p.frames) : pybind11::none();
+    return pybind11::make_tuple(p.cfgv, p.means, p.cov, p.opac, p.colors, e, f, p.viewbuf);
+  }, "the call shape of rasterize_views (checks, normalisation, flags) without the operator: what any backend object runs behind");
   m.def("rasterize_one_view", &rasterize_one_view);
   m.def("views_from_cameras", &views_from_cameras);
   m.def("setup_views", &setup_views_raw);

@@ -41,10 +41,21 @@ class Decoder(nn.Module):
 class DecoderSplattingCUDA(Decoder):
     background_color: Tensor
 
-    def __init__(self, cfg: Optional[DecoderSplattingCUDACfg] = None, dataset_cfg=None) -> None:
+    def __init__(self, cfg: Optional[DecoderSplattingCUDACfg] = None, dataset_cfg=None, on_overflow: Optional[str] = "nan") -> None:
+        """on_overflow: what the raster backend does when a deferred training forward outgrows its pair workspace.  "nan" (this
+        decoder's default - it is PF3plat's training surface, and PF3plat's optimizer step skips a step whose gradients hold a NaN,
+        src/model/model_wrapper.py:224-238): the step's image, loss and gradients are NaN, a `RasterOverflowWarning` is issued,
+        nothing is raised - every DDP rank still enters the gradient all-reduce.  "raise" (the library's own default, for callers
+        with a plain `optimizer.step()`): RuntimeError from that step's backward.  None: leave the backend as it is."""
         cfg = cfg if cfg is not None else DecoderSplattingCUDACfg()
         dataset_cfg = dataset_cfg if dataset_cfg is not None else DatasetCfgLike()
         super().__init__(cfg, dataset_cfg)
+        if on_overflow is not None:
+            from .rasterizer import get_backend
+
+            backend = get_backend()
+            if hasattr(backend, "on_overflow"):  # (tests slide other backend objects under the wrappers)
+                backend.on_overflow = on_overflow
         self.register_buffer(
             "background_color",
             torch.tensor(list(dataset_cfg.background_color), dtype=torch.float32),

@@ -154,10 +154,15 @@ class HipBackend:
     #   call is sized from the running maximum and its status is verified at the end of its own backward instead of in the forward
     #   (0: never - every forward blocks until its status has been read)
     # on_overflow: what a DEFERRED forward of the default policy does when its workspace turns out too small (its image is NaN by
-    #   then, so is the loss): "nan" (default) - its backward hands out NaN gradients with a one-line warning and raises nothing: the
-    #   reference's training loop skips such a step by itself (model_wrapper.py:224-238 looks for NaN gradients) and every rank of a
-    #   DDP job still enters the gradient all-reduce; "raise" - RuntimeError from that backward (round 4's behaviour).  The opt-in
-    #   "lazy" policy always raises at verification: its callers (inference loops, benchmarks) asked for that contract.
+    #   then, so is the loss): "raise" (the library's default) - RuntimeError from that forward's backward: a caller with a plain
+    #   `optimizer.step()` must never find NaN in its weights; "nan" - its backward (EVERY backward over that forward) hands out NaN
+    #   gradients with a `RasterOverflowWarning` (always displayed) and raises nothing: for loops that skip a step whose gradients
+    #   hold a NaN, as the reference's does (model_wrapper.py:224-238) - every rank of a DDP job then still enters the gradient
+    #   all-reduce.  `DecoderSplattingCUDA` (PF3plat's training surface) opts into "nan" when it is built.  The opt-in "lazy" policy
+    #   always raises at verification: its callers (inference loops, benchmarks) asked for that contract.
+    # headroom_min / headroom_max / headroom_sigmas: a workspace sized from a shape's history holds its largest pair count seen x
+    #   clamp(1 + sigmas x sigma / mean, min, max) (1.25 / 3.0 / 4.0): a loop over one scene keeps 1.25x, a training run that meets a
+    #   new scene every step widens it by itself (profiles/r06_skip_rate.md: how often a step outgrows it)
     # defer_status: True = lazy from the very first call (caller knows a safe capacity)
     # spin_us: longest busy-wait on a status copy before falling back to a blocking, error-reporting synchronize
     sync_policy = property(lambda self: self._c.sync_policy, lambda self, v: setattr(self._c, "sync_policy", v))
@@ -165,12 +170,24 @@ class HipBackend:
     on_overflow = property(lambda self: self._c.on_overflow, lambda self, v: setattr(self._c, "on_overflow", v))
     defer_status = property(lambda self: self._c.defer_status, lambda self, v: setattr(self._c, "defer_status", bool(v)))
     spin_us = property(lambda self: self._c.spin_us, lambda self, v: setattr(self._c, "spin_us", float(v)))
-    capacity_hint = property(lambda self: self._c.capacity_hint)  # (V, N, H, W) -> largest pair_capacity any call of that shape has needed (headroom included)
+    headroom_min = property(lambda self: self._c.headroom_min, lambda self, v: setattr(self._c, "headroom_min", float(v)))
+    headroom_max = property(lambda self: self._c.headroom_max, lambda self, v: setattr(self._c, "headroom_max", float(v)))
+    headroom_sigmas = property(lambda self: self._c.headroom_sigmas, lambda self, v: setattr(self._c, "headroom_sigmas", float(v)))
+    capacity_hint = property(lambda self: self._c.capacity_hint)  # a COPY: (V, N, H, W) -> largest pair_capacity any call of that shape has needed (headroom included); write through set_capacity_hint
     seen = property(lambda self: self._c.seen)  # (V, N, H, W) -> forwards of that shape whose status block has been read
     pending = property(lambda self: self._c.pending)  # tokens of lazy / deferred forwards not yet verified
-    poisoned = property(lambda self: self._c.poisoned)  # tokens of deferred forwards found overflowed whose backward has not run yet
+    poisoned = property(lambda self: self._c.poisoned)  # tokens of deferred forwards found overflowed (kept: every backward over such a forward answers NaN)
     last_status = property(lambda self: self._c.last_status)
     workspace_cache = property(lambda self: [None] * (self._c.workspace_cache_size + len(self._plan_ws)))  # (how many cached workspace sets are alive)
+
+    def set_capacity_hint(self, key, capacity: int):
+        """Pre-size a shape: key = (views, N, H, W) -> pair_capacity (the lazy / defer_status contract: "the caller knows a safe
+        capacity").  `capacity_hint` itself is a copy of the compiled backend's map - writing into it changes nothing."""
+        self._c.set_capacity_hint(tuple(int(k) for k in key), int(capacity))
+
+    def headroom_for(self, key) -> float:
+        """The head-room factor the next deferred / lazy call of shape (views, N, H, W) is sized with."""
+        return float(self._c.headroom_for(tuple(int(k) for k in key)))
 
     def _rc(self, rc: int, what: str, stages=None):
         if rc == 0:
@@ -692,42 +709,17 @@ def rasterize_views(means: Tensor, cov6: Tensor, opacities: Tensor, colors: Tens
             int(views_per_set), extra, means2d, int(max_sh_eval), bool(sh_planar), bool(cov_3x3), EXTRA_MODES[extra_mode] if extra_mode is not None else 0,
             bool(debug), bool(prefiltered), -1 if deterministic is None else int(bool(deterministic)), bool(scale_rot), frames,
             2 if camera_gradient == "depth" else 1)
-    # (any other backend object - tests slide the CPU oracle under the host wrappers - takes the Python statement of the same steps)
-    s, n = means.shape[0], means.shape[1]
-    v = viewbuf.shape[0]
-    if v != s * views_per_set:
-        raise ValueError(f"{v} views != {s} sets x {views_per_set} views per set")
-    h, w = image_shape
-    means, cov6, opacities, colors, extra = _f32c(means), _f32c(cov6), _f32c(opacities), _f32c(colors), _f32c(extra)
-    if use_sh and colors.dim() != 4:
-        raise ValueError("shs must be (sets, N, M, 3) or (sets, N, 3, M)")
-    if scale_rot:
-        if cov_3x3 or cov6.shape[2:] != (7,):
-            raise ValueError(f"scale/rotation records have shape {tuple(cov6.shape)}; expected (sets, N, 7)")
-        if frames is not None:
-            frames = _f32c(frames.detach())
-    elif frames is not None:
-        raise ValueError("`frames` goes with scale_rot=True")
-    elif cov6.shape[2:] != ((3, 3) if cov_3x3 else (6,)):
-        raise ValueError(f"covariances have shape {tuple(cov6.shape)}; expected (sets, N, {'3, 3' if cov_3x3 else '6'})")
-    m = (colors.shape[3] if sh_planar else colors.shape[2]) if use_sh else 0
-    flags = (_lib.FLAG_SH_PLANAR if (sh_planar and use_sh) else 0) | (_lib.FLAG_COV_3X3 if cov_3x3 else 0)
-    if deterministic is None:
-        deterministic = torch.are_deterministic_algorithms_enabled()
-    flags |= (_lib.FLAG_DEBUG if debug else 0) | (_lib.FLAG_PREFILTERED if prefiltered else 0)
-    flags |= _lib.FLAG_DETERMINISTIC if deterministic else 0
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (means, cov6, opacities, colors, extra, means2d, viewbuf)):
-        flags |= _lib.FLAG_BACKWARD_FOLLOWS  # the forward zero-fills the backward's accumulator rows on its way
-    if extra_mode is not None:
-        if extra is not None:
-            raise ValueError("give either `extra` or `extra_mode`")
-        flags |= EXTRA_MODES[extra_mode] << 4
-    has_extra = extra is not None or extra_mode is not None
-    cfg = RasterConfig(v, s, views_per_set, n, int(h), int(w), int(sh_degree), int(m), int(max_sh_eval), has_extra, flags,
-                       bool(scale_rot))
-    viewbuf = _f32c(viewbuf)
+    # any other backend object (tests slide the CPU oracle under the host wrappers): the SAME statement of the call shape - the
+    # compiled `prepare_call` (csrc/gsr_torch.cpp: checks, normalisation, flags; it touches no device) - then that backend's forward
     if camera_gradient not in ("full", "depth"):
         raise ValueError("camera_gradient must be 'full' or 'depth'")
+    cfgv, means, cov6, opacities, colors, extra, frames, viewbuf = _lib.load_torch_ext().prepare_call(
+        means, cov6, opacities, colors, viewbuf, int(image_shape[0]), int(image_shape[1]), int(sh_degree), bool(use_sh), int(views_per_set),
+        extra, means2d, int(max_sh_eval), bool(sh_planar), bool(cov_3x3), EXTRA_MODES[extra_mode] if extra_mode is not None else 0,
+        bool(debug), bool(prefiltered), -1 if deterministic is None else int(bool(deterministic)), bool(scale_rot), frames,
+        2 if camera_gradient == "depth" else 1)
+    cfg = RasterConfig(*cfgv[:9], bool(cfgv[9]), int(cfgv[10]), bool(cfgv[11]))
+    flags, has_extra = cfg.flags, cfg.has_extra
     if not (flags & _lib.FLAG_BACKWARD_FOLLOWS):  # nothing here can be differentiated: no autograd node, no saved workspaces
         color, extra_img, radii, _ = backend.forward(cfg, viewbuf, means, cov6, opacities, colors, extra, frames=frames,
                                                      reuse_workspaces=True)
@@ -793,6 +785,12 @@ def _cov3d_from_scale_rotation(scales: Tensor, rotations: Tensor, scale_modifier
     return _CovFromScaleRot.apply(scales, rotations, scale_modifier, get_backend())
 
 
+def _global_module_hooks() -> bool:
+    m = torch.nn.modules.module
+    return bool(m._global_forward_hooks or m._global_forward_pre_hooks or m._global_backward_hooks or
+                getattr(m, "_global_backward_pre_hooks", None) or getattr(m, "_global_forward_hooks_always_called", None))
+
+
 class GaussianRasterizer(nn.Module):
     """Per-view operator with the upstream call signature (reference cuda_splatting.py:113-124)."""
 
@@ -809,7 +807,17 @@ class GaussianRasterizer(nn.Module):
             return getattr(self, name)
         return super().__getattr__(name)
 
-    def __call__(self, *args, **kwargs):  # (nn.Module's hook machinery costs ~3 us per call; the reference makes one call per view)
+    def __call__(self, *args, **kwargs):
+        # nn.Module's hook machinery costs ~3 us per call and the reference makes one call per view: straight to `forward` - unless a
+        # hook could be waiting (module state has been initialised and a forward / pre-forward / backward hook is registered on this
+        # module, or a global module hook - a profiler's `register_module_forward_hook` - exists): then nn.Module's own __call__ runs
+        d = self.__dict__
+        if "_parameters" in d:
+            if d["_forward_hooks"] or d["_forward_pre_hooks"] or d["_backward_hooks"] or d.get("_backward_pre_hooks") or _global_module_hooks():
+                return nn.Module.__call__(self, *args, **kwargs)
+        elif _global_module_hooks():
+            self.__getattr__("_parameters")  # become a regular nn.Module first
+            return nn.Module.__call__(self, *args, **kwargs)
         return self.forward(*args, **kwargs)
 
     def _viewbuf(self, device) -> Tensor:

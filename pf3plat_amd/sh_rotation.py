@@ -104,16 +104,30 @@ def e3nn_band_rotations(rotations: Tensor, degree: int) -> list:
     return out
 
 
-# Harmonics that did NOT come out of the reference's adapter: `ply_export.gaussians_from_ply` registers the storage of the tensor it
-# returns here (views of it - a scene, a slice, a permutation - share the storage), so that `rotate_sh` can say when the reference's
-# e3nn-convention default is about to be applied to coefficients that live in the rasterizer's basis.
-_EXTERNAL_STORAGES: set = set()
+# Harmonics that did NOT come out of the reference's adapter: `ply_export.gaussians_from_ply` tags the tensor it returns (an attribute
+# on the tensor object: `_pf3plat_external_harmonics`) and registers its storage here BY WEAK REFERENCE to the tensor - views of it (a
+# scene, a slice, a permutation) share the storage, so `rotate_sh` can say when the reference's e3nn-convention default is about to be
+# applied to coefficients that live in the rasterizer's basis.  The entry disappears with the tensor: an address the caching allocator
+# hands out again later cannot trigger (and use up) the warning, and the table does not grow.  (Copies - `.to()`, `.clone()` - are new
+# storages and are not tracked: pass `basis=` explicitly for those.)
+_EXTERNAL_STORAGES: dict = {}  # storage address -> weakref to the tagged tensor
 _warned_external = False
 
 
 def mark_external_harmonics(harmonics: Tensor) -> Tensor:
-    _EXTERNAL_STORAGES.add(harmonics.untyped_storage().data_ptr())
+    import weakref
+
+    addr = harmonics.untyped_storage().data_ptr()
+    harmonics._pf3plat_external_harmonics = True
+    _EXTERNAL_STORAGES[addr] = weakref.ref(harmonics, lambda _r, a=addr: _EXTERNAL_STORAGES.pop(a, None))
     return harmonics
+
+
+def _is_external(t: Tensor) -> bool:
+    if getattr(t, "_pf3plat_external_harmonics", False):
+        return True
+    ref = _EXTERNAL_STORAGES.get(t.untyped_storage().data_ptr())
+    return ref is not None and ref() is not None
 
 
 def rotate_sh(sh_coefficients: Tensor, rotations: Tensor, basis: str | None = None) -> Tensor:
@@ -125,8 +139,7 @@ def rotate_sh(sh_coefficients: Tensor, rotations: Tensor, basis: str | None = No
     global _warned_external
     if basis is None:
         basis = "e3nn"
-        if (not _warned_external and _EXTERNAL_STORAGES and sh_coefficients.numel() > 0
-                and sh_coefficients.untyped_storage().data_ptr() in _EXTERNAL_STORAGES):
+        if not _warned_external and _EXTERNAL_STORAGES and sh_coefficients.numel() > 0 and _is_external(sh_coefficients):
             import warnings
 
             _warned_external = True

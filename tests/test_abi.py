@@ -210,10 +210,10 @@ def test_compiled_torch_binding_loads_and_carries_the_policy_defaults():
     for name in ("Backend", "rasterize", "rasterize_one_view", "views_from_cameras", "setup_views", "pack_view", "init"):
         assert hasattr(ext, name), name
     be = rasterizer.HipBackend()
-    assert (be.sync_policy, be.defer_after, be.on_overflow, be.defer_status) == ("sync", 4, "nan", False)
+    assert (be.sync_policy, be.defer_after, be.on_overflow, be.defer_status) == ("sync", 4, "raise", False)
     assert be.pending == [] and be.seen == {} and be.capacity_hint == {} and be.last_status is None and not be.poisoned
-    be.sync_policy, be.defer_after, be.on_overflow = "lazy", 0, "raise"
-    assert (be._c.sync_policy, be._c.defer_after, be._c.on_overflow) == ("lazy", 0, "raise")
+    be.sync_policy, be.defer_after, be.on_overflow = "lazy", 0, "nan"
+    assert (be._c.sync_policy, be._c.defer_after, be._c.on_overflow) == ("lazy", 0, "nan")
     with pytest.raises(ValueError):
         be.sync_policy = "sometimes"
     with pytest.raises(ValueError):

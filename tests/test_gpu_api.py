@@ -350,55 +350,80 @@ def test_reference_unchanged_decoder_path_at_config4_size():
 
 
 def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on():
-    """Eight training steps through the reference's own call structure (tests/reference_style.py: per-view operator, fresh
+    """Ten training steps through the reference's own call structure (tests/reference_style.py: per-view operator, fresh
     settings + rasterizer + `means2D` leaf per view) with the reference's optimizer step around them (model_wrapper.py:210-241: a
-    step whose gradients hold a NaN is skipped).  Default status policy: steps 0-3 read their status, steps 4-5 are deferred, at
-    step 6 the scene's footprints grow ninefold (> 3x the pairs): NO exception - a warning, a NaN image, all-NaN gradients, the
-    guard skips the step - and step 7 (same large scene) is finite and matches the oracle-driven same code."""
+    step whose gradients hold a NaN is skipped) - the trainer has opted into `on_overflow = "nan"`, as a loop with that guard does.
+    The footprints change from step to step, as a scale head's output does in training.  Steps 0-3 read their status; from step 4
+    on the forward is deferred and sized from the shape's history: running maximum x max(1.25, 1 + 4 sigma / mean).  Step 6 lists
+    ~1.6x the pairs of step 5 - inside the head-room the history has earned: NOT skipped (round 5 sized at a fixed 1.25x and lost
+    such a step).  At step 7 the footprints grow 25-fold (far more than 3x the pairs): NO exception - a warning, a NaN image, all-NaN
+    gradients, the guard skips the step - and steps 8-9 (same large scene) are finite; step 9 matches the oracle-driven same code."""
     import warnings
 
+    from pf3plat_amd._lib import RasterOverflowWarning
     from tests.reference_style import reference_style_decoder_forward
 
     n, hw = 6000, (64, 64)
     sc = synthetic.make_scene(61, n, hw, num_views=1)
     w = torch.rand((1, 1, 3, *hw), generator=torch.Generator().manual_seed(6))
     bgc = torch.tensor([0.1, 0.2, 0.3])
+    key = (1, n, *hw)
+
+    # what covariance factor lists 1.6x the pairs of factor 0.9?  (blocking calls of the plan API on a backend of its own)
+    probe = rasterizer.HipBackend()
+    ins = tuple(t.to(DEV).contiguous() for t in synthetic.scene_operator_inputs(sc))
+    vb = synthetic.scene_viewbuf(sc).to(DEV)
+    cfg = rasterizer.RasterConfig(1, 1, 1, n, *hw, 4, 25, 4, False)
+    plan = probe.make_plan(cfg, torch.device(DEV), capacity=64 * n)
+
+    def pairs_of(g):
+        probe.run_forward(plan, vb, ins[0], ins[1] * g, ins[2], ins[3])
+        st = probe.read_status(plan)
+        assert not st["overflow"]
+        return st["num_pairs"]
+
+    base5 = pairs_of(0.9)
+    g6 = min((1.5 + 0.25 * k for k in range(40)), key=lambda g: abs(pairs_of(g) / base5 - 1.6))
+    assert 1.5 < pairs_of(g6) / base5 < 1.75, (g6, pairs_of(g6) / base5)
+    grow = [1.0, 2.2, 0.6, 1.5, 1.0, 0.9, g6, 25.0, 25.0, 25.0]
+
     be = rasterizer.HipBackend()
     old = install_backend(be)
     try:
-        assert be.sync_policy == "sync" and be.defer_after == 4 and be.on_overflow == "nan"
+        assert be.sync_policy == "sync" and be.defer_after == 4 and be.on_overflow == "raise"  # the library's defaults
+        be.on_overflow = "nan"  # this loop has the reference's NaN guard: it opts in
         leaves = _leafs(sc, DEV)
         opt = torch.optim.SGD(leaves, lr=1e-4)
-        t = lambda x: x.to(DEV)
 
         def step(k, leaves_, device):
             m, c, h, o = leaves_
-            grow = 9.0 if k >= 6 else 1.0
             tt = lambda x: x.to(device)
-            img = reference_style_decoder_forward(Gaussians(m, c * grow, h, o), tt(sc.extrinsics), tt(sc.intrinsics), tt(sc.near),
+            img = reference_style_decoder_forward(Gaussians(m, c * grow[k], h, o), tt(sc.extrinsics), tt(sc.intrinsics), tt(sc.near),
                                                   tt(sc.far), hw, tt(bgc))
             (img * tt(w)).sum().backward()
             return img.detach()
 
         pairs = []
-        for k in range(8):
+        for k in range(10):
             before = [x.detach().clone() for x in leaves]
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter("always")
                 img = step(k, leaves, DEV)  # (no exception at any step)
             pairs.append(be.last_status["num_pairs"])
             nan_grad = any(torch.isnan(x.grad).any().item() for x in leaves)  # the reference's guard
-            if k == 6:
-                assert any("returns NaN gradients" in str(c.message) for c in caught)
+            if k == 7:
+                assert any(issubclass(c.category, RasterOverflowWarning) and "returns NaN gradients" in str(c.message) for c in caught)
                 # (every gradient the operator hands out is NaN; the covariance leaf's lower triangle receives none at all - the
                 # reference's triu gather - and stays 0)
                 assert torch.isnan(img).all() and nan_grad and all(torch.isnan(x.grad).any() for x in leaves)
-                assert all(torch.isnan(leaves[k].grad).all() for k in (0, 2, 3))
+                assert all(torch.isnan(leaves[j].grad).all() for j in (0, 2, 3))
             else:
-                assert not caught and torch.isfinite(img).all() and not nan_grad, k
-            if k == 7:  # against the oracle-driven same code on the same parameter values
+                assert not caught and torch.isfinite(img).all() and not nan_grad, (k, pairs)
+            if k == 5:
+                assert be.headroom_for(key) > 1.3  # the history's spread has widened the factor beyond the floor
+            if k == 9:  # against the oracle-driven same code on the same parameter values
                 cpu_leaves = [x.detach().clone().cpu().requires_grad_(True) for x in leaves]
-                oi = _with_oracle(lambda: step(7, cpu_leaves, "cpu"))
+                oi = _with_oracle(lambda: step(9, cpu_leaves, "cpu"))
                 assert rel_l2(img.cpu().numpy(), oi.numpy()) < 1e-4
                 _cmp_grads(leaves, cpu_leaves)
             if not nan_grad:
@@ -406,8 +431,9 @@ def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on
             else:
                 assert all(torch.equal(a, b.detach()) for a, b in zip(before, leaves))
             opt.zero_grad()
-        assert be.seen[(1, n, *hw)] == 8 and not be.pending and not be.poisoned
-        assert pairs[7] > 3 * pairs[5], pairs  # the jump was a real one (pairs[6] is step 6's own count, read at its backward)
+        assert be.seen[key] == 10 and not be.pending and len(be.poisoned) == 1
+        assert pairs[6] > 1.45 * pairs[5], pairs  # the 1.6x jump was a real one - and was rendered, not skipped
+        assert pairs[9] > 3 * pairs[6], pairs  # (pairs[7] is the skipped step's own count, read at its backward)
     finally:
         install_backend(old)
 
@@ -474,3 +500,87 @@ def test_two_host_threads_share_the_process_wide_backend():
         assert not be.pending
     finally:
         install_backend(old)
+
+
+@pytest.mark.parametrize("case", ["A", "B", "C", "D_depth", "D_disparity", "D_relative_disparity", "D_log", "E", "F"])
+def test_reference_wrapper_fixture_cases_through_the_product_path(case):
+    """tests/golden/wrapper_fixtures.npz (the inputs the REFERENCE's host wrapper was recorded on, tests/golden/make_wrapper_fixtures.py)
+    through the PRODUCT path - compiled `rasterize_views` (csrc/gsr_torch.cpp: `prepare_call` + the operator) on the HIP library -
+    against the same wrapper calls on the oracle backend, whose per-view arguments `tests/test_wrapper_fixtures.py` pins to the
+    reference's recorded calls on CPU.  Both paths state the call shape through the same compiled `prepare_call`."""
+    import os
+
+    fix = np.load(os.path.join(os.path.dirname(__file__), "golden", "wrapper_fixtures.npz"))
+
+    def run(device):
+        t = lambda name: torch.tensor(fix[name]).to(device)
+        k = case[0]
+        hw = tuple(int(x) for x in fix[f"{k}_in_hw"])
+        cams = (t(f"{k}_in_ext"), t(f"{k}_in_intr"), t(f"{k}_in_near"), t(f"{k}_in_far")) if k != "E" else None
+        if k in "AB":
+            return [pf3plat_amd.render_cuda(*cams, hw, t(f"{k}_in_bg"), t(f"{k}_in_means"), t(f"{k}_in_cov"), t(f"{k}_in_sh"), t(f"{k}_in_op"))]
+        if k == "C":
+            return [pf3plat_amd.render_cuda(*cams, hw, t("C_in_bg"), t("C_in_means"), t("C_in_cov"), t("C_in_sh"), t("C_in_op"),
+                                            scale_invariant=False, use_sh=False)]
+        if k == "D":
+            return [pf3plat_amd.render_depth_cuda(*cams, hw, t("D_in_means"), t("D_in_cov"), t("D_in_op"), mode=case[2:])]
+        if k == "E":
+            return [pf3plat_amd.render_cuda_orthographic(t("E_in_ext"), t("E_in_width"), t("E_in_height"), t("E_in_near"), t("E_in_far"), hw,
+                                                         t("E_in_bg"), t("E_in_means"), t("E_in_cov"), t("E_in_sh"), t("E_in_op"), fov_degrees=10.0)]
+        dec = pf3plat_amd.DecoderSplattingCUDA(dataset_cfg=pf3plat_amd.decoder.DatasetCfgLike(tuple(fix["F_in_bgcolor"])), on_overflow=None).to(device)
+        out = dec.forward(Gaussians(t("F_in_means"), t("F_in_cov"), t("F_in_sh"), t("F_in_op")), *cams, hw, depth_mode="depth")
+        return [out.color, out.depth]
+
+    assert isinstance(rasterizer.get_backend(), rasterizer.HipBackend)
+    got = run(DEV)
+    want = _with_oracle(lambda: run("cpu"))
+    for a, b in zip(got, want):
+        assert a.shape == b.shape and a.is_cuda
+        a, b = a.cpu().numpy(), b.numpy()
+        assert rel_l2(a, b) < 1e-4 or np.abs(a - b).max() < 1e-6, (case, rel_l2(a, b))
+
+
+def test_per_view_rasterizer_under_stream_capture_returns_the_eager_shapes_and_module_hooks_run():
+    """(i) `GaussianRasterizer` under HIP-graph capture returns (3, H, W) and (N) - what it returns eagerly (round 5's capture branch
+    handed out the (1, 3, H, W) / (1, N) views) - and the replay reproduces the eager image; (ii) the module's `__call__` skips
+    nn.Module's hook machinery only while no hook can be waiting: a registered forward hook (or a global module hook) runs."""
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from tests.util import make_camera, random_small_scene
+
+    sc = random_small_scene(5, 400, sh_coeffs=25, dtype=np.float32)
+    cam = make_camera(dtype=np.float32)
+    t = lambda a: torch.tensor(a, dtype=torch.float32, device=DEV)
+    settings = GaussianRasterizationSettings(
+        image_height=40, image_width=48, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], bg=t([0.1, 0.1, 0.1]), scale_modifier=1.0,
+        viewmatrix=t(cam["viewmatrix"]).reshape(4, 4), projmatrix=t(cam["projmatrix"]).reshape(4, 4), sh_degree=4, campos=t(cam["campos"]),
+        prefiltered=False, debug=False)
+    args = dict(means3D=t(sc["means"]), means2D=None, shs=t(sc["colors"]), colors_precomp=None, opacities=t(sc["opac"])[:, None], cov3D_precomp=t(sc["cov6"]))
+    with torch.no_grad():
+        eager, radii = GaussianRasterizer(settings)(**args)  # (the shape is known from here on: a capture is sized from its hint)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            GaussianRasterizer(settings)(**args)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            img, rad = GaussianRasterizer(settings)(**args)
+        assert img.shape == eager.shape == (3, 40, 48) and rad.shape == radii.shape == (400,)
+        img.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(img, eager) and torch.equal(rad, radii)
+        # hooks
+        seen = []
+        rast = GaussianRasterizer(settings)
+        rast.register_forward_hook(lambda mod, a, out: seen.append("module"))
+        rast(**args)
+        h = torch.nn.modules.module.register_module_forward_hook(lambda mod, a, out: seen.append("global"))
+        try:
+            GaussianRasterizer(settings)(**args)
+        finally:
+            h.remove()
+        assert seen == ["module", "global"]
+        out_plain, _ = GaussianRasterizer(settings)(**args)  # (and without any hook: the short path, the same image)
+        assert torch.equal(out_plain, eager)

@@ -482,12 +482,16 @@ def test_default_policy_defers_the_status_of_differentiated_calls_and_their_back
     for _ in range(4):
         be2.forward(cfg, vb, means, cov6, opac, colors, None)
     big = cov6 * 400.0
+    assert be2.on_overflow == "raise"  # the library's default; a loop that skips NaN-gradient steps (the reference's) opts into "nan":
+    be2.on_overflow = "nan"            # nothing is raised inside its training step then
     c_bad, _, _, saved_bad = be2.forward(cfg, vb, means, big, opac, colors, None)
-    assert be2.on_overflow == "nan"  # the default: nothing is raised inside a training step (the reference's loop could not catch it)
-    with pytest.warns(RuntimeWarning, match="returns NaN gradients"):
+    with pytest.warns(_lib.RasterOverflowWarning, match="returns NaN gradients"):
         bad = be2.backward(cfg, saved_bad, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
     assert torch.isnan(c_bad).all() and all(torch.isnan(t).all() for t in bad if t is not None)
-    assert not be2.pending and not be2.poisoned
+    assert not be2.pending and len(be2.poisoned) == 1
+    # EVERY backward over that forward answers NaN (retain_graph, several autograd.grad calls): the token stays poisoned
+    again = be2.backward(cfg, saved_bad, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=False)
+    assert all(torch.isnan(t).all() for t in again if t is not None) and len(be2.poisoned) == 1
     c_ok, _, _, saved_ok = be2.forward(cfg, vb, means, big, opac, colors, None)
     out = be2.backward(cfg, saved_ok, vb, means, big, opac, colors, None, g, None, True, rows_in_workspace=True)
     assert torch.isfinite(c_ok).all() and all(torch.isfinite(t).all() for t in out if t is not None)

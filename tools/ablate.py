@@ -38,9 +38,12 @@ def main():
         be.run_forward(plan, vb, means, cov6, opac, shs)
     torch.cuda.synchronize()
     lay = be.workspace_layout(plan["dims"])
-    st = plan["bin"][lay["keys"]: lay["keys"] + 1024 * 32].view(torch.int64).reshape(1024, 4).cpu().double()
+    chunk_ = min(range(1600, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)
+    end_ = lay["keys"] + (((n + chunk_ - 1) // chunk_) * (8192 + 136) + ((int(plan["dims"].pair_capacity) + 1023) // 1024 + 64) * 1024) * 8
+    blend_stamps = plan["bin"][end_ - (24576 + 1024) * 64: end_ - 24576 * 64].view(torch.int64).reshape(1024, 8).flip(0)[:, :4].cpu()  # slot 24576 + tile
+    st = blend_stamps.double()
     walked = plan["bin"][lay["tile_total"]: lay["tile_total"] + 1024 * 4].view(torch.int32).cpu().double()
-    raw = plan["bin"][lay["keys"]: lay["keys"] + 1024 * 32].view(torch.int64).reshape(1024, 4).cpu()
+    raw = blend_stamps
     rs = ((raw[:, 3] >> 32) & 0xffffffff).double() * 0.01  # us
     re = (raw[:, 3] & 0xffffffff).double() * 0.01
     print("blend_fwd wall clock (us): start skew", q0(rs - rs.min()), "| end", q0(re - rs.min()), "| duration", q0(re - rs), flush=True)

@@ -40,18 +40,18 @@ def main():
     torch.cuda.synchronize()
     lay = be.workspace_layout(plan["dims"])
     T = 1024
-    raw = plan["bin"][lay["keys"]: lay["keys"] + T * 32].view(torch.int64).reshape(T, 4).cpu()
     walked = plan["bin"][lay["tile_total"]: lay["tile_total"] + T * 4].view(torch.int32).cpu().double()
     rg = plan["bin"][lay["ranges"]: lay["ranges"] + T * 8].view(torch.int32).reshape(T, 2).cpu()
     ln = (rg[:, 1] - rg[:, 0]).double()
-    bs = ((raw[:, 3] >> 32) & 0xffffffff).double() * 0.01  # blend start / end, us (100 MHz clock, low 32 bits)
-    be_ = (raw[:, 3] & 0xffffffff).double() * 0.01
-    hw = (raw[:, 1] >> 32) & 0xffffffff
-    cu = ((hw >> 16) & 0xf) * 4096 + ((hw >> 13) & 0x7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)
     chunk = min(range(2048, 1023, -64), key=lambda c: (((n + c - 1) // c + 255) // 256) * c)
     rows = (n + chunk - 1) // chunk
     cap = int(plan["dims"].pair_capacity)
     end = lay["keys"] + (rows * (8192 + 136) + ((cap + 1023) // 1024 + 64) * 1024) * 8
+    raw = plan["bin"][end - (24576 + T) * 64: end - 24576 * 64].view(torch.int64).reshape(T, 8).flip(0)[:, :4].cpu()  # blend stamps: slot 24576 + tile
+    bs = ((raw[:, 3] >> 32) & 0xffffffff).double() * 0.01  # blend start / end, us (100 MHz clock, low 32 bits)
+    be_ = (raw[:, 3] & 0xffffffff).double() * 0.01
+    hw = (raw[:, 1] >> 32) & 0xffffffff
+    cu = ((hw >> 16) & 0xf) * 4096 + ((hw >> 13) & 0x7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xf)
     sl = plan["bin"][end - (8192 + T) * 64: end - 8192 * 64].view(torch.int64).reshape(T, 8).flip(0).cpu()
     ss_b = (sl[:, 0] & 0xffffffff).double() * 0.01  # per bid
     se_b = (sl[:, 6] & 0xffffffff).double() * 0.01
