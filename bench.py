@@ -500,7 +500,69 @@ def main():
                             f"all_gather_into_tensor of the {K} x {world} views at the end",
                 "views_per_s": world * K / float(dt5.item()), "ms_per_step": 1e3 * float(dt5.item()) / K}
 
+    def strong_leg():
+        """SURVEY 8e's other partitioning - STRONG scaling: V = 8 views of ONE 131 072-Gaussian scene (seed 50 on every rank: the
+        Gaussians are replicated), the views sharded over the ranks (`shard_range`), every rank runs the training step of its views
+        (forward that announces its backward + backward, plan API) and ONE bucketed all-reduce sums the per-Gaussian gradients
+        (`reduce_gaussian_grads`: ~45 MB - ring-bound over xGMI).  Total work is fixed as N grows.  Mirrors the reference's data
+        parallelism with the gradient all-reduce DDP performs (src/main.py:109).  Same protocol (warm-ups, K timed, barriers, MAX)."""
+        from pf3plat_amd.distributed import reduce_gaussian_grads, shard_range
+
+        n_s, v_all = args.config5_gaussians, 8
+        b0, b1 = shard_range(v_all, rank, world)
+        v_loc = b1 - b0
+        offs = torch.linspace(-0.35, 0.35, v_all).tolist()
+        sc_s = synthetic.make_scene(50, n_s, (H, W), d_sh=D_SH, num_views=v_all, view_offsets=offs)
+        ins_s = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc_s))
+        vb_all = synthetic.scene_viewbuf(sc_s).to(dev)
+        plan_s, vb_s, g_s = None, None, None
+        if v_loc > 0:
+            vb_s = vb_all[b0:b1].contiguous()
+            cfg_s = RasterConfig(v_loc, 1, v_loc, n_s, H, W, 4, D_SH, 4, False, _gl0.FLAG_BACKWARD_FOLLOWS)
+            plan_s = be.make_plan(cfg_s, dev, capacity=8 * v_loc * n_s, backward=True)
+            be.run_forward(plan_s, vb_s, *ins_s)
+            plan_s = be.make_plan(cfg_s, dev, capacity=be.capacity_for(cfg_s, be.read_status(plan_s), headroom=1.1), backward=True)
+            g_s = torch.rand((v_all, 3, H, W), generator=torch.Generator().manual_seed(9)).to(dev)[b0:b1].contiguous()
+        zeros = None if v_loc > 0 else [torch.zeros_like(ins_s[0]), torch.zeros_like(ins_s[1]), torch.zeros_like(ins_s[2]), torch.zeros_like(ins_s[3])]
+        red_dev = dev if backend == "nccl" else "cpu"
+
+        def one_step():
+            if v_loc > 0:
+                be.run_forward(plan_s, vb_s, *ins_s)
+                be.run_backward(plan_s, vb_s, *ins_s, None, g_s, want_means2d=False)
+                grads = [plan_s["d_means"], plan_s["d_cov6"], plan_s["d_opac"], plan_s["d_colors"]]
+            else:
+                grads = zeros
+            if backend != "nccl":  # functional path (gloo): the exchange on host copies
+                host = [g_.cpu() for g_ in grads]
+                reduce_gaussian_grads(host)
+                return host
+            reduce_gaussian_grads(grads)
+            return grads
+
+        for _ in range(max(Wm, 3)):
+            last = one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            last = one_step()
+        barrier()
+        dts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(dts, op=dist.ReduceOp.MAX)
+        # every rank must hold the SAME summed gradient (and a non-trivial one)
+        chk = torch.tensor([float(last[0].double().abs().sum().item())], dtype=torch.float64, device=red_dev)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return {"workload": f"strong scaling: {v_all} views of ONE {n_s}-Gaussian scene sharded over {world} ranks ({v_loc} on rank 0), Gaussians "
+                            "replicated, training step per rank (fwd + bwd, plan API), one all-reduce of the per-Gaussian gradients per step",
+                "scaling": "strong", "views_per_s": v_all * K / float(dts.item()), "ms_per_step": 1e3 * float(dts.item()) / K,
+                "views_per_rank": [shard_range(v_all, r, world)[1] - shard_range(v_all, r, world)[0] for r in range(world)],
+                "grad_bytes_all_reduced": int(sum(t.numel() for t in last) * 4),
+                "grad_checksum_equal_on_all_ranks": bool(abs(float(hi.item()) - float(lo.item())) <= 1e-6 * max(1.0, float(hi.item()))) and float(hi.item()) > 0.0}
+
     config5 = config5_leg() if (dist_on and not args.config5) else None
+    strong = strong_leg() if (dist_on and not args.config5) else None
 
     result = {
         "metric": "rendered views/sec, 300k Gaussians @ 256x256 (fwd raster); bwd ms and HBM GB/s vs roofline alongside",
@@ -524,6 +586,8 @@ def main():
         result["gather_check"] = gather_check
         if config5 is not None:
             result["config5"] = config5
+        if strong is not None:
+            result["strong_scaling_8_views"] = strong
     result["config"]["preheat"] = (f"{preheat_steps} untimed steps (~{args.preheat_ms:.0f} ms) before the {Wm} warm-up steps: MI355X leaves its "
                                    "low-power state only after some hundred steps (tools/clock_probe.py; profiles/r03_clock_probe.txt)")
     if clocks is not None:

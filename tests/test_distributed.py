@@ -155,6 +155,72 @@ def test_eight_rank_gloo_config5_one_scene_per_rank_one_fused_gather(tmp_path):
     assert len(set(round(x, 4) for x in sums)) == world  # eight different scenes: a permuted slot would show
 
 
+def _worker_strong(rank, world, port, out_dir):
+    """SURVEY 8e's strong-scaling partitioning at a small size: ONE scene replicated on every rank, its 8 views sharded over the
+    ranks (`shard_range`), each rank differentiates its own views, one `reduce_gaussian_grads` sums the per-Gaussian gradients."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import pf3plat_amd
+        from pf3plat_amd import synthetic
+        from pf3plat_amd.types import Gaussians
+        from tests.oracle_backend import OracleBackend
+        from tests.util import install_backend
+
+        torch.set_num_threads(1)
+        install_backend(OracleBackend())
+        n_views = 8
+        sc = synthetic.make_scene(50, 300, (16, 16), num_views=n_views, view_offsets=torch.linspace(-0.35, 0.35, n_views).tolist())
+        b, e = shard_range(n_views, rank, world)
+        g = sc.gaussians
+        leaves = [x.clone().requires_grad_(True) for x in (g.means, g.covariances, g.harmonics, g.opacities)]
+        w = torch.rand((n_views, 3, 16, 16), generator=torch.Generator().manual_seed(9))
+        if e > b:
+            out = pf3plat_amd.DecoderSplattingCUDA().forward(Gaussians(*leaves), sc.extrinsics[:, b:e], sc.intrinsics[:, b:e], sc.near[:, b:e],
+                                                             sc.far[:, b:e], (16, 16))
+            (out.color[0] * w[b:e]).sum().backward()
+            grads = [x.grad for x in leaves]
+        else:
+            grads = [torch.zeros_like(x) for x in leaves]
+        reduce_gaussian_grads(grads)  # the one exchange step of a training step
+        np.savez(os.path.join(out_dir, f"strong_rank{rank}.npz"), span=np.array([b, e]), **{f"g{i}": t.numpy() for i, t in enumerate(grads)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [8, 3])  # 8: one view per rank (the node); 3: ragged shards (3 + 3 + 2 views)
+def test_gloo_strong_scaling_eight_views_of_one_scene_gradient_all_reduce(tmp_path, world):
+    """`bench.py --gpus N`'s strong-scaling leg, its bookkeeping on CPU: 8 views of ONE scene over `world` gloo ranks, every rank ends
+    with the gradient of the whole 8-view loss - equal on all ranks and equal to the single-process gradient."""
+    mp.start_processes(_worker_strong, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True, start_method="fork")
+    import pf3plat_amd
+    from pf3plat_amd import synthetic
+    from pf3plat_amd.types import Gaussians
+    from tests.oracle_backend import OracleBackend
+    from tests.util import install_backend
+
+    got = [np.load(tmp_path / f"strong_rank{r}.npz") for r in range(world)]
+    spans = [tuple(int(x) for x in g["span"]) for g in got]
+    assert spans[0][0] == 0 and spans[-1][1] == 8 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))  # a partition of the 8 views
+    for r in range(1, world):
+        for i in range(4):
+            np.testing.assert_array_equal(got[r][f"g{i}"], got[0][f"g{i}"])  # every rank holds the same summed gradient
+    old = install_backend(OracleBackend())
+    try:
+        sc = synthetic.make_scene(50, 300, (16, 16), num_views=8, view_offsets=torch.linspace(-0.35, 0.35, 8).tolist())
+        g = sc.gaussians
+        leaves = [x.clone().requires_grad_(True) for x in (g.means, g.covariances, g.harmonics, g.opacities)]
+        out = pf3plat_amd.DecoderSplattingCUDA().forward(Gaussians(*leaves), sc.extrinsics, sc.intrinsics, sc.near, sc.far, (16, 16))
+        w = torch.rand((8, 3, 16, 16), generator=torch.Generator().manual_seed(9))
+        (out.color[0] * w).sum().backward()
+    finally:
+        install_backend(old)
+    for i, x in enumerate(leaves):
+        np.testing.assert_allclose(got[0][f"g{i}"], x.grad.numpy(), rtol=2e-4, atol=1e-6)
+        assert np.abs(got[0][f"g{i}"]).sum() > 0
+
+
 def test_gather_is_identity_without_process_group():
     x = torch.arange(6.0).reshape(2, 3)
     assert gather_views(x) is x
@@ -187,6 +253,8 @@ def test_bench_py_two_ranks_on_one_gpu_real_hip_path():
     assert abs(a - b) > 1.0  # two different scenes
     assert abs(d["value"] - 2 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert d["config5"]["views_per_s"] > 0 and "one fused" in d["config5"]["workload"]
+    st = d["strong_scaling_8_views"]
+    assert st["scaling"] == "strong" and st["views_per_rank"] == [4, 4] and st["grad_checksum_equal_on_all_ranks"] and st["views_per_s"] > 0
 
 
 @pytest.mark.gpu
@@ -244,3 +312,5 @@ def test_bench_py_eight_ranks_on_one_gpu_config5_leg():
     assert abs(d["value"] - 8 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) < 1e-6 * d["value"]
     assert d["config"]["windows"]["R"] == 2 and len(d["config"]["windows"]["ms_per_step_of_each_window"]) == 2
     assert d["config5"]["views_per_s"] > 0 and "8 scenes" in d["config5"]["workload"] and "one fused" in d["config5"]["workload"]
+    st = d["strong_scaling_8_views"]  # SURVEY 8e's other partitioning: 8 views of ONE scene, one per rank, gradient all-reduce
+    assert st["scaling"] == "strong" and st["views_per_rank"] == [1] * 8 and st["grad_checksum_equal_on_all_ranks"] and st["views_per_s"] > 0

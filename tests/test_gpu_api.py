@@ -356,7 +356,7 @@ def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on
     The footprints change from step to step, as a scale head's output does in training.  Steps 0-3 read their status; from step 4
     on the forward is deferred and sized from the shape's history: running maximum x max(1.25, 1 + 4 sigma / mean).  Step 6 lists
     ~1.6x the pairs of step 5 - inside the head-room the history has earned: NOT skipped (round 5 sized at a fixed 1.25x and lost
-    such a step).  At step 7 the footprints grow 25-fold (far more than 3x the pairs): NO exception - a warning, a NaN image, all-NaN
+    such a step).  At step 7 the footprints grow 36-fold (far more than 3x the pairs): NO exception - a warning, a NaN image, all-NaN
     gradients, the guard skips the step - and steps 8-9 (same large scene) are finite; step 9 matches the oracle-driven same code."""
     import warnings
 
@@ -385,7 +385,7 @@ def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on
     base5 = pairs_of(0.9)
     g6 = min((1.5 + 0.25 * k for k in range(40)), key=lambda g: abs(pairs_of(g) / base5 - 1.6))
     assert 1.5 < pairs_of(g6) / base5 < 1.75, (g6, pairs_of(g6) / base5)
-    grow = [1.0, 2.2, 0.6, 1.5, 1.0, 0.9, g6, 25.0, 25.0, 25.0]
+    grow = [1.0, 1.3, 0.8, 1.15, 1.0, 0.9, g6, 36.0, 36.0, 36.0]
 
     be = rasterizer.HipBackend()
     old = install_backend(be)
@@ -420,7 +420,7 @@ def test_reference_training_loop_skips_a_step_whose_pair_count_jumps_and_goes_on
             else:
                 assert not caught and torch.isfinite(img).all() and not nan_grad, (k, pairs)
             if k == 5:
-                assert be.headroom_for(key) > 1.3  # the history's spread has widened the factor beyond the floor
+                assert be.headroom_for(key) > 1.25  # the history's spread has widened the factor beyond the floor
             if k == 9:  # against the oracle-driven same code on the same parameter values
                 cpu_leaves = [x.detach().clone().cpu().requires_grad_(True) for x in leaves]
                 oi = _with_oracle(lambda: step(9, cpu_leaves, "cpu"))

@@ -32,6 +32,17 @@ T = 1024
 
 
 def choose_chunk(n, v, slots=256):
+    """-> (chunk, set_mode): the library's choose_chunk for one set of v views (csrc/gsr_hip.hip)."""
+    cmax = (2304 // v) & ~63 if 2 <= v <= 4 else 0
+    if cmax and v * T <= 5120 and -(-n // cmax) <= 256:  # k_preprocess_bin_set: a workgroup bins its chunk for every view of the set
+        best, best_cost = cmax, None
+        for c in range(cmax, 511, -64):
+            if -(-n // c) > 256:
+                break
+            cost = -(-(-(-n // c)) // 256) * c
+            if best_cost is None or cost <= best_cost:
+                best, best_cost = c, cost
+        return best, True
     best, best_cost = 1600, None
     for c in range(1600, 511, -64):
         blocks = v * -(-n // c)
@@ -40,7 +51,7 @@ def choose_chunk(n, v, slots=256):
             break
         if best_cost is None or cost < best_cost:
             best, best_cost = c, cost
-    return best
+    return best, False
 
 
 def xcd_remap(b, n):
@@ -91,9 +102,10 @@ def main():
         be.run_forward(plan, vb, *ins)
     torch.cuda.synchronize()
     lay = be.workspace_layout(plan["dims"])
-    chunk = choose_chunk(n, V)
+    chunk, set_mode = choose_chunk(n, V)
     rows = -(-n // chunk)
-    blocks = V * rows
+    blocks = V * rows  # key slots (layout); the set launch runs `rows` workgroups, each binning its chunk for all V views
+    wgs = rows if set_mode else blocks
     cap = int(plan["dims"].pair_capacity)
     end = lay["keys"] + (blocks * (8192 + 136) + ((cap + 1023) // 1024 + 64) * 1024) * 8
 
@@ -104,9 +116,9 @@ def main():
         return slots_raw(first, count).double() * 0.01
 
     # ---------------- K1
-    b = slots(0, blocks)
+    b = slots(0, wgs)
     t0 = b[:, 0].min()
-    print(f"K1: chunk {chunk}, rows {rows} x views {V} = {blocks} workgroups")
+    print(f"K1: chunk {chunk}, " + (f"{rows} workgroups x {V} views each (set launch)" if set_mode else f"rows {rows} x views {V} = {blocks} workgroups"))
     names = ["start", "projection + histogram", "scan + pair matrix", "pairs walked", "copy-out"]
     print("  binning workgroups, phase END (us from the first start): max", [round((b[:, k].max() - t0).item(), 2) for k in range(5)],
           "| median", [round(torch.median(b[:, k] - t0).item(), 2) for k in range(5)], "  =", names)
@@ -120,6 +132,8 @@ def main():
               "| eval", q(c[:, 3] - c[:, 2]), "| end", q(c[:, 3] - t0))
         print(f"  K1 ends: binning waves {round((b[:, 4].max() - t0).item(), 2)} us, colour waves {round((c[:, 3].max() - t0).item(), 2)} us")
     pm = plan["bin"][lay["counts"]: lay["counts"] + blocks * (T + 8) * 8].view(torch.int32).reshape(blocks, T + 8, 2)[:, :T, 1].sum(1).cpu().double()
+    if set_mode:
+        pm = pm.reshape(V, rows).sum(0)
     cc = lambda x, y: round(torch.corrcoef(torch.stack([x, y]))[0, 1].item(), 3)
     print("  pairs per workgroup", q(pm), "| corr(end, pairs)", cc(b[:, 4] - t0, pm), " corr(projection end, pairs)", cc(b[:, 1] - t0, pm))
 
@@ -144,7 +158,7 @@ def main():
     bid_of_tile = torch.zeros(VT, dtype=torch.int64)
     bid_of_tile[tile_of_bid] = torch.arange(VT)
     k2t0 = ss.min()
-    k1_start_low32 = (slots_raw(0, blocks)[:, 0].min() & 0xffffffff).double() * 0.01
+    k1_start_low32 = (slots_raw(0, wgs)[:, 0].min() & 0xffffffff).double() * 0.01
     print(f"K2: {VT} tiles; first tile starts {round((k2t0 - k1_start_low32).item(), 2)} us after K1's first workgroup")
     q6 = lambda x: q(x, (0.0, 0.1, 0.5, 0.9, 0.99, 1.0))
     print("  quantiles 0/10/50/90/99/100 (us): sort start", q6(ss - k2t0), "| start -> blend start", q6(bs - ss), "| blend duration", q6(be_ - bs),
