@@ -130,25 +130,9 @@ constexpr int kChunkPrefer = 1600;
 // workgroups sit two to a CU (LDS in 1280-byte steps: images of up to 1496 tiles).
 static bool color_in_bin_by_dims(const GsrDims& d, const Grid& g);
 static bool bin_two_per_cu(const Grid& g, bool color_in_bin);
-static bool bin_set_by_dims(const GsrDims& d, const Grid& g);
-static int set_chunk_max(int views_per_set);
 static int choose_chunk(const GsrDims& d) {
   const long long V = d.num_views > 0 ? d.num_views : 1, N = d.num_gaussians > 0 ? d.num_gaussians : 1;
   const Grid g = make_grid(d.width, d.height);
-  if (bin_set_by_dims(d, g)) {
-    // the set binning launch (k_preprocess_bin_set): a workgroup bins its chunk for every view of the set - chunk x views per set
-    // items, at most 2304 - and a view's column of the pair matrix has at most 256 rows.  Fewest rounds x chunk; the smaller chunk
-    // on ties here (more workgroups of a single round: configs[3] = 256 workgroups of 512 Gaussians x 3 views)
-    const long long S = d.num_sets > 0 ? d.num_sets : 1;
-    long long best_cost = -1;
-    int best = set_chunk_max(d.views_per_set);
-    for (int c = set_chunk_max(d.views_per_set); c >= kChunkSmall; c -= 64) {
-      if ((N + c - 1) / c > 256) break;
-      const long long blocks = S * ((N + c - 1) / c), cost = ((blocks + kCUs - 1) / kCUs) * c;
-      if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = c; }
-    }
-    return best;
-  }
   const bool plain_two = bin_two_per_cu(g, color_in_bin_by_dims(d, g));
   const long long slots = plain_two ? 2 * kCUs : kCUs;
   long long best_cost = -1;
@@ -759,13 +743,11 @@ __device__ __forceinline__ GaussIn load_gauss(const Params& p, int v, int i) {
   return in;
 }
 template <class F, class B>
-__device__ __forceinline__ PreRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big, const GsrView* cam_copy = nullptr) {
+__device__ __forceinline__ PreRec preprocess_one(const Params& p, int v, int i, const GaussIn& in, F&& hit, B&& big) {
   const int N = p.d.num_gaussians;
   // (per-lane loads of the uniform record: held in scalar registers - view_const, as k_preprocess_bwd does - the ~30 registers spill in
   // the binning kernels, forward +0.6 us)
-  // cam_copy: the caller's copy of view v's record (k_preprocess_bin_set: in LDS - its view changes from item to item, and a record
-  // read from memory at the head of every item is a round trip under the colour stream on the item's critical path)
-  const GsrView& cam = cam_copy ? *cam_copy : p.views[v];
+  const GsrView& cam = p.views[v];
   const Grid& g = p.g;
   const size_t oi = (size_t)v * N + i;
 
@@ -1498,256 +1480,6 @@ __global__ __launch_bounds__(kBinThreads, (!kColor && kMaxT == kBinTwoMaxT) ? 8 
   if (staged) {
     __syncthreads();
     for (uint32_t k = tid; k < total; k += kBinThreads) region[k] = lds_keys[k];
-  }
-  GSR_STAMP(4);
-#undef GSR_STAMP
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1 for SETS of 2 .. 4 views (round 6): one workgroup bins its chunk of Gaussians for EVERY view of the set.
-// PF3plat's decoder call is one scene x three views (reference decoder_splatting_cuda.py:35-67); as (view, row) workgroups that was
-// 3 x 82 workgroups of 1600 Gaussians, each wave projecting in THREE passes of which the third held three of its eleven waves, five
-// colour waves done at 18 us of a 28 us launch (profiles/r06_a_stamps_*: projection 15.3 us, 0.29 of the roofline on the launch's
-// bytes against 0.56 for the single view).  Here a workgroup owns `chunk` Gaussians (512 for 131 072: 256 workgroups, one round) and
-// its work list is the chunk's (view, 64-Gaussian unit) ITEMS: twelve binning waves take them in passes of twelve (configs[3]:
-// 8 units x 3 views = two full passes), four colour waves stream the chunk's harmonics ONCE and evaluate every view of the set.
-// Per-(view, tile) counters in LDS, ONE region of the key buffer per workgroup (the views' tiles one after the other: the pair
-// matrix rows of the workgroup's views carry offsets into it and `blk_base` of each (view, row) points at it, so the tile launch
-// needs to know nothing), staged pairs 2 bytes each in the two unit buffers the fifth colour wave and the old staging area had.
-// Everything else - prefetch of the next item's inputs, the record transpose, the scan / walk / copy-out under the colour stream -
-// is k_preprocess_bin<true, .>'s.
-// ------------------------------------------------------------------------------------------------
-#ifndef GSR_BIN_SET
-#define GSR_BIN_SET 1  // 0: measurement builds without the set instance
-#endif
-constexpr int kSetColorWaves = 4, kSetBinWaves = kBinThreads / 64 - kSetColorWaves;  // 4 + 12
-constexpr int kSetIters = 3;                                                        // projection passes a wave can hold in registers
-constexpr int kSetMaxItems = kSetIters * kSetBinWaves * 64;                         // 2304 (view, Gaussian) items per workgroup
-constexpr int kSetStageBytes = kSetBinWaves * 1024;                                 // record transpose; later the items' depths (3072 floats)
-constexpr int kSetStagePairs = 2 * kColorLdsFloats * 4 / 2;                         // 19 200 two-byte entries in two unit buffers
-constexpr int kSetMaxTiles = 5120;                                                  // views per set x tiles (LDS: 12 + 20 + 6 x 18.75 KB + 10 KB static)
-static_assert(kSetMaxItems * 4 <= kSetStageBytes && kSetMaxItems < 65536, "depth table fits the transpose area, an item index 16 bits");
-constexpr size_t bin_set_lds_bytes(int TT) {
-  return (size_t)kSetStageBytes + (((size_t)TT * 4 + 15) & ~(size_t)15) + (size_t)(kSetColorWaves + 2) * kColorLdsFloats * 4;
-}
-static_assert(bin_set_lds_bytes(kSetMaxTiles) + 11200u <= 160u * 1024u, "LDS of the set binning launch (11 088 B static)");
-static int set_chunk_max(int views_per_set) { return (kSetMaxItems / views_per_set) & ~63; }
-static bool bin_set_by_dims(const GsrDims& d, const Grid& g) {
-  if (!GSR_BIN_SET || !color_in_bin_by_dims(d, g) || d.views_per_set < 2 || d.views_per_set > 4) return false;
-  if ((long long)d.views_per_set * g.T > kSetMaxTiles) return false;
-  const long long cmax = set_chunk_max(d.views_per_set);
-  return ((long long)d.num_gaussians + cmax - 1) / cmax <= kSortThreads;  // the tile launch gathers a column of at most 256 rows
-}
-template <bool kJ>
-__global__ __launch_bounds__(kBinThreads, 4) void k_preprocess_bin_set(const Params p) {
-  extern __shared__ float4 dyn_stage[];
-  constexpr int kWavesA = kSetBinWaves, kBinT = kWavesA * 64;
-  uint32_t* hist = reinterpret_cast<uint32_t*>(dyn_stage + kSetStageBytes / 16);
-  __shared__ float bigs[kBigList][10];
-  __shared__ uint32_t nbig, wtot[kBinThreads / 64], sBase, next_unit, bin_bar;
-  __shared__ GsrView sCam[4];  // the set's camera records (768 B)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, row = blockIdx.x, set = blockIdx.y;
-  const int Vs = p.d.views_per_set, T = p.g.T, TT = Vs * T, N = p.d.num_gaussians;
-  if (tid < Vs * (int)(sizeof(GsrView) / 4)) reinterpret_cast<float*>(sCam)[tid] = reinterpret_cast<const float*>(p.views + (size_t)set * Vs)[tid];
-  const bool dbg = GSR_ABL(p.d.flags, GSR_FLAG_DEBUG_TIMING);
-  unsigned long long* stamp = dbg_stamps(p, (size_t)(blockIdx.y * gridDim.x + blockIdx.x));
-#define GSR_STAMP(k) do { if (dbg && tid == 0) stamp[k] = __builtin_amdgcn_s_memrealtime(); } while (0)
-  GSR_STAMP(0);
-  for (int k = tid; k < TT; k += kBinThreads) hist[k] = 0;
-  if (tid == 0) {
-    nbig = 0;
-    next_unit = 0;
-    bin_bar = 0;
-    if (row == 0 && set == 0) {  // only the tile launch touches these, and it runs after this kernel
-      p.status->overflow = 0; p.status->max_list = 0; *p.tail_counter = 0u;
-      *p.page_counter_tiles = (unsigned long long)p.call_tag << 32;
-    }
-  }
-  __syncthreads();
-  const int chunk0 = row * p.chunk, end = min(N, chunk0 + p.chunk);
-  const int upc = (end - chunk0 + 63) >> 6, nitems = upc * Vs;  // units of this chunk; its (view, unit) items
-  float* const colbufs = reinterpret_cast<float*>(hist + ((TT + 3) & ~3));  // four unit buffers of the colour waves, then two of staging
-  if (w >= kWavesA) {  // ---- colour waves: the chunk's units, every view of the set per unit (the harmonics are read once)
-    float* buf = colbufs + (size_t)(w - kWavesA) * kColorLdsFloats;
-    const int u0 = chunk0 >> 6;
-    while (true) {
-      uint32_t k = 0;
-      if (lane == 0) k = atomicAdd(&next_unit, 1u);
-      const int t = (int)__builtin_amdgcn_readfirstlane((int)k);
-      if (t >= upc) break;
-      color_unit_wave<kJ>(p, set, u0 + t, buf, lane, 0, Vs);
-    }
-    return;
-  }
-  // ---- binning waves.  Item j = w + pass * 12 of the workgroup: view j / upc of the set, unit j % upc of the chunk
-  float4* stage = dyn_stage + w * 64;  // this wave's 1 KB of record transpose
-  auto item_of = [&](int it, int& vv, int& first) {
-    const int j = w + it * kWavesA;
-    vv = 0; first = end;
-    if (j < nitems) {
-      vv = (j >= upc) + (j >= 2 * upc) + (j >= 3 * upc);
-      first = chunk0 + (j - vv * upc) * 64;
-    }
-    vv = __builtin_amdgcn_readfirstlane(vv); first = __builtin_amdgcn_readfirstlane(first);
-  };
-  float4 q3s[kSetIters];
-  uint32_t inl = 0;  // bit it: this lane's wide footprint of pass it did not fit the deferred list
-  int vv_n, first_n;
-  item_of(0, vv_n, first_n);
-  GaussIn nxt{};
-  if (first_n + lane < end) nxt = load_gauss(p, set * Vs + vv_n, first_n + lane);
-#pragma unroll
-  for (int it = 0; it < kSetIters; ++it) {
-    const int vv = vv_n, first = first_n;
-    q3s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (first >= end) continue;  // wave-uniform; items are taken in order, so every later pass is empty as well
-    const int v = set * Vs + vv, i = first + lane;
-    const GaussIn cur = nxt;
-    if (it + 1 < kSetIters) {
-      item_of(it + 1, vv_n, first_n);
-      if (first_n + lane < end) nxt = load_gauss(p, set * Vs + vv_n, first_n + lane);
-    }
-    uint32_t* hv = hist + vv * T;
-    auto count = [&](int t) { atomicAdd(&hv[t], 1u); };
-    PreRec rec{};
-    if (i < end) {
-      rec = preprocess_one(p, v, i, cur, count, [&](int gi, const Foot& f, float depth) {
-        const uint32_t slot = atomicAdd(&nbig, 1u);
-        if (slot < (uint32_t)kBigList) {
-          float* b = bigs[slot];
-          b[0] = f.cx; b[1] = f.cy; b[2] = f.A; b[3] = f.B; b[4] = f.C; b[5] = f.tau;
-          b[6] = __int_as_float(f.sx0 | (f.sx1 << 16)); b[7] = __int_as_float(f.sy0 | (f.sy1 << 16));
-          b[8] = __int_as_float(gi | (vv << 28)); b[9] = depth;
-        } else {
-          inl |= 1u << it;
-          big_walk_lane(f, p.g, count);
-        }
-      }, &sCam[vv]);
-      q3s[it] = rec.q3;
-    }
-    if (!GSR_ABL(p.d.flags, GSR_FLAG_ABLATE_NO_GEOM_STORE)) store_records_wave_1k(p.geom + (size_t)v * N + first, end - first, rec, stage, lane);
-    if (p.grad_rows) zero_rows_wave(p, v, first, end - first, lane);
-  }
-  auto arrive = [&]() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_fetch_add(&bin_bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  };
-  auto wait_for = [&](uint32_t target) {
-    while (__hip_atomic_load(&bin_bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  };
-  uint32_t bar = 0;
-  auto group_barrier = [&]() { arrive(); bar += kWavesA; wait_for(bar); };
-  group_barrier();  // every pair of the small footprints is in its counter, every record has left the transpose area
-  float* dtab = reinterpret_cast<float*>(dyn_stage);  // depth of item (vv, i): dtab[vv * chunk + i - chunk0]
-#pragma unroll
-  for (int it = 0; it < kSetIters; ++it) {
-    int vv, first;
-    item_of(it, vv, first);
-    if (first + lane < end) dtab[vv * p.chunk + first + lane - chunk0] = q3s[it].w;
-  }
-  const int nb = (int)min(nbig, (uint32_t)kBigList);
-  for (int e = w; e < nb; e += kWavesA) {  // wide footprints: one wave each, 64 candidate tiles per step
-    uint32_t* hv = hist + (__float_as_int(bigs[e][8]) >> 28) * T;
-    big_walk_wave(foot_from_lds(bigs[e], p.g), p.g, lane, [&](int t) { atomicAdd(&hv[t], 1u); });
-  }
-  group_barrier();
-  GSR_STAMP(1);
-  // ---- exclusive scan of the counters, the views' tiles one after the other (thread t owns `per` consecutive counters)
-  constexpr int kPer = (kSetMaxTiles + kBinT - 1) / kBinT;  // 7
-  const int per = (TT + kBinT - 1) / kBinT;
-  const int b0 = tid * per;
-  uint32_t cnt[kPer], sum = 0;
-#pragma unroll
-  for (int q = 0; q < kPer; ++q) {
-    cnt[q] = (q < per && b0 + q < TT) ? hist[b0 + q] : 0u;
-    sum += cnt[q];
-  }
-  const uint32_t incl = wave_inclusive_scan_u32(sum);
-  if (lane == 63) wtot[w] = incl;
-  group_barrier();  // also: every counter has been read
-  uint32_t basew = 0, total = 0;
-#pragma unroll
-  for (int k = 0; k < kWavesA; ++k) {
-    const uint32_t x = wtot[k];
-    basew += (k < w) ? x : 0u;
-    total += x;
-  }
-  // the workgroup's region: the Vs consecutive fixed slots of its (view, row) blocks as ONE, or - beyond that / beyond what the
-  // staging area holds - pages of the pool
-  const uint32_t room = min((uint32_t)kSetStagePairs, (uint32_t)Vs * (uint32_t)kSlotStride - 136u);
-  if (tid == 0) {
-    uint32_t base = (uint32_t)((((size_t)set * p.rows + row) * Vs) * kSlotStride);
-    if (total > room) {
-      const uint32_t npages = (total + kPage - 1) / kPage;
-      const uint32_t first = take_pages(p.page_counter, p.call_tag, npages), half = p.key_pages / 2;  // lower half of the pool
-      base = (first <= half && npages <= half - first) ? p.pool_off + first * (uint32_t)kPage : 0xffffffffu;
-    }
-    sBase = base;
-    for (int vv = 0; vv < Vs; ++vv) {
-      const size_t blk = (size_t)(set * Vs + vv) * p.rows + row;
-      p.blk_base[blk] = base;               // every view's row points at the one region; the matrix rows carry offsets into it
-      p.blk_total[blk] = vv == 0 ? total : 0u;  // (summed over all blocks by the tile launch: the call's pair count)
-    }
-  }
-  {
-    uint32_t run = basew + incl - sum;
-#pragma unroll
-    for (int q = 0; q < kPer; ++q)
-      if (q < per && b0 + q < TT) {
-        const int idx = b0 + q, vv = (idx >= T) + (idx >= 2 * T) + (idx >= 3 * T);
-        p.pair_mat[((size_t)(set * Vs + vv) * p.rows + row) * (T + 8) + (idx - vv * T)] = make_uint2(run, cnt[q]);
-        hist[idx] = run;  // from here on: the (view, tile)'s cursor inside the region
-        run += cnt[q];
-      }
-  }
-  group_barrier();
-  GSR_STAMP(2);
-  const uint32_t base = sBase;
-  if (base == 0xffffffffu || total == 0) return;
-  const bool staged = total <= room;
-  unsigned long long* region = p.keys + base;
-  unsigned short* st16 = reinterpret_cast<unsigned short*>(colbufs + (size_t)kSetColorWaves * kColorLdsFloats);
-#pragma unroll
-  for (int it = 0; it < kSetIters; ++it) {
-    int vv, first;
-    item_of(it, vv, first);
-    const int i = first + lane;
-    if (i >= end) continue;
-    uint32_t* hv = hist + vv * T;
-    const int tab0 = vv * p.chunk - chunk0;
-    auto put = [&](int gi, int t, float depth) {
-      const uint32_t slot = atomicAdd(&hv[t], 1u);
-      if (staged) st16[slot] = (unsigned short)(tab0 + gi);
-      else region[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
-    };
-    walk_pairs(p, q3s[it], i, 0, T, put, [&](int gi) {
-      if (!((inl >> it) & 1u)) return;  // deferred: walked by a whole wave below
-      const Foot ft = foot_of_record(p.geom + (size_t)(set * Vs + vv) * N + gi, p.g);  // this wave's own store (complete since the first barrier)
-      const float depth = q3s[it].w;
-      big_walk_lane(ft, p.g, [&](int t) { put(gi, t, depth); });
-    });
-  }
-  for (int e = w; e < nb; e += kWavesA) {
-    const float* b = bigs[e];
-    const int word = __float_as_int(b[8]), gi = word & 0x0fffffff, vv = word >> 28;
-    const float depth = b[9];
-    uint32_t* hv = hist + vv * T;
-    const int tab0 = vv * p.chunk - chunk0;
-    big_walk_wave(foot_from_lds(b, p.g), p.g, lane, [&](int t) {
-      const uint32_t slot = atomicAdd(&hv[t], 1u);
-      if (staged) st16[slot] = (unsigned short)(tab0 + gi);
-      else region[slot] = ((unsigned long long)__float_as_uint(depth) << 32) | (uint32_t)gi;
-    });
-  }
-  GSR_STAMP(3);
-  if (staged) {
-    group_barrier();
-    const int c = p.chunk;
-    for (uint32_t k = tid; k < total; k += kBinT) {
-      const int loc = st16[k], vv = (loc >= c) + (loc >= 2 * c) + (loc >= 3 * c);
-      region[k] = ((unsigned long long)__float_as_uint(dtab[loc]) << 32) | (uint32_t)(chunk0 + loc - vv * c);
-    }
   }
   GSR_STAMP(4);
 #undef GSR_STAMP
@@ -4405,10 +4137,7 @@ static int ensure_bin_attributes(int* dev_out) {
                                 (int)bin_lds_bytes(kBinTwoMaxT, false)));
   const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess &&
                   hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_color) == hipSuccess;
-  const int with_set = (int)bin_set_lds_bytes(kSetMaxTiles);  // (+ 11.1 KB static: the camera records of the set sit in LDS too)
-  const bool ok_set = ok && hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin_set<false>), hipFuncAttributeMaxDynamicSharedMemorySize, with_set) == hipSuccess &&
-                      hipFuncSetAttribute(reinterpret_cast<const void*>(k_preprocess_bin_set<true>), hipFuncAttributeMaxDynamicSharedMemorySize, with_set) == hipSuccess;
-  if (ok && ok_set) g_color_bin_ok.fetch_or(bit, std::memory_order_relaxed);
+  if (ok) g_color_bin_ok.fetch_or(bit, std::memory_order_relaxed);
   else (void)hipGetLastError();
   g_lds_set.fetch_or(bit, std::memory_order_release);
   return GSR_OK;
@@ -4548,12 +4277,7 @@ static int forward_impl(const GsrDims* dims, const GsrView* views, const float* 
     const size_t shmem = bin_lds_bytes(p.g.T, color_in_bin);
     // (two plain workgroups per CU where the image's tile counters leave the LDS for it: LDS comes in 1280-byte steps)
     const bool two_per_cu = bin_two_per_cu(p.g, color_in_bin);
-    if (color_in_bin && bin_set_by_dims(d, p.g)) {  // sets of 2 .. 4 views: one workgroup per (row, set), every view of the set in it
-      const dim3 sgrid((unsigned)p.rows, (unsigned)d.num_sets);
-      const size_t smem = bin_set_lds_bytes(d.views_per_set * p.g.T);
-      if (p.shj) hipLaunchKernelGGL((k_preprocess_bin_set<true>), sgrid, dim3(kBinThreads), smem, st, p);
-      else hipLaunchKernelGGL((k_preprocess_bin_set<false>), sgrid, dim3(kBinThreads), smem, st, p);
-    } else if (two_per_cu) hipLaunchKernelGGL((k_preprocess_bin<false, false, kBinTwoMaxT>), bgrid, dim3(kBinThreads), shmem, st, p);
+    if (two_per_cu) hipLaunchKernelGGL((k_preprocess_bin<false, false, kBinTwoMaxT>), bgrid, dim3(kBinThreads), shmem, st, p);
     else if (!color_in_bin) hipLaunchKernelGGL((k_preprocess_bin<false, false>), bgrid, dim3(kBinThreads), shmem, st, p);
     else if (p.shj) hipLaunchKernelGGL((k_preprocess_bin<true, true>), bgrid, dim3(kBinThreads), shmem, st, p);
     else hipLaunchKernelGGL((k_preprocess_bin<true, false>), bgrid, dim3(kBinThreads), shmem, st, p);

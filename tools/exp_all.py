@@ -1,6 +1,6 @@
 """Measurement aid (GPU box): the step times the round's targets are written in, for the library variant in GSR_LIB_PATH, in ONE process
 (plan API, kernels only): headline forward, fwd + bwd, BASELINE configs[3] (3 views x 131 072 Gaussians, colour + depth) forward and
-training step, 8 views of the headline scene, 48 views of the 131 072-Gaussian scene; an image checksum per shape.
+training step - on the independently drawn scene and ("cfg4s", "shards") on the pixel-aligned one -, one 131 072-Gaussian view ("shard"), 8 views of the headline scene, 48 views of the 131 072-Gaussian scene; an image checksum per shape.
 usage: python tools/exp_all.py <label> [steps=300]"""
 import os
 import sys
@@ -18,8 +18,8 @@ be = HipBackend()
 H = W = 256
 
 
-def shape(seed, n, views, offsets=None, extra_mode=0, train=False):
-    sc = synthetic.make_scene(seed, n, (H, W), num_views=views, view_offsets=offsets)
+def shape(seed, n, views, offsets=None, extra_mode=0, train=False, structure="random"):
+    sc = synthetic.make_scene(seed, n, (H, W), num_views=views, view_offsets=offsets, structure=structure)
     ins = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
     vb = synthetic.scene_viewbuf(sc).to(dev)
     fl = (_lib.FLAG_BACKWARD_FOLLOWS if train else 0) | (extra_mode << 4)
@@ -62,6 +62,10 @@ def main():
                                   ("fwd+bwd", dict(seed=2, n=300000, views=1, train=True), K // 2, 1),
                                   ("cfg4 fwd", dict(seed=50, n=131072, views=3, extra_mode=1), K // 2, 1),
                                   ("cfg4 train", dict(seed=50, n=131072, views=3, extra_mode=1, train=True), K // 3, 1),
+                                  ("shard", dict(seed=50, n=131072, views=1), K, 1),
+                                  ("cfg4s fwd", dict(seed=50, n=131072, views=3, extra_mode=1, structure="pixel_aligned"), K // 2, 1),
+                                  ("cfg4s train", dict(seed=50, n=131072, views=3, extra_mode=1, train=True, structure="pixel_aligned"), K // 3, 1),
+                                  ("shards", dict(seed=50, n=131072, views=1, structure="pixel_aligned"), K, 1),
                                   ("8 views/view", dict(seed=2, n=300000, views=8, offsets=offs8), 40, 8),
                                   ("48 views/view", dict(seed=50, n=131072, views=48, offsets=torch.linspace(-0.45, 0.45, 48).tolist()), 10, 48)):
         if only and name.split()[0] not in only and name not in only:

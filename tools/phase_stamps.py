@@ -32,17 +32,7 @@ T = 1024
 
 
 def choose_chunk(n, v, slots=256):
-    """-> (chunk, set_mode): the library's choose_chunk for one set of v views (csrc/gsr_hip.hip)."""
-    cmax = (2304 // v) & ~63 if 2 <= v <= 4 else 0
-    if cmax and v * T <= 5120 and -(-n // cmax) <= 256:  # k_preprocess_bin_set: a workgroup bins its chunk for every view of the set
-        best, best_cost = cmax, None
-        for c in range(cmax, 511, -64):
-            if -(-n // c) > 256:
-                break
-            cost = -(-(-(-n // c)) // 256) * c
-            if best_cost is None or cost <= best_cost:
-                best, best_cost = c, cost
-        return best, True
+    """-> (chunk, False): the library's choose_chunk (csrc/gsr_hip.hip).  (The flag named round 6's set binning launch, measured and dropped.)"""
     best, best_cost = 1600, None
     for c in range(1600, 511, -64):
         blocks = v * -(-n // c)
