@@ -922,10 +922,13 @@ def main():
                 # ---- BASELINE configs[3], the call PF3plat's decoder makes every step (decoder_splatting_cuda.py:35-67, depth rendered
                 # with the colour: config/main.yaml:50): 3 views of 131 072 Gaussians, colour + depth, through the plan API - the
                 # kernels alone, with SURVEY 8d's bytes (inputs once per set), the fraction of the roofline, and the dominant kernel
-                def config4_roofline(train):
-                    c4 = config4_call(train)
-                    gc4 = torch.rand((3, 3, H, W), device=dev)
-                    ge4 = torch.rand((3, H, W), device=dev)
+                def shape_roofline(c4, train, workload, profile_note):
+                    """A V-views-of-one-set call of the plan API as a roofline object: step time (time_calls), SURVEY 8d's bytes with the set's
+                    inputs charged once, N_v / R16 / 8x8 pairs / entries the tile launch walked, event-timed stages, dominant kernel."""
+                    cfg_c, n_c, v_c = c4["cfg"], c4["cfg"].num_gaussians, c4["cfg"].num_views
+                    has_x = bool(cfg_c.has_extra)
+                    gc4 = torch.rand((v_c, 3, H, W), device=dev)
+                    ge4 = torch.rand((v_c, H, W), device=dev) if has_x else None
 
                     def one():
                         be.run_forward(c4["plan"], c4["vb"], *c4["ins"])
@@ -933,9 +936,13 @@ def main():
                             be.run_backward(c4["plan"], c4["vb"], *c4["ins"], None, gc4, ge4)
 
                     t4_ = time_calls(one, 200, 200)
-                    assert not be.read_status(c4["plan"])["overflow"]
-                    nv_any4, pv4 = multi_view_stats(c4["plan"], 131072, 3, H, W)
-                    fwd_b, bwd_b = multi_view_bytes(131072, nv_any4, pv4, H * W, D_SH, extra=True)
+                    st_c = be.read_status(c4["plan"])
+                    assert not st_c["overflow"]
+                    lay_c = be.workspace_layout(c4["plan"]["dims"])
+                    vt_c = v_c * 4 * ((H + 15) // 16) * ((W + 15) // 16)
+                    walked = int(c4["plan"]["bin"][lay_c["tile_total"]: lay_c["tile_total"] + vt_c * 4].view(torch.int32).sum().item())
+                    nv_any4, pv4 = multi_view_stats(c4["plan"], n_c, v_c, H, W)
+                    fwd_b, bwd_b = multi_view_bytes(n_c, nv_any4, pv4, H * W, D_SH, extra=has_x)
                     total_b = fwd_b + (bwd_b if train else 0)
                     stages = {}
                     for _ in range(20):
@@ -948,13 +955,13 @@ def main():
                     r16_4 = sum(b_ for _, b_ in pv4)
                     nv_4 = sum(a_ for a_, _ in pv4)
                     kc4 = 12 * D_SH
-                    share = {"tiles": r16_4 * (8 + 36) + 3 * H * W * 24, "preprocess": 12 * 131072 + nv_any4 * (28 + kc4) + nv_4 * 40 + 8 * r16_4,
-                             "blend_bwd": 3 * H * W * 24 + r16_4 * 44 + nv_4 * 40,
-                             "preprocess_bwd": nv_4 * 40 + nv_any4 * (36 + kc4) + 131072 * (40 + kc4)}
-                    return {"workload": "BASELINE configs[3] through the plan API: B = 1, G = 131072 (seed 50), V = 3 views 256x256 of one set, colour + "
-                                        "built-in depth channel" + (", forward (GSR_FLAG_BACKWARD_FOLLOWS) + backward" if train else ", forward only"),
+                    px_b = 20 + (4 if has_x else 0)
+                    share = {"tiles": r16_4 * (8 + 36) + v_c * H * W * px_b, "preprocess": 12 * n_c + nv_any4 * (28 + kc4) + nv_4 * 40 + 8 * r16_4,
+                             "blend_bwd": v_c * H * W * px_b + r16_4 * 44 + nv_4 * 40,
+                             "preprocess_bwd": nv_4 * 40 + nv_any4 * (36 + kc4) + n_c * (40 + kc4)}
+                    return {"workload": workload + (", forward (GSR_FLAG_BACKWARD_FOLLOWS) + backward" if train else ", forward only"),
                             "ms_per_call": 1e3 * t4_, "N_v_any": nv_any4, "N_v_per_view": [a_ for a_, _ in pv4], "R16_per_view": [b_ for _, b_ in pv4],
-                            "num_pairs_8x8": c4["status"]["num_pairs"], "max_tile_list": c4["status"]["max_list"],
+                            "num_pairs_8x8": st_c["num_pairs"], "max_tile_list": st_c["max_list"], "list_entries_walked_by_the_tile_launch": walked,
                             "algorithmic_bytes": total_b, "forward_bytes": fwd_b, "backward_bytes": bwd_b if train else None,
                             "bound": "hbm", "achieved": total_b / t4_ / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": total_b / t4_ / 1e9 / HBM_PEAK_GBS,
                             "stage_ms_event_timed": {k_: round(v_, 5) for k_, v_ in stages.items()},
@@ -962,10 +969,26 @@ def main():
                                                 "algorithmic_bytes": share.get(dom4),
                                                 "frac": None if dom4 not in share else share[dom4] / (stages[dom4] * 1e-3) / 1e9 / HBM_PEAK_GBS},
                             "note": "bytes: SURVEY 8d with the set's inputs once (12 N + N_v(any)(28 + 12 K); backward: N_v(any)(36 + 12 K) + N (40 + 12 K)) "
-                                    "and per view N_v 40 + R16 52 + HW 24 forward (HW 24 + R16 44 + N_v 80 backward); rocprofv3 averages of the same "
-                                    "child run: profiles/r05_*_kernel_stats_config4_{fwd,train}.md"}
+                                    "and per view N_v 40 + R16 52 + HW 20 (+ 4 with the depth channel) forward (HW 20 (+ 4) + R16 44 + N_v 80 backward); "
+                                    + profile_note}
+
+                def config4_roofline(train, structure="random"):
+                    what = ("BASELINE configs[3] through the plan API: B = 1, G = 131072 (seed 50), V = 3 views 256x256 of one set, colour + built-in depth channel"
+                            + ("" if structure == "random" else "; PIXEL-ALIGNED scene (synthetic.make_scene(structure='pixel_aligned'): one Gaussian per pixel of "
+                               "the two context images in raster order on smooth depth surfaces, opacity skewed to 1 - what the reference's encoder emits, "
+                               "encoder_costvolume.py:509-573)"))
+                    return shape_roofline(config4_call(train, structure), train, what,
+                                          "rocprofv3 averages of the same child run: profiles/r06_*_kernel_stats_config4" + ("s" if structure != "random" else "") + "_{fwd,train}.md")
 
                 result["roofline_config4"] = {"fwd": config4_roofline(False), "train": config4_roofline(True)}
+                # ---- the same call on the scene structure PF3plat's encoder really emits (VERDICT r05 missing 3): raster-order, pixel-aligned
+                # Gaussians on two smooth depth surfaces - memory-order coherence for the binning launch, long runs for the tile launch's gather
+                result["roofline_config4_structured"] = {"fwd": config4_roofline(False, "pixel_aligned"), "train": config4_roofline(True, "pixel_aligned")}
+                # ---- BASELINE configs[4]'s share of ONE GPU: one DL3DV-shaped scene of 131 072 Gaussians, one target view, colour only
+                # (assets/evaluation_index_dl3dv_10view.json: 2 context -> 1 target; the multi-GPU line shards eight of these, one per rank)
+                result["roofline_config5_shard"] = shape_roofline(
+                    shard131k_call(), False, "BASELINE configs[4], one GPU's shard through the plan API: one scene of 131072 Gaussians (seed 50), ONE target view 256x256, colour only",
+                    "rocprofv3 averages of the same child run: profiles/r06_*_kernel_stats_shard131k.md")
                 # ---- two calls in flight (NOT the headline): the headline step alternating between two HIP streams, each with its own
                 # workspaces and output - the tail of one call's tile launch may run under the head of the next call's binning launch.
                 # What cross-call overlap buys with the kernels as they are (a binning workgroup owns its CU: DESIGN 8)

@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _scene_case(seed, n, hw, views=1, use_sh=True, with_extra=True, grads=True, d_sh=25, scale_invariant=True, near=1.0,
-                view_offsets=None, extra_mode=0, flags=0):
-    sc = synthetic.make_scene(seed, n, hw, num_views=views, d_sh=d_sh, near=near, view_offsets=view_offsets)
+                view_offsets=None, extra_mode=0, flags=0, structure="random", source_shape=None):
+    sc = synthetic.make_scene(seed, n, hw, num_views=views, d_sh=d_sh, near=near, view_offsets=view_offsets, structure=structure,
+                              source_shape=source_shape)
     means, cov6, opac, colors = gpu_util.scene_tensors(sc, use_sh)
     vb = gpu_util.scene_viewbuf(sc, scale_invariant)
     h, w = hw
@@ -166,6 +167,26 @@ def test_config4_full_size_131072_gaussians_3_views_colour_and_depth():
     cfg, res = _scene_case(50, 131072, (256, 256), views=3, extra_mode=1)
     _all_checks(cfg, res, max_tiles=48, strict=True)
     assert all(st.n_visible > 100000 for st in res["oracle"]["stats"])
+
+
+def test_config4_full_size_on_the_pixel_aligned_scene_the_encoder_emits():
+    """BASELINE configs[3] at its real size on the scene STRUCTURE PF3plat's encoder hands its decoder (reference
+    src/model/encoder/encoder_costvolume.py:509-573, gaussian_adapter.py:63-111): one Gaussian per pixel of the two 256 x 256 context images
+    in raster order, on two smooth depth surfaces, opacity skewed to 1 (synthetic.make_scene(structure="pixel_aligned")) - 3 views, colour +
+    built-in depth, forward and backward against the oracle: strict (1e-4 over ALL pixels and ALL gradient rows, nothing set aside).  This
+    is the input order under which a binning workgroup's chunk lands in a narrow band of the image: runs of 50-200 keys per (row, tile)
+    (the tile launch's cooperative long-run gather), workgroups listing more pairs than their fixed key slot holds (page pool)."""
+    cfg, res = _scene_case(50, 131072, (256, 256), views=3, extra_mode=1, structure="pixel_aligned")
+    _all_checks(cfg, res, max_tiles=128, strict=True)
+    st = res["hip"]["status"] if "status" in res["hip"] else None
+    assert st is None or not st["overflow"]
+
+
+def test_pixel_aligned_scene_small_source_grid_and_ragged_views():
+    """The same structure at a small size (a 24 x 40 source grid: 1920 Gaussians), rendered into two views of a different shape:
+    generator arguments, long runs on a small grid, strict."""
+    cfg, res = _scene_case(9, 2 * 24 * 40, (72, 56), views=2, structure="pixel_aligned", source_shape=(24, 40))
+    _all_checks(cfg, res, strict=True)
 
 
 def test_against_fp64_oracle_gradients():
