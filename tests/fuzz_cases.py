@@ -12,10 +12,12 @@ from pf3plat_amd.rasterizer import RasterConfig
 from tests import gpu_util
 
 
-def draw_case(rng, build: bool = True):
+def draw_case(rng, build: bool = True, structure: str = "random"):
     """One random case: -> (desc, inputs) with inputs = (cfg, viewbuf, means, cov6, opac, colors, extra, g_color, g_extra, capacity),
     all CPU tensors.  build=False makes exactly the same draws (the generator ends in the same state) without building anything:
-    -> (desc, None)."""
+    -> (desc, None).  structure="pixel_aligned" (round 6): the same draws, but the scene is the encoder-structured one
+    (synthetic.make_scene(structure="pixel_aligned")) with the largest square source grid of at most n / 2 pixels - raster-ordered
+    Gaussians, long (row, tile) runs; no extra random draw, so case (seed, k) names the same shape in both modes."""
     n = int(rng.choice([0, 1, 7, 63, 64, 65, 500, 1023, 1024, 1025, 3000, 9000, 20000]))
     h, w = int(rng.integers(1, 161)), int(rng.integers(1, 161))
     if rng.random() < 0.15:
@@ -31,6 +33,10 @@ def draw_case(rng, build: bool = True):
     nears = [float(rng.choice([1.0, 0.5, 2.0])) for _ in range(sets)]
     scale_inv = [bool(rng.random() < 0.7) for _ in range(sets)]
     extra_np = rng.uniform(0.5, 2.0, (views, n)).astype(np.float32) if with_extra else None
+    side = int(np.sqrt(n // 2)) if structure == "pixel_aligned" else 0
+    if side >= 2:  # (smaller cases stay independently drawn)
+        n = 2 * side * side
+        extra_np = extra_np[:, :n].copy() if extra_np is not None else None
     deg = int(round(d_sh ** 0.5)) - 1
     flags = _lib.FLAG_WINDOWED_BINNING if windowed else 0
     # native layouts and built-in extra modes (depth / disparity / relative disparity / log from the camera-space depth)
@@ -46,7 +52,8 @@ def draw_case(rng, build: bool = True):
                 planar=planar, cov33=cov33, emode=emode, follows=follows, det=det)
     if not build:
         return desc, None
-    scs = [synthetic.make_scene(seed + s, n, (h, w), num_views=vps, d_sh=d_sh, near=nears[s]) for s in range(sets)]
+    kw = dict(structure="pixel_aligned", source_shape=(side, side)) if side >= 2 else {}
+    scs = [synthetic.make_scene(seed + s, n, (h, w), num_views=vps, d_sh=d_sh, near=nears[s], **kw) for s in range(sets)]
     parts = [gpu_util.scene_tensors(sc, use_sh) for sc in scs]
     means, cov6, opac, colors = (torch.cat([p[k] for p in parts], 0) for k in range(4))
     vb = torch.cat([gpu_util.scene_viewbuf(sc, scale_inv[s]) for s, sc in enumerate(scs)], 0)

@@ -1,6 +1,7 @@
 """Randomised HIP-vs-oracle parity sweep (MI355X box): random Gaussian counts, image sizes, view / set structure, SH degrees,
 extra channel, scale factors and pair capacities, every case through the same checks as tests/test_gpu_parity.py.
 usage: python tools/fuzz_parity.py [seconds=60] [seed=0]
+       FUZZ_STRUCTURE=pixel_aligned: the same cases on the encoder-structured scene (raster-ordered Gaussians: long (row, tile) runs)
        python tools/fuzz_parity.py --cases 1000 --seeds 0,1,2,3,4 --out gpurun_out/fuzz.json   (the margin survey: every case's worst
        image / gradient rel-L2 and its outlier counts -> histogram; tools/fuzz_report.py turns the file into profiles/*.md)"""
 import os
@@ -19,7 +20,7 @@ from tests import gpu_util, parity_checks  # noqa: E402
 def one_case(rng):
     from tests.fuzz_cases import draw_case
 
-    desc, (cfg, vb, means, cov6, opac, colors, extra, gc, ge, cap) = draw_case(rng)
+    desc, (cfg, vb, means, cov6, opac, colors, extra, gc, ge, cap) = draw_case(rng, structure=os.environ.get("FUZZ_STRUCTURE", "random"))
     n, views, h, w = cfg.num_gaussians, cfg.num_views, cfg.height, cfg.width
     one_case.last = desc
     one_case.inputs = (cfg, vb, means, cov6, opac, colors, extra, gc, ge)
