@@ -2538,6 +2538,10 @@ __global__ __launch_bounds__(kFwdThreads, (kLds == 2048 && kGather && !kExtra) ?
 #ifndef GSR_PREFIX
 #define GSR_PREFIX 512
 #endif
+#ifndef GSR_DEPHASE_SLEEP
+#define GSR_DEPHASE_SLEEP 16  // s_sleep argument between the four de-phase groups of k_tile_fwd_prefix's first resident round (~0.5 us).
+#endif                        // Round 6, 0 / 8 / 16 / 32 / 48: headline 52.55 / 52.5 / 52.3 / 52.4 / 52.5 us, one 131 072-Gaussian view
+                              // 41.7 / 41.65 / 41.4 / 42.0 / 42.3, the same on the pixel-aligned scene 47.9 / 47.8 / 48.2 / 49.2 / 49.5
 #ifndef GSR_LONG_RUN
 #define GSR_LONG_RUN 24  // runs of more keys than this are copied by the whole workgroup (k_tile_fwd_prefix)
 #endif
@@ -2607,9 +2611,9 @@ __global__ __launch_bounds__(kFwdThreads, kCompact ? 6 : 4) void k_tile_fwd_pref
   const int tg = xcd_remap((int)bid, (int)p.sort_blocks);
   const int v = tg / T, t = tg - v * T;
   // (de-phasing of the first resident round: see sort_tile.  With this kernel's shorter gather 1 us between the four groups is
-  // enough: sleeps of 16 / 24 / 32 / 40 / 64 gave 53.0 / 52.9 / 53.0 / 53.0 / 53.9 us for the forward)
+  // enough: sleeps of 16 / 24 / 32 / 40 / 64 gave 53.0 / 52.9 / 53.0 / 53.0 / 53.9 us for the forward; round 6: 16 - GSR_DEPHASE_SLEEP)
   if (bid < 1024u)
-    for (int q = 0; q < (int)((bid >> kDephaseShift) % kDephaseGroups); ++q) __builtin_amdgcn_s_sleep(32);
+    for (int q = 0; q < (int)((bid >> kDephaseShift) % kDephaseGroups); ++q) __builtin_amdgcn_s_sleep(GSR_DEPHASE_SLEEP);
   // ---- gather: column (v, :, t) of the pair matrix, one row per thread
   uint2 e0 = make_uint2(0u, 0u);
   uint32_t bb0 = 0;
