@@ -1061,8 +1061,9 @@ def main():
                 pf3plat_amd.get_backend().check_pending(wait=True)
                 result["decoder_config4"] = {"workload": "DecoderSplattingCUDA.forward, B=1, G=131072, K=25, V=3, colour+depth (sync_policy lazy)",
                                              "ms_per_call": 1e3 * t4, "views_per_s": 3 / t4,
-                                             "device_time_of_the_call": "k_setup_views 4.8 us + binning and tile launches 83 us + the status block's 16-byte copy 4.9 us "
-                                                                        "(tools/decoder_call_profile.py: the call is device-bound, the host needs 28 us of it)"}
+                                             "device_time_of_the_call": "four dependent launches: k_setup_views (4.8 us) + binning and tile launches (~83 us) + the status block's "
+                                                                        "16-byte copy (a blit kernel, 4.9 us); tools/decoder_call_profile.py: the call is device-bound, the host needs "
+                                                                        "~28 us of it.  Round 6 measured three ways of dropping the copy and a shorter set-up kernel: docs/DEAD_ENDS.md"}
                 # ---- the same decoder call made the REFERENCE's way, unchanged (tests/reference_style.py restates its two functions:
                 # decoder_splatting_cuda.py:44-67 repeats every Gaussian tensor V times, cuda_splatting.py:64-127 pre-scales with torch
                 # ops, re-lays the harmonics out, and loops over the views in Python - two .item() syncs, a settings object and a

@@ -12,6 +12,8 @@ mkdir -p $O
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -m gpu -q > $O/pytest.log 2>&1
 tail -1 $O/pytest.log
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
+tail -1 $O/smoke.log
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
 tail -2 $O/bench.err
