@@ -989,6 +989,50 @@ def main():
                 result["roofline_config5_shard"] = shape_roofline(
                     shard131k_call(), False, "BASELINE configs[4], one GPU's shard through the plan API: one scene of 131072 Gaussians (seed 50), ONE target view 256x256, colour only",
                     "rocprofv3 averages of the same child run: profiles/r06_*_kernel_stats_shard131k.md")
+                # ---- PF3plat's TRAINING call shape: the decoder renders context + target views of every scene of the batch
+                # (model_wrapper.py:148-156: 3 views per scene; config/main.yaml:25: batch_size 4; the experiments use 14): B = 4 sets x 3
+                # views of 131 072 Gaussians, colour + depth, ONE launch chain - per call and per scene
+                def training_batch(b_sets):
+                    scs = [synthetic.make_scene(50 + b_, 131072, (H, W), d_sh=D_SH, num_views=3) for b_ in range(b_sets)]
+                    parts = [synthetic.scene_operator_inputs(sc_) for sc_ in scs]
+                    ins_b = tuple(torch.cat([p_[k_] for p_ in parts], 0).to(dev).contiguous() for k_ in range(4))
+                    vb_b = torch.cat([synthetic.scene_viewbuf(sc_).to(dev) for sc_ in scs], 0)
+                    v_b = 3 * b_sets
+                    out = {}
+                    for train in (False, True):
+                        fl = (_gl0.FLAG_BACKWARD_FOLLOWS if train else 0) | (1 << 4)
+                        cfg_b = RasterConfig(v_b, b_sets, 3, 131072, H, W, 4, D_SH, 4, True, fl)
+                        plan_b = be.make_plan(cfg_b, dev, capacity=8 * v_b * 131072, backward=train)
+                        be.run_forward(plan_b, vb_b, *ins_b)
+                        st_b = be.read_status(plan_b)
+                        plan_b = be.make_plan(cfg_b, dev, capacity=be.capacity_for(cfg_b, st_b, headroom=1.1), backward=train)
+                        gc_b = torch.rand((v_b, 3, H, W), device=dev)
+                        ge_b = torch.rand((v_b, H, W), device=dev)
+
+                        def one():
+                            be.run_forward(plan_b, vb_b, *ins_b)
+                            if train:
+                                be.run_backward(plan_b, vb_b, *ins_b, None, gc_b, ge_b)
+
+                        t_b = time_calls(one, 60, 20)
+                        assert not be.read_status(plan_b)["overflow"]
+                        # SURVEY 8d's bytes, set by set (each set's inputs charged once)
+                        fwd_b = bwd_b = 0
+                        for b_ in range(b_sets):
+                            sub = dict(plan_b, geom=plan_b["geom"][b_ * 3 * 131072 * 32:])
+                            nv_any_b, pv_b = multi_view_stats(sub, 131072, 3, H, W)
+                            f_, w_ = multi_view_bytes(131072, nv_any_b, pv_b, H * W, D_SH, extra=True)
+                            fwd_b += f_
+                            bwd_b += w_
+                        tot_b = fwd_b + (bwd_b if train else 0)
+                        out["train" if train else "fwd"] = {"ms_per_call": 1e3 * t_b, "ms_per_scene": 1e3 * t_b / b_sets, "algorithmic_bytes": tot_b,
+                                                             "frac": tot_b / t_b / 1e9 / HBM_PEAK_GBS, "num_pairs_8x8": st_b["num_pairs"]}
+                        del plan_b
+                    out["workload"] = (f"PF3plat's training decoder call through the plan API: B = {b_sets} scenes (seeds 50 ...) x 3 views of 131072 Gaussians, colour + "
+                                       "built-in depth, one launch chain (reference model_wrapper.py:148-156, config/main.yaml:25)")
+                    return out
+
+                result["training_batch_4_scenes"] = training_batch(4)
                 # ---- two calls in flight (NOT the headline): the headline step alternating between two HIP streams, each with its own
                 # workspaces and output - the tail of one call's tile launch may run under the head of the next call's binning launch.
                 # What cross-call overlap buys with the kernels as they are (a binning workgroup owns its CU: DESIGN 8)
