@@ -182,6 +182,26 @@ def test_config4_full_size_on_the_pixel_aligned_scene_the_encoder_emits():
     assert st is None or not st["overflow"]
 
 
+def test_training_batch_of_four_scenes_x_three_views_full_size_colour_and_depth():
+    """The call PF3plat's TRAINING step makes (reference src/model/model_wrapper.py:148-156 renders every scene of the batch in one decoder
+    call; config/main.yaml:25 batch_size 4): B = 4 sets x 3 views of 131 072 Gaussians, colour + built-in depth, one launch chain -
+    two independently drawn scenes and two pixel-aligned ones in the same call, each set with its own near plane (scale-invariant
+    factor), forward and backward against the oracle, strict."""
+    n, hw = 131072, (256, 256)
+    scs = [synthetic.make_scene(60 + b, n, hw, num_views=3, near=(1.0, 2.0, 0.5, 1.0)[b], structure=("random", "pixel_aligned")[b & 1])
+           for b in range(4)]
+    parts = [gpu_util.scene_tensors(sc) for sc in scs]
+    means, cov6, opac, colors = (torch.cat([p_[k] for p_ in parts]) for k in range(4))
+    vb = torch.cat([gpu_util.scene_viewbuf(sc) for sc in scs])
+    cfg = RasterConfig(12, 4, 3, n, 256, 256, 4, 25, 4, True, 1 << 4)
+    rng = np.random.default_rng(60)
+    gc = torch.tensor(rng.uniform(0, 1, (12, 3, 256, 256)).astype(np.float32))
+    ge = torch.tensor(rng.uniform(0, 1, (12, 256, 256)).astype(np.float32))
+    res = gpu_util.run_both(cfg, vb, means, cov6, opac, colors, None, gc, ge)
+    _all_checks(cfg, res, max_tiles=16, strict=True)
+    assert all(st.n_visible > 100000 for st in res["oracle"]["stats"])
+
+
 def test_pixel_aligned_scene_small_source_grid_and_ragged_views():
     """The same structure at a small size (a 24 x 40 source grid: 1920 Gaussians), rendered into two views of a different shape:
     generator arguments, long runs on a small grid, strict."""
