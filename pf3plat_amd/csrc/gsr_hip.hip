@@ -130,6 +130,13 @@ constexpr int kChunkPrefer = 1600;
 // workgroups sit two to a CU (LDS in 1280-byte steps: images of up to 1496 tiles).
 static bool color_in_bin_by_dims(const GsrDims& d, const Grid& g);
 static bool bin_two_per_cu(const Grid& g, bool color_in_bin);
+// A round of binning workgroups costs its chunk AND a fixed part (prologue, scan, pair walk, copy-out: ~6 of the 23 us a 1600-Gaussian
+// workgroup lives) - in Gaussians.  It only decides between chunk sizes that need different numbers of rounds: PF3plat's training batch
+// (4 scenes x 3 views x 131 072: 984 workgroups of 1600 in four rounds, against 1536 of 1024 in six as the plain product chose) forward
+// 300 -> 292 us; 0 / 400 / 800 measured, forced 1344 / 1408 / 1472 (whole passes of the eleven binning waves) are slower than 1600.
+#ifndef GSR_CHUNK_FIXED
+#define GSR_CHUNK_FIXED 400
+#endif
 static int choose_chunk(const GsrDims& d) {
   const long long V = d.num_views > 0 ? d.num_views : 1, N = d.num_gaussians > 0 ? d.num_gaussians : 1;
   const Grid g = make_grid(d.width, d.height);
@@ -138,7 +145,7 @@ static int choose_chunk(const GsrDims& d) {
   long long best_cost = -1;
   int best = kChunkPrefer;
   for (int c = kChunkPrefer; c >= kChunkSmall; c -= 64) {
-    const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + slots - 1) / slots) * c;
+    const long long blocks = V * ((N + c - 1) / c), cost = ((blocks + slots - 1) / slots) * (c + GSR_CHUNK_FIXED);
     // chunks below kChunkMin only while a single round of workgroups holds them all: one 131 072-Gaussian view (configs[4]'s share of
     // a GPU, PF3plat's native size) took 128 workgroups of 1024 - half the chip idle through the whole binning launch (19.5 us); 256
     // workgroups of 512 are one projection pass per wave instead of two.  With several rounds the per-workgroup prologue, scan and

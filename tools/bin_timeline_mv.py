@@ -33,7 +33,7 @@ for _ in range(4):
 torch.cuda.synchronize()
 lay = be.workspace_layout(plan["dims"])
 slots = 512 if V > 4 else 256  # (two plain binning workgroups per CU for images of up to 1496 tiles: choose_chunk in gsr_hip.hip)
-chunk = min(range(1600, 1023, -64), key=lambda c: ((V * ((n + c - 1) // c) + slots - 1) // slots) * c)
+chunk = min(range(1600, 1023, -64), key=lambda c: ((V * ((n + c - 1) // c) + slots - 1) // slots) * (c + 400))
 rows = (n + chunk - 1) // chunk
 cap = int(plan["dims"].pair_capacity)
 end = lay["keys"] + (V * rows * (8192 + 136) + ((cap + 1023) // 1024 + 64) * 1024) * 8

@@ -1,7 +1,7 @@
 """Measurement aid (GPU box): PF3plat's TRAINING call shape - B scenes x 3 views (context + target views of every scene of the batch:
 reference src/model/model_wrapper.py:148-156, config/main.yaml:25 batch_size 4, config/experiment/re10k.yaml:14 batch_size 14) of 131 072
 Gaussians each, colour + depth, through the plan API: forward and training step per call and per scene, for B = 1, 2, 4, 8, 14.
-usage: python tools/exp_batch.py [structure = random | pixel_aligned]"""
+usage: python tools/exp_batch.py [structure = random | pixel_aligned] [batch sizes = 1,2,4,8,14]"""
 import os
 import sys
 import time
@@ -34,7 +34,7 @@ def timed(step, reps, warm):
     return best * 1e6
 
 
-for B in (1, 2, 4, 8, 14):
+for B in (tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 2, 4, 8, 14)):
     scs = [synthetic.make_scene(50 + b, N, (H, W), num_views=VPS, structure=structure) for b in range(B)]
     parts = [synthetic.scene_operator_inputs(sc) for sc in scs]
     ins = tuple(torch.cat([p[k] for p in parts], 0).to(dev).contiguous() for k in range(4))

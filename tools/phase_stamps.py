@@ -8,6 +8,8 @@
 
 usage: python tools/phase_stamps.py <label> [-D...]      shape from the environment:
   PS_N (131072)  PS_V (3)  PS_SEED (50)  PS_EXTRA (1: colour + built-in depth)  PS_TRAIN (0)  PS_STRUCT (random | pixel_aligned)
+  PS_SETS (1): that many scenes (seeds PS_SEED ...) of PS_V views each in ONE call - K1's binning workgroups only (the stamp slots of
+               the colour units and of the tile launch are laid out for one set)
   GSR_KEEP_LIB=1: use tools/libgsr_hip_ablate.so as built (cross-compiled before the GPU call)
 """
 import os
@@ -36,7 +38,7 @@ def choose_chunk(n, v, slots=256):
     best, best_cost = 1600, None
     for c in range(1600, 511, -64):
         blocks = v * -(-n // c)
-        cost = -(-blocks // slots) * c
+        cost = -(-blocks // slots) * (c + 400)  # GSR_CHUNK_FIXED
         if c < 1024 and blocks > slots:
             break
         if best_cost is None or cost < best_cost:
@@ -65,11 +67,14 @@ def main():
     kw = {}
     if struct != "random":
         kw["structure"] = struct
-    sc = synthetic.make_scene(seed, n, (H, W), d_sh=25, num_views=V, view_offsets=None, **kw)
-    ins = tuple(t.to(dev).contiguous() for t in synthetic.scene_operator_inputs(sc))
-    vb = synthetic.scene_viewbuf(sc).to(dev)
+    sets = int(os.environ.get("PS_SETS", 1))
+    scs = [synthetic.make_scene(seed + b_, n, (H, W), d_sh=25, num_views=V, view_offsets=None, **kw) for b_ in range(sets)]
+    parts = [synthetic.scene_operator_inputs(sc) for sc in scs]
+    ins = tuple(torch.cat([p_[k] for p_ in parts], 0).to(dev).contiguous() for k in range(4))
+    vb = torch.cat([synthetic.scene_viewbuf(sc).to(dev) for sc in scs], 0)
     fl = (_lib.FLAG_BACKWARD_FOLLOWS if train else 0) | (extra << 4)
-    cfg = RasterConfig(V, 1, V, n, H, W, 4, 25, 4, bool(extra), fl)
+    Vs, V = V, V * sets
+    cfg = RasterConfig(V, sets, Vs, n, H, W, 4, 25, 4, bool(extra), fl)
     be = HipBackend()
     plan = be.make_plan(cfg, dev, capacity=8 * V * n, backward=bool(train))
     be.run_forward(plan, vb, *ins)
@@ -113,6 +118,15 @@ def main():
     print("  binning workgroups, phase END (us from the first start): max", [round((b[:, k].max() - t0).item(), 2) for k in range(5)],
           "| median", [round(torch.median(b[:, k] - t0).item(), 2) for k in range(5)], "  =", names)
     print("  phase DURATIONS, quantiles 0/10/50/90/100:", {names[k]: q(b[:, k] - b[:, k - 1]) for k in range(1, 5)})
+    if sets > 1:  # multi-round launch: when does a workgroup start, how long does it live, by the order of its start
+        order = torch.argsort(b[:, 0])
+        st_, life = (b[order, 0] - t0), (b[order, 4] - b[order, 0])
+        for r0 in range(0, wgs, 256):
+            sl_ = slice(r0, min(wgs, r0 + 256))
+            print(f"  workgroups {r0}-{sl_.stop - 1} by start: start {q(st_[sl_])} | lifetime {q(life[sl_])} | projection {q((b[order, 1] - b[order, 0])[sl_])}"
+                  f" | scan {q((b[order, 2] - b[order, 1])[sl_])} | walk {q((b[order, 3] - b[order, 2])[sl_])} | copy-out {q((b[order, 4] - b[order, 3])[sl_])}")
+        print(f"  K1's last binning wave ends {round((b[:, 4].max() - t0).item(), 2)} us after the first start")
+        return
     units = (n + 63) // 64
     c = slots(16384, units)
     ok = c[:, 3] > 0
