@@ -66,6 +66,28 @@ def test_workspace_sizes_and_validation():
     assert lib.gsr_backward(ctypes.byref(bad), *([None] * 19)) == -1
 
 
+def test_binning_chunk_follows_the_shape_of_the_call():
+    """Gaussians per binning workgroup (choose_chunk, csrc/gsr_hip.hip), read back from the layout: the pair matrix holds views x rows x
+    (tiles + 8) entries of 8 bytes between `counts` and `tile_total`.  One round of workgroups on the 256 CUs where it exists (the
+    headline: 247 of 1216; configs[3]: 82 x 3 of 1600; one 131 072-Gaussian view: 256 of 512) - and for calls of several rounds (PF3plat's
+    training batch: 4 scenes x 3 views) the chunk whose rounds cost least with the fixed part of a round counted: 1600, not 1024."""
+    be = rasterizer.HipBackend()
+
+    def rows(views, sets, n):
+        dims = be._dims(rasterizer.RasterConfig(views, sets, views // sets, n, 256, 256, 4, 25, 4, False), 8 * views * n)
+        lay = be.workspace_layout(dims)
+        per_row = (1024 + 8) * 8
+        r = (lay["tile_total"] - lay["counts"]) // (views * per_row)
+        assert 0 <= (lay["tile_total"] - lay["counts"]) - r * views * per_row < 256  # (the region is padded to 256 bytes)
+        return r
+
+    assert rows(1, 1, 300000) == 247       # chunk 1216
+    assert rows(3, 1, 131072) == 82        # chunk 1600: 246 workgroups, one round
+    assert rows(1, 1, 131072) == 256       # chunk 512: one round of small workgroups
+    assert rows(12, 4, 131072) == 82       # four rounds of 1600 (six rounds of 1024 measured slower)
+    assert rows(6, 2, 131072) == 82
+
+
 def test_flag_bits_are_validated_and_ablation_switches_are_not_in_the_product_library():
     """Unknown GsrDims.flags bits are rejected; the measurement-only ablation / phase-stamp switches (0x100 .. 0x2000, only in
     a -DGSR_ABLATE build made by tools/ablate.py) are unknown bits to the shipped library; extra modes above 4 do not exist."""
