@@ -202,6 +202,36 @@ def test_training_batch_of_four_scenes_x_three_views_full_size_colour_and_depth(
     assert all(st.n_visible > 100000 for st in res["oracle"]["stats"])
 
 
+def test_batch_of_fourteen_scenes_equals_its_fourteen_single_scene_calls_bit_for_bit():
+    """A size-independent property at the batch size the reference's experiments train with (config/experiment/re10k.yaml:14: 14
+    scenes x 3 views of 131 072 Gaussians, colour + built-in depth): one call over the batch returns, scene by scene, the BITS of the
+    fourteen calls that render a scene alone - image, depth, radii, and (deterministic backward: integer sums, order-free) every
+    gradient.  The batch takes other binning chunks, other workgroup counts and several resident rounds; none of it may show."""
+    from pf3plat_amd import _lib
+
+    b_sets, n, hw = 14, 131072, (256, 256)
+    flags = (1 << 4) | _lib.FLAG_DETERMINISTIC
+    scs = [synthetic.make_scene(80 + b, n, hw, num_views=3, structure=("random", "pixel_aligned")[b & 1]) for b in range(b_sets)]
+    parts = [gpu_util.scene_tensors(sc) for sc in scs]
+    vbs = [gpu_util.scene_viewbuf(sc) for sc in scs]
+    rng = np.random.default_rng(80)
+    gc = torch.tensor(rng.uniform(0, 1, (3 * b_sets, 3, 256, 256)).astype(np.float32))
+    ge = torch.tensor(rng.uniform(0, 1, (3 * b_sets, 256, 256)).astype(np.float32))
+    cfg_b = RasterConfig(3 * b_sets, b_sets, 3, n, 256, 256, 4, 25, 4, True, flags)
+    whole = gpu_util.run_hip(cfg_b, torch.cat(vbs), *(torch.cat([p_[k] for p_ in parts]) for k in range(4)), None, gc, ge)
+    assert not whole["status"]["overflow"]
+    cfg_1 = RasterConfig(3, 1, 3, n, 256, 256, 4, 25, 4, True, flags)
+    for b in range(b_sets):
+        one = gpu_util.run_hip(cfg_1, vbs[b], *parts[b], None, gc[3 * b: 3 * b + 3], ge[3 * b: 3 * b + 3])
+        v = slice(3 * b, 3 * b + 3)
+        assert np.array_equal(whole["color"][v].view(np.uint32), one["color"].view(np.uint32)), b
+        assert np.array_equal(whole["extra"][v].view(np.uint32), one["extra"].view(np.uint32)), b
+        assert np.array_equal(whole["radii"][v], one["radii"]), b
+        for name in ("means", "cov6", "opac", "colors"):
+            assert np.array_equal(whole["grads"][name][b: b + 1].view(np.uint32), one["grads"][name].view(np.uint32)), (b, name)
+        assert np.array_equal(whole["grads"]["means2d"][v].view(np.uint32), one["grads"]["means2d"].view(np.uint32)), b
+
+
 def test_pixel_aligned_scene_small_source_grid_and_ragged_views():
     """The same structure at a small size (a 24 x 40 source grid: 1920 Gaussians), rendered into two views of a different shape:
     generator arguments, long runs on a small grid, strict."""
